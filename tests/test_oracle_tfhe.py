@@ -1,0 +1,127 @@
+"""The exact CPU PBS oracle (oracle/tfhe_oracle.c): self-consistency pins.
+Ciphertext-level parity with Concrete is unpinned (Concrete is absent); these pins are
+(1) NTT == schoolbook, (2) decrypt(PBS(enc m)) == LUT[m] for all m, (3) noise within budget."""
+import numpy as np
+import pytest
+
+from oracle import tfhe_oracle as to
+
+Q = to.Q
+RNG = np.random.default_rng(42)
+
+
+def rand_q(n):
+    v = RNG.integers(0, 2**63, n, dtype=np.uint64) * np.uint64(2) + RNG.integers(0, 2, n, dtype=np.uint64)
+    return np.where(v >= np.uint64(Q), v - np.uint64(Q), v)
+
+
+@pytest.mark.parametrize("logN", [2, 4, 6, 8])
+def test_ntt_matches_schoolbook(logN):
+    a, b = rand_q(1 << logN), rand_q(1 << logN)
+    assert np.array_equal(to.negacyclic(logN, a, b), to.negacyclic(logN, a, b, schoolbook=True))
+    # edge: X^(N-1) * X = -1
+    N = 1 << logN
+    e1 = np.zeros(N, np.uint64); e1[N - 1] = 1
+    e2 = np.zeros(N, np.uint64); e2[1] = 1
+    c = to.negacyclic(logN, e1, e2)
+    assert int(c[0]) == Q - 1 and not c[1:].any()
+
+
+def test_decompose_recomposes():
+    for levels, bl in [(3, 15), (8, 4), (2, 8), (1, 23)]:
+        for a in list(rand_q(200)) + [0, 1, Q - 1, Q // 2, Q // 2 + 1, (1 << 63) - 1]:
+            d = to.decompose(a, levels, bl)
+            assert all(-(1 << (bl - 1)) <= int(x) < (1 << (bl - 1)) for x in d[1:])
+            assert -(1 << (bl - 1)) <= int(d[0]) <= (1 << (bl - 1))
+            rec = sum(int(d[i]) << (64 - bl * (i + 1)) for i in range(levels))
+            c = int(a) if int(a) <= Q // 2 else int(a) - Q
+            err = rec - c
+            assert abs(err) <= 1 << (63 - levels * bl), (a, d, err)  # exact: the top digit absorbs the carry
+
+
+def test_modswitch():
+    for a in list(rand_q(200)) + [0, Q - 1, Q // 2]:
+        for lg in (5, 11, 13):
+            assert to.modswitch(a, lg) == ((int(a) * (1 << lg) + Q // 2) // Q) % (1 << lg)
+
+
+def small_params():
+    return to.default_params(n=16, log_N=8, bs_levels=3, bs_base_log=15, ks_levels=8, ks_base_log=4,
+                             lwe_noise=2.0 ** -40, glwe_noise=2.0 ** -50)
+
+
+def test_keygen_structure():
+    P = small_params()
+    K = to.keygen(P, 7)
+    K2 = to.keygen(P, 7)
+    assert np.array_equal(K.bsk, K2.bsk) and np.array_equal(K.ksk, K2.ksk)
+    assert set(np.unique(K.sk_small)) <= {0, 1} and set(np.unique(K.sk_big)) <= {0, 1}
+    assert (K.bsk < np.uint64(Q)).all() and (K.ksk < np.uint64(Q)).all()
+    # every KSK row decrypts to sk_big[j] * 2^(64 - 4*(lev+1)) up to noise
+    ph = to.lwe_phase(K.sk_small, K.ksk.reshape(-1, P.n + 1)).reshape(P.k * P.N, P.ks_levels)
+    for j in range(0, P.k * P.N, 7):
+        for lev in range(P.ks_levels):
+            want = int(K.sk_big[j]) << (64 - 4 * (lev + 1))
+            got = int(ph[j, lev])
+            err = (got - want) % Q
+            err = err - Q if err > Q // 2 else err
+            assert abs(err) < 2 ** 30
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+def test_pbs_evaluates_every_lut_entry(p):
+    P = small_params()  # N = 256, n = 16: box half-width 8 positions vs mod-switch sigma ~0.9
+    K = to.keygen(P, 11 + p)
+    ctx = to.Ctx(P, K.bsk, K.ksk)
+    M = 1 << p
+    msgs = np.arange(-M // 2, M // 2)
+    table = np.array([(3 * m * m - 5 * m + 1) % M - M // 2 for m in msgs], dtype=np.int64)
+    dl = 63 - p
+    tv = to.make_test_vector(P.log_N, p, table, dl)
+    ct = to.lwe_encrypt(K.sk_big, P.glwe_noise, 99, 0, to.encode(msgs, dl))
+    assert list(to.decode(to.lwe_phase(K.sk_big, ct), dl)) == list(msgs)
+    out, ks = ctx.pbs(ct, tv, np.zeros(M, np.uint32), want_ks=True)
+    assert list(to.decode(to.lwe_phase(K.sk_small, ks), dl)) == list(msgs)  # keyswitch keeps the message
+    assert np.array_equal(ks, ctx.keyswitch(ct))
+    assert np.array_equal(out, ctx.blind_rotate(ks, tv, np.zeros(M, np.uint32)))
+    assert list(to.decode(to.lwe_phase(K.sk_big, out), dl)) == list(table)
+    # output noise well inside half a box
+    ph = to.lwe_phase(K.sk_big, out)
+    for x, f in zip(ph, table):
+        e = (int(x) - (int(f) << dl)) % Q
+        e = e - Q if e > Q // 2 else e
+        assert abs(e) < 2 ** (dl - 8)
+
+
+def test_pbs_default_params_identity_and_sign():
+    P = to.default_params()
+    assert (P.n, P.N, P.k, P.bs_levels) == (630, 1024, 1, 3)  # BASELINE.json north-star set
+    K = to.keygen(P, 0x5EED)
+    ctx = to.Ctx(P, K.bsk, K.ksk)
+    p, dl = 4, 59
+    msgs = np.array([-8, -3, 0, 5, 7])
+    ident = np.arange(-8, 8, dtype=np.int64)
+    neg = np.array([1 if m < 0 else 0 for m in range(-8, 8)], dtype=np.int64)
+    tvs = np.stack([to.make_test_vector(10, p, ident, dl), to.make_test_vector(10, p, neg, dl)])
+    ct = to.lwe_encrypt(K.sk_big, P.glwe_noise, 5, 0, to.encode(msgs, dl))
+    cts = np.concatenate([ct, ct])
+    ids = np.array([0] * 5 + [1] * 5, np.uint32)
+    out = ctx.pbs(cts, tvs, ids)
+    got = to.decode(to.lwe_phase(K.sk_big, out), dl)
+    assert list(got[:5]) == list(msgs)
+    assert list(got[5:]) == [1, 1, 0, 0, 0]
+
+
+def test_lincomb():
+    P = small_params()
+    K = to.keygen(P, 3)
+    dl = 59
+    msgs = np.array([1, -2, 3, 0])
+    ct = to.lwe_encrypt(K.sk_big, P.glwe_noise, 1, 0, to.encode(msgs, dl))
+    # row0 = 2*c0 - c1 + 1 ; row1 = c2 + c3 - c0 ; row2 = const -4
+    row_ptr = [0, 2, 5, 5]
+    idx = [0, 1, 2, 3, 0]
+    coef = [2, -1, 1, 1, -1]
+    consts = to.encode([1, 0, -4], dl)
+    out = to.lincomb(P.big, ct, row_ptr, idx, coef, consts)
+    assert list(to.decode(to.lwe_phase(K.sk_big, out), dl)) == [5, 2, -4]
