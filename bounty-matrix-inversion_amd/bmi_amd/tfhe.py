@@ -1,0 +1,269 @@
+"""ctypes binding of the C ABI in include/bmi_tfhe.h (libbmi_tfhe.so).
+
+This is the binding a maintainer of the reference would add in place of concrete-python's Circuit
+object (reference call sites: matrix_inversion/main.py:53-86,177).  It fails loudly when the HIP
+library is missing: the PBS path has no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libbmi_tfhe.so")
+Q = 0xFFFFFFFF00000001
+
+
+class Params(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("log_N", C.c_uint32), ("k", C.c_uint32), ("bs_levels", C.c_uint32),
+                ("bs_base_log", C.c_uint32), ("ks_levels", C.c_uint32), ("ks_base_log", C.c_uint32),
+                ("reserved", C.c_uint32), ("lwe_noise", C.c_double), ("glwe_noise", C.c_double)]
+
+    @property
+    def N(self):
+        return 1 << self.log_N
+
+    @property
+    def big(self):
+        return self.k * self.N + 1
+
+    @property
+    def small(self):
+        return self.n + 1
+
+
+class BmiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_U64P = C.POINTER(C.c_uint64)
+_SIGS = {
+    "bmi_default_params": [C.POINTER(Params)],
+    "bmi_ctx_create": [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)],
+    "bmi_get_params": [C.c_void_p, C.POINTER(Params)],
+    "bmi_keygen": [C.c_void_p, C.c_uint64],
+    "bmi_export_keys": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "bmi_encrypt": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p],
+    "bmi_decrypt": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p],
+    "bmi_phase": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
+    "bmi_lut_register": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)],
+    "bmi_lut_get": [C.c_void_p, C.c_uint32, C.c_void_p],
+    "bmi_pbs_batch": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p],
+    "bmi_keyswitch_batch": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p],
+    "bmi_blind_rotate_batch": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p],
+    "bmi_lincomb_batch": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                          C.c_void_p, C.c_void_p],
+    "bmi_pbs_batch_host": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
+    "bmi_keyswitch_batch_host": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
+    "bmi_blind_rotate_batch_host": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
+    "bmi_negacyclic_mul_host": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
+    "bmi_sync": [C.c_void_p, C.c_void_p],
+    "bmi_set_kernel_variant": [C.c_void_p, C.c_int],
+    "bmi_key_bytes": [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+}
+
+
+def _load_hip_runtime():
+    """libbmi_tfhe.so is linked without a HIP runtime of its own (-no-hip-rt): it binds to the one already
+    in the process.  PyTorch-ROCm bundles its own libamdhip64.so, and two HIP runtimes in one process cannot
+    both own the GPU, so prefer torch's copy when torch is installed; otherwise use the system ROCm."""
+    cands = []
+    try:
+        import torch  # noqa: F401  (plumbing only: device memory / streams / torch.distributed)
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    cands += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    errs = []
+    for c in cands:
+        try:
+            return C.CDLL(c, mode=C.RTLD_GLOBAL)
+        except OSError as e:
+            errs.append(f"{c}: {e}")
+    raise BmiError("no HIP runtime (libamdhip64.so) could be loaded: " + "; ".join(errs))
+
+
+def load_library():
+    """Loads libbmi_tfhe.so; raises BmiError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BmiError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(make -C bounty-matrix-inversion_amd/csrc). There is no CPU fallback for the PBS path.")
+        _load_hip_runtime()
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        lib.bmi_ctx_destroy.argtypes = [C.c_void_p]
+        lib.bmi_ctx_destroy.restype = None
+        lib.bmi_last_error.argtypes = [C.c_void_p]
+        lib.bmi_last_error.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+def default_params(**kw):
+    P = Params()
+    load_library().bmi_default_params(C.byref(P))
+    for k, v in kw.items():
+        setattr(P, k, v)
+    return P
+
+
+def _ptr(a):
+    """host numpy array / torch tensor (host or device) / int -> raw address"""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return C.c_void_p(a.ctypes.data)
+    if hasattr(a, "data_ptr"):
+        assert a.is_contiguous()
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(type(a))
+
+
+class Engine:
+    """One context = crypto parameters + keys + one GPU (reference analogue: a compiled fhe.Circuit)."""
+
+    def __init__(self, params=None, device=0):
+        self.lib = load_library()
+        self.P = params if params is not None else default_params()
+        h = C.c_void_p()
+        rc = self.lib.bmi_ctx_create(C.byref(self.P), int(device), C.byref(h))
+        if rc != 0:
+            raise BmiError(f"bmi_ctx_create failed ({rc}): {self.lib.bmi_last_error(None).decode()}")
+        self.h = h
+        self.device = device
+        self._luts = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bmi_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise BmiError(f"{what} failed ({rc}): {self.lib.bmi_last_error(self.h).decode()}")
+
+    # ---- keys
+    def keygen(self, seed=0x5EED):
+        self._ck(self.lib.bmi_keygen(self.h, C.c_uint64(seed)), "bmi_keygen")
+
+    def export_keys(self):
+        P = self.P
+        rows = (P.k + 1) * P.bs_levels
+        sk_small = np.zeros(P.n, np.uint64)
+        sk_big = np.zeros(P.k * P.N, np.uint64)
+        bsk = np.zeros((P.n, rows, P.k + 1, P.N), np.uint64)
+        ksk = np.zeros((P.k * P.N, P.ks_levels, P.n + 1), np.uint64)
+        self._ck(self.lib.bmi_export_keys(self.h, _ptr(sk_small), _ptr(sk_big), _ptr(bsk), _ptr(ksk)), "bmi_export_keys")
+        return sk_small, sk_big, bsk, ksk
+
+    def key_bytes(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.bmi_key_bytes(self.h, C.byref(a), C.byref(b)), "bmi_key_bytes")
+        return a.value, b.value
+
+    # ---- encrypt / decrypt (host buffers)
+    def encrypt(self, msgs, delta_log):
+        msgs = np.ascontiguousarray(msgs, dtype=np.int64).reshape(-1)
+        out = np.zeros((msgs.size, self.P.big), np.uint64)
+        self._ck(self.lib.bmi_encrypt(self.h, _ptr(msgs), msgs.size, delta_log, _ptr(out)), "bmi_encrypt")
+        return out
+
+    def decrypt(self, cts, delta_log):
+        cts = np.ascontiguousarray(cts, dtype=np.uint64).reshape(-1, self.P.big)
+        out = np.zeros(cts.shape[0], np.int64)
+        self._ck(self.lib.bmi_decrypt(self.h, _ptr(cts), cts.shape[0], delta_log, _ptr(out)), "bmi_decrypt")
+        return out
+
+    def phase(self, cts):
+        cts = np.ascontiguousarray(cts, dtype=np.uint64).reshape(-1, self.P.big)
+        out = np.zeros(cts.shape[0], np.uint64)
+        self._ck(self.lib.bmi_phase(self.h, _ptr(cts), cts.shape[0], _ptr(out)), "bmi_phase")
+        return out
+
+    # ---- LUTs
+    def lut_register(self, table, msg_bits, out_delta_log):
+        table = np.ascontiguousarray(table, dtype=np.int64).reshape(-1)
+        if table.size != 1 << msg_bits:
+            raise ValueError("table must have 2^msg_bits entries")
+        key = (table.tobytes(), msg_bits, out_delta_log)
+        if key in self._luts:
+            return self._luts[key]
+        lid = C.c_uint32()
+        self._ck(self.lib.bmi_lut_register(self.h, _ptr(table), msg_bits, out_delta_log, C.byref(lid)), "bmi_lut_register")
+        self._luts[key] = lid.value
+        return lid.value
+
+    def lut_get(self, lut_id):
+        tv = np.zeros(self.P.N, np.uint64)
+        self._ck(self.lib.bmi_lut_get(self.h, lut_id, _ptr(tv)), "bmi_lut_get")
+        return tv
+
+    def set_kernel_variant(self, v):
+        self._ck(self.lib.bmi_set_kernel_variant(self.h, int(v)), "bmi_set_kernel_variant")
+
+    # ---- hot path, host buffers (numpy in / numpy out)
+    def pbs_host(self, cts, lut_ids):
+        cts = np.ascontiguousarray(cts, dtype=np.uint64).reshape(-1, self.P.big)
+        ids = np.ascontiguousarray(lut_ids, dtype=np.uint32).reshape(-1)
+        assert ids.size == cts.shape[0]
+        out = np.zeros_like(cts)
+        self._ck(self.lib.bmi_pbs_batch_host(self.h, _ptr(cts), _ptr(ids), cts.shape[0], _ptr(out)), "bmi_pbs_batch_host")
+        return out
+
+    def keyswitch_host(self, cts):
+        cts = np.ascontiguousarray(cts, dtype=np.uint64).reshape(-1, self.P.big)
+        out = np.zeros((cts.shape[0], self.P.small), np.uint64)
+        self._ck(self.lib.bmi_keyswitch_batch_host(self.h, _ptr(cts), cts.shape[0], _ptr(out)), "bmi_keyswitch_batch_host")
+        return out
+
+    def blind_rotate_host(self, small, lut_ids):
+        small = np.ascontiguousarray(small, dtype=np.uint64).reshape(-1, self.P.small)
+        ids = np.ascontiguousarray(lut_ids, dtype=np.uint32).reshape(-1)
+        out = np.zeros((small.shape[0], self.P.big), np.uint64)
+        self._ck(self.lib.bmi_blind_rotate_batch_host(self.h, _ptr(small), _ptr(ids), small.shape[0], _ptr(out)),
+                 "bmi_blind_rotate_batch_host")
+        return out
+
+    def negacyclic_mul_host(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, self.P.N)
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, self.P.N)
+        c = np.zeros_like(a)
+        self._ck(self.lib.bmi_negacyclic_mul_host(self.h, _ptr(a), _ptr(b), a.shape[0], _ptr(c)), "bmi_negacyclic_mul_host")
+        return c
+
+    # ---- hot path, device buffers (torch int64 tensors viewed as uint64 words; `stream` = raw hipStream_t)
+    def pbs(self, d_in, d_lut_ids, count, d_out, stream=0):
+        self._ck(self.lib.bmi_pbs_batch(self.h, _ptr(d_in), _ptr(d_lut_ids), count, _ptr(d_out), C.c_void_p(stream)),
+                 "bmi_pbs_batch")
+
+    def keyswitch(self, d_in, count, d_small, stream=0):
+        self._ck(self.lib.bmi_keyswitch_batch(self.h, _ptr(d_in), count, _ptr(d_small), C.c_void_p(stream)),
+                 "bmi_keyswitch_batch")
+
+    def blind_rotate(self, d_small, d_lut_ids, count, d_out, stream=0):
+        self._ck(self.lib.bmi_blind_rotate_batch(self.h, _ptr(d_small), _ptr(d_lut_ids), count, _ptr(d_out),
+                                                 C.c_void_p(stream)), "bmi_blind_rotate_batch")
+
+    def lincomb(self, d_store, d_row_ptr, d_idx, d_coef, d_const, count, d_out, stream=0):
+        self._ck(self.lib.bmi_lincomb_batch(self.h, _ptr(d_store), _ptr(d_row_ptr), _ptr(d_idx), _ptr(d_coef),
+                                            _ptr(d_const), count, _ptr(d_out), C.c_void_p(stream)), "bmi_lincomb_batch")
+
+    def sync(self, stream=0):
+        self._ck(self.lib.bmi_sync(self.h, C.c_void_p(stream)), "bmi_sync")

@@ -1,0 +1,523 @@
+// Host side of libbmi_tfhe.so: the C ABI of include/bmi_tfhe.h — context, deterministic key
+// generation, encryption / decryption, LUT (test-polynomial) construction and the batch entry points
+// that launch the HIP kernels of bmi_kernels.hip.  No CPU fallback exists for the PBS path: every
+// batch call needs a HIP device and fails loudly without one.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/bmi_tfhe.h"
+#include "bmi_internal.hpp"
+#include "ntt_wave.hpp"
+
+using gl::i64;
+using gl::u64;
+
+namespace {
+
+// --------------------------------------------------------------------------- deterministic RNG
+// Counter-based splitmix64 (same specification as the oracle so that key generation can be
+// cross-checked bit for bit): value(stream, idx) = mix(stream_key + (idx + 1) * GOLDEN).
+inline u64 mix64(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+struct Stream {
+    u64 key;
+    Stream(u64 seed, u64 id) : key(mix64(seed ^ (id * 0xD6E8FEB86659FD93ULL))) {}
+    u64 raw(u64 idx) const { return mix64(key + (idx + 1) * 0x9E3779B97F4A7C15ULL); }
+    u64 bit(u64 idx) const { return raw(idx) & 1; }
+    u64 uniform(u64 idx) const {
+        u64 u = raw(idx);
+        return u >= gl::P ? u - gl::P : u;
+    }
+    u64 gauss(u64 idx, double sigma) const {  // Box-Muller, rounded to an element of Z_q
+        const double u1 = (double)((raw(2 * idx) >> 11) + 1) * (1.0 / 9007199254740992.0);
+        const double u2 = (double)(raw(2 * idx + 1) >> 11) * (1.0 / 9007199254740992.0);
+        const double g = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586476925286766559 * u2);
+        const long long e = std::llround(g * sigma * 18446744073709551616.0);
+        return e >= 0 ? (u64)e % gl::P : gl::P - ((u64)(-e) % gl::P);
+    }
+};
+enum : u64 { S_SK_SMALL = 1, S_SK_BIG, S_BSK_MASK, S_BSK_NOISE, S_KSK_MASK, S_KSK_NOISE, S_ENC_MASK, S_ENC_NOISE };
+
+thread_local std::string g_create_error;
+
+u64 pow_mod(u64 b, u64 e) {
+    u64 r = 1;
+    while (e) {
+        if (e & 1) r = gl::mul(r, b);
+        b = gl::mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+
+template <class F>
+void parallel_for(size_t n, F f) {
+    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    if (n < 4 * nt) nt = 1;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([=]() {
+            for (size_t i = t; i < n; i += nt) f(i);
+        });
+    for (auto &x : th) x.join();
+}
+
+}  // namespace
+
+struct bmi_ctx {
+    bmi_params P{};
+    int device = 0;
+    uint32_t N = 0, big_n = 0, rows = 0, ks_stride = 0;
+    hipStream_t stream = nullptr;  // the context's own stream (host-buffer entry points)
+    bool have_keys = false;
+    u64 seed = 0, enc_counter = 0;
+    std::vector<u64> sk_small, sk_big, bsk_std, ksk;
+    u64 *d_bsk = nullptr, *d_ksk = nullptr, *d_tw = nullptr, *d_luts = nullptr;
+    uint32_t n_luts = 0, lut_cap = 0;
+    std::vector<std::vector<u64>> luts_host;
+    // growable device scratch
+    u64 *d_small = nullptr;
+    size_t small_cap = 0;
+    u64 *d_io_a = nullptr, *d_io_b = nullptr;
+    uint32_t *d_io_ids = nullptr;
+    size_t io_cap = 0;
+    int variant = 0;
+    mutable std::string err;
+};
+
+namespace {
+
+int fail(const bmi_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+#define HIP_OK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(ctx, -2, std::string(#call) + ": " + hipGetErrorString(e__));                  \
+    } while (0)
+
+int ensure_small(bmi_ctx *c, size_t count) {
+    if (count <= c->small_cap) return 0;
+    if (c->d_small) HIP_OK(c, hipFree(c->d_small));
+    size_t cap = std::max<size_t>(count, 1024);
+    HIP_OK(c, hipMalloc(&c->d_small, cap * (c->P.n + 1) * sizeof(u64)));
+    c->small_cap = cap;
+    return 0;
+}
+int ensure_io(bmi_ctx *c, size_t count) {
+    if (count <= c->io_cap) return 0;
+    if (c->d_io_a) HIP_OK(c, hipFree(c->d_io_a));
+    if (c->d_io_b) HIP_OK(c, hipFree(c->d_io_b));
+    if (c->d_io_ids) HIP_OK(c, hipFree(c->d_io_ids));
+    size_t cap = std::max<size_t>(count, 256);
+    HIP_OK(c, hipMalloc(&c->d_io_a, cap * (c->big_n + 1) * sizeof(u64)));
+    HIP_OK(c, hipMalloc(&c->d_io_b, cap * (c->big_n + 1) * sizeof(u64)));
+    HIP_OK(c, hipMalloc(&c->d_io_ids, cap * sizeof(uint32_t)));
+    c->io_cap = cap;
+    return 0;
+}
+
+// out += X^t * a  (negacyclic), coefficient-wise in Z_q
+void add_shifted(u64 *out, const u64 *a, uint32_t t, uint32_t N) {
+    for (uint32_t j = 0; j + t < N; j++) out[j + t] = gl::add(out[j + t], a[j]);
+    for (uint32_t j = N - t; j < N; j++) out[j + t - N] = gl::sub(out[j + t - N], a[j]);
+}
+
+std::vector<u64> build_twiddles() {
+    using namespace nttw;
+    std::vector<u64> tw(TW_WORDS);
+    for (int k1 = 0; k1 < 16; k1++)
+        for (int l = 0; l < 64; l++) {
+            const u64 e = (u64)l * (2 * k1 + 1);
+            tw[TW_W1 + k1 * 64 + l] = pow_mod(PSI, e);
+            tw[TW_W1I + k1 * 64 + l] = gl::mul(pow_mod(PSI_INV, e), N_INV);
+        }
+    const u64 inv8 = pow_mod(8, gl::P - 2);
+    for (int v = 0; v < 16; v++)
+        for (int t = 0; t < 4; t++) {
+            tw[TW_W2 + v * 4 + t] = pow_mod(8, (u64)t * v);
+            tw[TW_W2I + v * 4 + t] = pow_mod(inv8, (u64)t * v);
+        }
+    return tw;
+}
+
+bool params_supported(const bmi_params &P, std::string &why) {
+    if (P.log_N != 10) { why = "only log_N = 10 (N = 1024) has a HIP kernel in this build"; return false; }
+    if (P.k != 1) { why = "only k = 1 has a HIP kernel in this build"; return false; }
+    if (P.bs_levels != 3 || P.bs_base_log != 15) { why = "only (l, Bg) = (3, 2^15) has a HIP kernel in this build"; return false; }
+    if (P.n == 0 || P.n > 639) { why = "n must be in [1, 639]"; return false; }
+    if (P.ks_levels * P.ks_base_log > 63 || P.ks_base_log > 7 || P.ks_levels == 0) { why = "unsupported keyswitch decomposition"; return false; }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bmi_default_params(bmi_params *out) {
+    if (!out) return -1;
+    *out = bmi_params{630, 10, 1, 3, 15, 8, 4, 0, std::ldexp(1.0, -25), std::ldexp(1.0, -44)};
+    return 0;
+}
+
+const char *bmi_last_error(const bmi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
+    if (!params || !out) return fail(nullptr, -1, "null argument");
+    std::string why;
+    if (!params_supported(*params, why)) return fail(nullptr, -1, why);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, -3, "no HIP device: the PBS path has no CPU fallback (hipGetDeviceCount: " +
+                                     std::string(hipGetErrorString(e)) + ")");
+    if (device < 0 || device >= ndev) return fail(nullptr, -1, "bad device index");
+    bmi_ctx *c = new bmi_ctx();
+    c->P = *params;
+    c->device = device;
+    c->N = 1u << params->log_N;
+    c->big_n = params->k * c->N;
+    c->rows = (params->k + 1) * params->bs_levels;
+    c->ks_stride = (params->n + 1 + 7) & ~7u;
+    auto bail = [&](const std::string &m) {
+        g_create_error = m;
+        delete c;
+        return -2;
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice failed");
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+    std::vector<u64> tw = build_twiddles();
+    if (hipMalloc(&c->d_tw, tw.size() * sizeof(u64)) != hipSuccess) return bail("hipMalloc(twiddles) failed");
+    if (hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess)
+        return bail("hipMemcpy(twiddles) failed");
+    c->lut_cap = 1024;
+    if (hipMalloc(&c->d_luts, (size_t)c->lut_cap * c->N * sizeof(u64)) != hipSuccess) return bail("hipMalloc(luts) failed");
+    *out = c;
+    return 0;
+}
+
+void bmi_ctx_destroy(bmi_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (void *p : {(void *)c->d_bsk, (void *)c->d_ksk, (void *)c->d_tw, (void *)c->d_luts, (void *)c->d_small,
+                    (void *)c->d_io_a, (void *)c->d_io_b, (void *)c->d_io_ids})
+        if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bmi_get_params(const bmi_ctx *c, bmi_params *out) {
+    if (!c || !out) return -1;
+    *out = c->P;
+    return 0;
+}
+
+int bmi_keygen(bmi_ctx *c, uint64_t seed) {
+    if (!c) return -1;
+    HIP_OK(c, hipSetDevice(c->device));
+    const bmi_params &P = c->P;
+    const uint32_t n = P.n, N = c->N, k = P.k, l = P.bs_levels, lk = P.ks_levels, rows = c->rows;
+    c->seed = seed;
+    c->enc_counter = 0;
+    c->sk_small.assign(n, 0);
+    c->sk_big.assign((size_t)k * N, 0);
+    {
+        Stream s1(seed, S_SK_SMALL), s2(seed, S_SK_BIG);
+        for (uint32_t i = 0; i < n; i++) c->sk_small[i] = s1.bit(i);
+        for (uint32_t i = 0; i < k * N; i++) c->sk_big[i] = s2.bit(i);
+    }
+    // --- bootstrap key: GGSW(s_i) rows, standard domain.  B = sum_j A_j * S_j + E by shifted adds (S binary).
+    c->bsk_std.assign((size_t)n * rows * (k + 1) * N, 0);
+    {
+        Stream sm(seed, S_BSK_MASK), se(seed, S_BSK_NOISE);
+        const u64 *skb = c->sk_big.data();
+        const u64 *sks = c->sk_small.data();
+        u64 *bsk = c->bsk_std.data();
+        const double sigma = P.glwe_noise;
+        const uint32_t bl = P.bs_base_log;
+        parallel_for((size_t)n * rows, [=](size_t ir) {
+            const uint32_t i = (uint32_t)(ir / rows), r = (uint32_t)(ir % rows), comp = r / l, lev = r % l;
+            u64 *row = bsk + ir * (k + 1) * N;
+            u64 *B = row + (size_t)k * N;
+            for (uint32_t x = 0; x < N; x++) B[x] = se.gauss((u64)ir * N + x, sigma);
+            for (uint32_t j = 0; j < k; j++) {
+                u64 *A = row + (size_t)j * N;
+                for (uint32_t x = 0; x < N; x++) A[x] = sm.uniform(((u64)ir * (k + 1) + j) * N + x);
+                for (uint32_t t = 0; t < N; t++)
+                    if (skb[(size_t)j * N + t]) add_shifted(B, A, t, N);
+            }
+            if (sks[i]) row[(size_t)comp * N] = gl::add(row[(size_t)comp * N], (u64)1 << (64 - bl * (lev + 1)));
+        });
+    }
+    // --- keyswitch key
+    c->ksk.assign((size_t)k * N * lk * (n + 1), 0);
+    {
+        Stream sm(seed, S_KSK_MASK), se(seed, S_KSK_NOISE);
+        const u64 *skb = c->sk_big.data();
+        const u64 *sks = c->sk_small.data();
+        u64 *ksk = c->ksk.data();
+        const double sigma = P.lwe_noise;
+        const uint32_t bl = P.ks_base_log;
+        parallel_for((size_t)k * N * lk, [=](size_t jr) {
+            const uint32_t j = (uint32_t)(jr / lk), lev = (uint32_t)(jr % lk);
+            u64 *row = ksk + jr * (n + 1);
+            u64 b = se.gauss(jr, sigma);
+            for (uint32_t x = 0; x < n; x++) {
+                row[x] = sm.uniform((u64)jr * (n + 1) + x);
+                if (sks[x]) b = gl::add(b, row[x]);
+            }
+            if (skb[j]) b = gl::add(b, (u64)1 << (64 - bl * (lev + 1)));
+            row[n] = b;
+        });
+    }
+    // --- upload: bootstrap key -> NTT domain on the GPU; keyswitch key with padded rows
+    const size_t bsk_words = c->bsk_std.size();
+    if (!c->d_bsk) HIP_OK(c, hipMalloc(&c->d_bsk, bsk_words * sizeof(u64)));
+    u64 *d_tmp = nullptr;
+    HIP_OK(c, hipMalloc(&d_tmp, bsk_words * sizeof(u64)));
+    HIP_OK(c, hipMemcpy(d_tmp, c->bsk_std.data(), bsk_words * sizeof(u64), hipMemcpyHostToDevice));
+    int rc = bmi::launch_bsk_to_ntt(d_tmp, c->d_bsk, c->d_tw, (uint32_t)(bsk_words / N), c->stream);
+    if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_ntt launch failed"); }
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipFree(d_tmp));
+    const size_t ksk_rows = (size_t)k * N * lk;
+    if (!c->d_ksk) HIP_OK(c, hipMalloc(&c->d_ksk, ksk_rows * c->ks_stride * sizeof(u64)));
+    HIP_OK(c, hipMemset(c->d_ksk, 0, ksk_rows * c->ks_stride * sizeof(u64)));
+    HIP_OK(c, hipMemcpy2D(c->d_ksk, c->ks_stride * sizeof(u64), c->ksk.data(), (n + 1) * sizeof(u64),
+                          (n + 1) * sizeof(u64), ksk_rows, hipMemcpyHostToDevice));
+    c->have_keys = true;
+    return 0;
+}
+
+int bmi_export_keys(const bmi_ctx *c, uint64_t *sk_small, uint64_t *sk_big, uint64_t *bsk, uint64_t *ksk) {
+    if (!c) return -1;
+    if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
+    if (sk_small) std::memcpy(sk_small, c->sk_small.data(), c->sk_small.size() * 8);
+    if (sk_big) std::memcpy(sk_big, c->sk_big.data(), c->sk_big.size() * 8);
+    if (bsk) std::memcpy(bsk, c->bsk_std.data(), c->bsk_std.size() * 8);
+    if (ksk) std::memcpy(ksk, c->ksk.data(), c->ksk.size() * 8);
+    return 0;
+}
+
+int bmi_key_bytes(const bmi_ctx *c, uint64_t *bsk_bytes, uint64_t *ksk_bytes) {
+    if (!c) return -1;
+    if (bsk_bytes) *bsk_bytes = (u64)c->P.n * c->rows * (c->P.k + 1) * c->N * 8;
+    if (ksk_bytes) *ksk_bytes = (u64)c->big_n * c->P.ks_levels * (c->P.n + 1) * 8;
+    return 0;
+}
+
+int bmi_encrypt(bmi_ctx *c, const int64_t *msgs, uint32_t count, uint32_t delta_log, uint64_t *ct_out) {
+    if (!c || !msgs || !ct_out) return -1;
+    if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
+    if (delta_log > 62) return fail(c, -1, "delta_log out of range");
+    Stream sm(c->seed, S_ENC_MASK), se(c->seed, S_ENC_NOISE);
+    const uint32_t dim = c->big_n;
+    const u64 first = c->enc_counter;
+    const u64 *key = c->sk_big.data();
+    const double sigma = c->P.glwe_noise;
+    parallel_for(count, [=](size_t i) {
+        u64 *ct = ct_out + i * (dim + 1);
+        const u64 torus = gl::mul(gl::from_i64(msgs[i]), (u64)1 << delta_log);
+        u64 b = gl::add(torus, se.gauss(first + i, sigma));
+        for (uint32_t x = 0; x < dim; x++) {
+            ct[x] = sm.uniform((first + i) * (u64)(dim + 1) + x);
+            if (key[x]) b = gl::add(b, ct[x]);
+        }
+        ct[dim] = b;
+    });
+    c->enc_counter += count;
+    return 0;
+}
+
+int bmi_phase(const bmi_ctx *c, const uint64_t *ct_in, uint32_t count, uint64_t *phase) {
+    if (!c || !ct_in || !phase) return -1;
+    if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
+    const uint32_t dim = c->big_n;
+    const u64 *key = c->sk_big.data();
+    for (uint32_t i = 0; i < count; i++) {
+        const u64 *ct = ct_in + (size_t)i * (dim + 1);
+        u64 p = ct[dim];
+        for (uint32_t x = 0; x < dim; x++)
+            if (key[x]) p = gl::sub(p, ct[x]);
+        phase[i] = p;
+    }
+    return 0;
+}
+
+int bmi_decrypt(const bmi_ctx *c, const uint64_t *ct_in, uint32_t count, uint32_t delta_log, int64_t *msgs) {
+    if (!c || !ct_in || !msgs) return -1;
+    if (delta_log == 0 || delta_log > 62) return fail(c, -1, "delta_log out of range");
+    std::vector<u64> ph(count);
+    int rc = bmi_phase(c, ct_in, count, ph.data());
+    if (rc) return rc;
+    for (uint32_t i = 0; i < count; i++) {
+        const i64 v = gl::centered(ph[i]);
+        msgs[i] = (v >> delta_log) + ((v >> (delta_log - 1)) & 1);
+    }
+    return 0;
+}
+
+int bmi_lut_register(bmi_ctx *c, const int64_t *table, uint32_t msg_bits, uint32_t out_delta_log, uint32_t *lut_id) {
+    if (!c || !table || !lut_id) return -1;
+    const uint32_t N = c->N;
+    if (msg_bits == 0 || (1u << msg_bits) * 2 > N) return fail(c, -1, "msg_bits out of range for N");
+    if (out_delta_log > 62) return fail(c, -1, "out_delta_log out of range");
+    if (c->n_luts == c->lut_cap) return fail(c, -1, "LUT table full");
+    // Signed messages on the whole negacyclic circle: box width w = N / 2^p, boxes centred on m*w.
+    const uint32_t M = 1u << msg_bits, Mh = M >> 1, w = N >> msg_bits, half = w >> 1;
+    std::vector<u64> tv(N);
+    for (uint32_t j = 0; j < N; j++) {
+        const uint32_t box = (j + half) / w;  // 0 .. M
+        i64 f;
+        bool negate;
+        if (box < Mh) { f = table[box + Mh]; negate = false; }        // m = box >= 0
+        else if (box < M) { f = table[box - Mh]; negate = true; }      // m = box - M < 0, reached as -X^(j-N)
+        else { f = table[Mh]; negate = true; }                         // m = 0 from below
+        const u64 v = gl::mul(gl::from_i64(f), (u64)1 << out_delta_log);
+        tv[j] = negate ? gl::neg(v) : v;
+    }
+    HIP_OK(c, hipSetDevice(c->device));
+    HIP_OK(c, hipMemcpy(c->d_luts + (size_t)c->n_luts * N, tv.data(), N * sizeof(u64), hipMemcpyHostToDevice));
+    c->luts_host.push_back(std::move(tv));
+    *lut_id = c->n_luts++;
+    return 0;
+}
+
+int bmi_lut_get(const bmi_ctx *c, uint32_t lut_id, uint64_t *test_vector) {
+    if (!c || !test_vector) return -1;
+    if (lut_id >= c->n_luts) return fail(c, -1, "unknown LUT id");
+    std::memcpy(test_vector, c->luts_host[lut_id].data(), c->N * 8);
+    return 0;
+}
+
+int bmi_set_kernel_variant(bmi_ctx *c, int variant) {
+    if (!c) return -1;
+    if (variant < 0 || variant > 2) return fail(c, -1, "variant must be 0, 1 or 2");
+    c->variant = variant;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- the hot path
+int bmi_keyswitch_batch(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64_t *d_small, void *stream) {
+    if (!c || (count && (!d_in || !d_small))) return -1;
+    if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
+    int rc = bmi::launch_keyswitch(d_in, c->d_ksk, d_small, count, c->P.n, c->big_n, c->P.ks_levels, c->P.ks_base_log,
+                                   c->ks_stride, (hipStream_t)stream);
+    return rc ? fail(c, -2, std::string("keyswitch launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+}
+
+int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *d_lut_ids, uint32_t count,
+                           uint64_t *d_out, void *stream) {
+    if (!c || (count && (!d_small || !d_lut_ids || !d_out))) return -1;
+    if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
+    int rc = bmi::launch_blind_rotate_tp(d_small, d_lut_ids, c->d_luts, c->d_bsk, c->d_tw, d_out, count, c->P.n,
+                                         (hipStream_t)stream);
+    return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+}
+
+int bmi_pbs_batch(bmi_ctx *c, const uint64_t *d_in, const uint32_t *d_lut_ids, uint32_t count, uint64_t *d_out,
+                  void *stream) {
+    if (!c) return -1;
+    HIP_OK(c, hipSetDevice(c->device));
+    int rc = ensure_small(c, count);
+    if (rc) return rc;
+    rc = bmi_keyswitch_batch(c, d_in, count, c->d_small, stream);
+    if (rc) return rc;
+    return bmi_blind_rotate_batch(c, c->d_small, d_lut_ids, count, d_out, stream);
+}
+
+int bmi_lincomb_batch(bmi_ctx *c, const uint64_t *d_store, const uint32_t *d_row_ptr, const uint32_t *d_idx,
+                      const int64_t *d_coef, const uint64_t *d_const_body, uint32_t count, uint64_t *d_out,
+                      void *stream) {
+    if (!c || (count && (!d_store || !d_row_ptr || !d_const_body || !d_out))) return -1;
+    int rc = bmi::launch_lincomb(d_store, d_row_ptr, d_idx, (const i64 *)d_coef, d_const_body, d_out, count, c->big_n + 1,
+                                 (hipStream_t)stream);
+    return rc ? fail(c, -2, std::string("lincomb launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+}
+
+int bmi_sync(bmi_ctx *c, void *stream) {
+    if (!c) return -1;
+    HIP_OK(c, hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------- host-buffer convenience forms
+int bmi_pbs_batch_host(bmi_ctx *c, const uint64_t *in, const uint32_t *lut_ids, uint32_t count, uint64_t *out) {
+    if (!c || !in || !lut_ids || !out) return -1;
+    HIP_OK(c, hipSetDevice(c->device));
+    int rc = ensure_io(c, count);
+    if (rc) return rc;
+    const size_t w = (size_t)(c->big_n + 1) * 8;
+    HIP_OK(c, hipMemcpyAsync(c->d_io_a, in, count * w, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(c, hipMemcpyAsync(c->d_io_ids, lut_ids, count * 4, hipMemcpyHostToDevice, c->stream));
+    rc = bmi_pbs_batch(c, c->d_io_a, c->d_io_ids, count, c->d_io_b, c->stream);
+    if (rc) return rc;
+    HIP_OK(c, hipMemcpyAsync(out, c->d_io_b, count * w, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bmi_keyswitch_batch_host(bmi_ctx *c, const uint64_t *in, uint32_t count, uint64_t *small_out) {
+    if (!c || !in || !small_out) return -1;
+    HIP_OK(c, hipSetDevice(c->device));
+    int rc = ensure_io(c, count);
+    if (rc) return rc;
+    rc = ensure_small(c, count);
+    if (rc) return rc;
+    HIP_OK(c, hipMemcpyAsync(c->d_io_a, in, (size_t)count * (c->big_n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    rc = bmi_keyswitch_batch(c, c->d_io_a, count, c->d_small, c->stream);
+    if (rc) return rc;
+    HIP_OK(c, hipMemcpyAsync(small_out, c->d_small, (size_t)count * (c->P.n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bmi_blind_rotate_batch_host(bmi_ctx *c, const uint64_t *small_in, const uint32_t *lut_ids, uint32_t count,
+                                uint64_t *out) {
+    if (!c || !small_in || !lut_ids || !out) return -1;
+    HIP_OK(c, hipSetDevice(c->device));
+    int rc = ensure_io(c, count);
+    if (rc) return rc;
+    rc = ensure_small(c, count);
+    if (rc) return rc;
+    HIP_OK(c, hipMemcpyAsync(c->d_small, small_in, (size_t)count * (c->P.n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(c, hipMemcpyAsync(c->d_io_ids, lut_ids, count * 4, hipMemcpyHostToDevice, c->stream));
+    rc = bmi_blind_rotate_batch(c, c->d_small, c->d_io_ids, count, c->d_io_b, c->stream);
+    if (rc) return rc;
+    HIP_OK(c, hipMemcpyAsync(out, c->d_io_b, (size_t)count * (c->big_n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bmi_negacyclic_mul_host(bmi_ctx *c, const uint64_t *a, const uint64_t *b, uint32_t count, uint64_t *out) {
+    if (!c || !a || !b || !out) return -1;
+    HIP_OK(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)count * c->N * 8;
+    u64 *da = nullptr, *db = nullptr, *dc = nullptr;
+    HIP_OK(c, hipMalloc(&da, bytes));
+    HIP_OK(c, hipMalloc(&db, bytes));
+    HIP_OK(c, hipMalloc(&dc, bytes));
+    HIP_OK(c, hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    HIP_OK(c, hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
+    int rc = bmi::launch_negacyclic_mul(da, db, dc, c->d_tw, count, c->stream);
+    if (rc) return fail(c, -2, "negacyclic_mul launch failed");
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipMemcpy(out, dc, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc);
+    return 0;
+}
+
+}  // extern "C"

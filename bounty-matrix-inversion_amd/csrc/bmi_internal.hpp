@@ -1,0 +1,24 @@
+// Internal declarations shared by the kernel TU (bmi_kernels.hip) and the host TU (bmi_host.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "goldilocks.hpp"
+
+#ifndef BMI_TP_WAVES
+#define BMI_TP_WAVES 4  // ciphertexts (= wavefronts) per workgroup in the throughput blind rotation
+#endif
+
+namespace bmi {
+using gl::i64;
+using gl::u64;
+
+int launch_bsk_to_ntt(const u64 *std_polys, u64 *ntt_polys, const u64 *g_tw, uint32_t n_polys, hipStream_t s);
+int launch_negacyclic_mul(const u64 *a, const u64 *b, u64 *c, const u64 *g_tw, uint32_t count, hipStream_t s);
+int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const u64 *bsk,
+                           const u64 *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s);
+int launch_keyswitch(const u64 *in, const u64 *ksk, u64 *out, uint32_t count, uint32_t n, uint32_t big_n,
+                     uint32_t levels, uint32_t base_log, uint32_t ks_stride, hipStream_t s);
+int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *idx, const i64 *coef,
+                   const u64 *const_body, u64 *out, uint32_t count, uint32_t width, hipStream_t s);
+}  // namespace bmi

@@ -1,0 +1,331 @@
+// HIP kernels (gfx950 / CDNA4) of the TFHE programmable-bootstrap engine.
+//
+//   k_bsk_to_ntt        standard-domain GGSW rows -> NTT (evaluation) domain, lane-layout, once per keygen
+//   k_blind_rotate_tp   THROUGHPUT variant: one wavefront = one ciphertext; mod-switch, n CMUXes
+//                       (decompose -> 6 forward NTTs -> 12 pointwise MACs -> 2 inverse NTTs), sample extraction
+//   k_keyswitch         big-key LWE -> small-key LWE (signed base-2^4 decomposition, 128-bit accumulators)
+//   k_lincomb           leveled linear combinations of ciphertexts (CSR)
+//   k_negacyclic_mul    test hook: c = a * b mod (X^N + 1, q) through the wave NTT
+//
+// Data layout in HBM
+//   bootstrap key : [n][(k+1)l = 6][k+1 = 2][N] 64-bit words, NTT domain, each polynomial stored in the
+//                   wave's register layout (nttw::eval_offset) so one lane reads 16 B and one wave 1 KiB
+//                   per load instruction (fully coalesced); 61,931,520 B for the default set.
+//   keyswitch key : [k*N][ks_levels][n+1 padded to KS_STRIDE] words, row-major: consecutive threads read
+//                   consecutive columns of one row.
+//   ciphertexts   : big  [count][k*N+1], small [count][n+1] words.
+#include <hip/hip_runtime.h>
+
+#include "bmi_internal.hpp"
+#include "ntt_wave.hpp"
+
+using gl::u64;
+using gl::i64;
+using namespace nttw;
+
+namespace {
+
+__device__ __forceinline__ void stage_twiddles(u64 *lds_tw, const u64 *__restrict__ g_tw) {
+    for (int i = threadIdx.x; i < TW_WORDS; i += blockDim.x) lds_tw[i] = g_tw[i];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bsk_to_ntt(const u64 *__restrict__ std_polys, u64 *__restrict__ ntt_polys,
+                                                    const u64 *__restrict__ g_tw, uint32_t n_polys) {
+    __shared__ u64 lds[TW_WORDS + 4 * SCRATCH_WORDS];
+    stage_twiddles(lds, g_tw);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t poly = blockIdx.x * 4 + wave;
+    if (poly >= n_polys) return;
+    u64 *scratch = lds + TW_WORDS + wave * SCRATCH_WORDS;
+    u64 x[16];
+    static_for<0, 16>([&](auto J) { x[J] = std_polys[(size_t)poly * N + lane + 64 * J]; });
+    forward(x, lane, lds, scratch);
+    static_for<0, 16>([&](auto V) { ntt_polys[(size_t)poly * N + eval_offset(lane, V)] = x[V]; });
+}
+
+// c = a * b  (negacyclic), one wave per product
+__global__ void __launch_bounds__(256) k_negacyclic_mul(const u64 *__restrict__ a, const u64 *__restrict__ b,
+                                                        u64 *__restrict__ c, const u64 *__restrict__ g_tw,
+                                                        uint32_t count) {
+    __shared__ u64 lds[TW_WORDS + 4 * SCRATCH_WORDS];
+    stage_twiddles(lds, g_tw);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t p = blockIdx.x * 4 + wave;
+    if (p >= count) return;
+    u64 *scratch = lds + TW_WORDS + wave * SCRATCH_WORDS;
+    u64 x[16], y[16];
+    static_for<0, 16>([&](auto J) {
+        x[J] = a[(size_t)p * N + lane + 64 * J];
+        y[J] = b[(size_t)p * N + lane + 64 * J];
+    });
+    forward(x, lane, lds, scratch);
+    forward(y, lane, lds, scratch);
+    static_for<0, 16>([&](auto V) { x[V] = gl::mul(x[V], y[V]); });
+    inverse(x, lane, lds, scratch);
+    static_for<0, 16>([&](auto J) { c[(size_t)p * N + lane + 64 * J] = x[J]; });
+}
+
+// ------------------------------------------------------------------------------------------------
+// Signed decomposition of one coefficient for the bootstrap gadget (l = 3, base 2^15): digits of the
+// centred lift rounded to its top 45 bits; d[0] is the most significant and absorbs the final carry.
+__device__ __forceinline__ void decompose3x15(u64 a, int (&d)[3]) {
+    i64 c = gl::centered(a);
+    i64 r = (c >> 19) + ((c >> 18) & 1);
+    int d2 = (int)(r & 0x7FFF);
+    r >>= 15;
+    if (d2 >= 0x4000) { d2 -= 0x8000; r += 1; }
+    int d1 = (int)(r & 0x7FFF);
+    r >>= 15;
+    if (d1 >= 0x4000) { d1 -= 0x8000; r += 1; }
+    d[0] = (int)r;
+    d[1] = d1;
+    d[2] = d2;
+}
+
+// THROUGHPUT blind rotation: one wavefront per ciphertext, WAVES ciphertexts per workgroup.
+// Accumulator (2 polynomials) lives in registers; LDS holds the twiddles (shared by the workgroup),
+// one transpose/rotation tile per wave and the mod-switched mask of the wave's ciphertext.
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
+    k_blind_rotate_tp(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
+                      const u64 *__restrict__ luts, const u64 *__restrict__ bsk, const u64 *__restrict__ g_tw,
+                      u64 *__restrict__ out, uint32_t count, uint32_t n) {
+    constexpr int AT_WORDS = 160;  // 640 x uint16
+    __shared__ u64 lds[TW_WORDS + WAVES * (SCRATCH_WORDS + AT_WORDS)];
+    stage_twiddles(lds, g_tw);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t ct = blockIdx.x * WAVES + wave;
+    if (ct >= count) return;  // whole wave leaves; no workgroup barrier follows
+    u64 *scratch = lds + TW_WORDS + wave * (SCRATCH_WORDS + AT_WORDS);
+    uint16_t *at = reinterpret_cast<uint16_t *>(scratch + SCRATCH_WORDS);
+    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
+
+    // modulus switch of the whole small ciphertext (mask + body) to Z_{2N}
+    for (uint32_t i = lane; i <= n; i += 64) at[i] = (uint16_t)gl::modswitch(lwe[i], LOG_N + 1);
+    wave_sync();
+
+    // ACC = X^(-b~) * (0, tv)
+    u64 acc[2][16];
+    {
+        const u64 *tv = luts + (size_t)lut_ids[ct] * N;
+        const uint32_t bt = at[n];
+        static_for<0, 16>([&](auto J) {
+            const uint32_t e = (lane + 64 * J + bt) & (2 * N - 1);
+            const u64 v = tv[e & (N - 1)];
+            acc[0][J] = 0;
+            acc[1][J] = (e & N) ? gl::neg(v) : v;
+        });
+    }
+
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t a_t = at[i];
+        if (a_t == 0) continue;  // wave-uniform: X^0 * ACC - ACC = 0 adds exactly zero
+        u64 accn[2][16];
+        static_for<0, 16>([&](auto V) { accn[0][V] = 0; accn[1][V] = 0; });
+        const u64 *bsk_i = bsk + (size_t)i * 12 * N;
+        static_for<0, 2>([&](auto C) {
+            constexpr int c = C;
+            // diff = X^(a~) * ACC_c - ACC_c, through the wave's LDS tile (natural order)
+            wave_sync();
+            static_for<0, 16>([&](auto J) { scratch[lane + 64 * J] = acc[c][J]; });
+            wave_sync();
+            int dig[3][16];
+            static_for<0, 16>([&](auto J) {
+                const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
+                u64 v = scratch[e & (N - 1)];
+                v = (e & N) ? gl::neg(v) : v;
+                int d[3];
+                decompose3x15(gl::sub(v, acc[c][J]), d);
+                dig[0][J] = d[0]; dig[1][J] = d[1]; dig[2][J] = d[2];
+            });
+            static_for<0, 3>([&](auto LEV) {
+                constexpr int lev = LEV;
+                u64 x[16];
+                static_for<0, 16>([&](auto J) { x[J] = gl::from_i64((i64)dig[lev][J]); });
+                forward(x, lane, lds, scratch);
+                const u64 *row = bsk_i + (size_t)(c * 3 + lev) * 2 * N;
+                static_for<0, 8>([&](auto VP) {
+                    const ulonglong2 b0 = reinterpret_cast<const ulonglong2 *>(row)[VP * 64 + lane];
+                    const ulonglong2 b1 = reinterpret_cast<const ulonglong2 *>(row + N)[VP * 64 + lane];
+                    accn[0][2 * VP] = gl::add(accn[0][2 * VP], gl::mul(x[2 * VP], b0.x));
+                    accn[0][2 * VP + 1] = gl::add(accn[0][2 * VP + 1], gl::mul(x[2 * VP + 1], b0.y));
+                    accn[1][2 * VP] = gl::add(accn[1][2 * VP], gl::mul(x[2 * VP], b1.x));
+                    accn[1][2 * VP + 1] = gl::add(accn[1][2 * VP + 1], gl::mul(x[2 * VP + 1], b1.y));
+                });
+            });
+        });
+        static_for<0, 2>([&](auto OC) {
+            constexpr int oc = OC;
+            inverse(accn[oc], lane, lds, scratch);
+            static_for<0, 16>([&](auto J) { acc[oc][J] = gl::add(acc[oc][J], accn[oc][J]); });
+        });
+    }
+
+    // sample extraction of coefficient 0: a_out[0] = A[0], a_out[t] = -A[N - t], b_out = B[0]
+    u64 *o = out + (size_t)ct * (N + 1);
+    static_for<0, 16>([&](auto J) {
+        const uint32_t m = lane + 64 * J;
+        if (m == 0) {
+            o[0] = acc[0][J];
+            o[N] = acc[1][J];
+        } else {
+            o[N - m] = gl::neg(acc[0][J]);
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// Keyswitch: out = (0,...,0,b) - sum_j sum_lev dec_lev(a_j) * KSK[j][lev].  One workgroup handles KS_TILE
+// ciphertexts; thread t owns output columns t, t+256, t+512.  Digits are staged in LDS (int8).
+constexpr int KS_TILE = 8;
+constexpr int KS_THREADS = 256;
+constexpr int KS_COLS = 3;  // ceil(631 / 256)
+
+__device__ __forceinline__ u64 reduce_neg_i128(__int128 a) {
+    // returns (-a) mod q for |a| < 2^100
+    __int128 m = -a;
+    bool negative = m < 0;
+    unsigned __int128 u = negative ? (unsigned __int128)(-m) : (unsigned __int128)m;
+    u64 r = gl::reduce128((u64)(u >> 64), (u64)u);
+    return negative ? gl::neg(r) : r;
+}
+
+__global__ void __launch_bounds__(KS_THREADS)
+    k_keyswitch(const u64 *__restrict__ in, const u64 *__restrict__ ksk, u64 *__restrict__ out, uint32_t count,
+                uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride) {
+    extern __shared__ signed char digits[];  // [KS_TILE][big_n * levels]
+    const uint32_t first = blockIdx.x * KS_TILE;
+    const uint32_t tile = min((uint32_t)KS_TILE, count - first);
+    const uint32_t rows = big_n * levels;
+    const uint32_t shift = 64 - levels * base_log;
+    const i64 B = (i64)1 << base_log, half = B >> 1;
+    for (uint32_t idx = threadIdx.x; idx < tile * big_n; idx += KS_THREADS) {
+        const uint32_t b = idx / big_n, j = idx % big_n;
+        const i64 c = gl::centered(in[(size_t)(first + b) * (big_n + 1) + j]);
+        i64 r = (c >> shift) + ((c >> (shift - 1)) & 1);
+        signed char *d = digits + (size_t)b * rows + (size_t)j * levels;
+        for (int lev = (int)levels - 1; lev >= 1; lev--) {
+            i64 v = r & (B - 1);
+            r >>= base_log;
+            if (v >= half) { v -= B; r += 1; }
+            d[lev] = (signed char)v;
+        }
+        d[0] = (signed char)r;
+    }
+    __syncthreads();
+
+    __int128 acc[KS_TILE][KS_COLS];
+#pragma unroll
+    for (int b = 0; b < KS_TILE; b++)
+#pragma unroll
+        for (int cc = 0; cc < KS_COLS; cc++) acc[b][cc] = 0;
+    bool col_ok[KS_COLS];
+#pragma unroll
+    for (int cc = 0; cc < KS_COLS; cc++) col_ok[cc] = threadIdx.x + cc * KS_THREADS <= n;
+
+    for (uint32_t r = 0; r < rows; r++) {
+        const u64 *krow = ksk + (size_t)r * ks_stride;
+        u64 kv[KS_COLS];
+#pragma unroll
+        for (int cc = 0; cc < KS_COLS; cc++) kv[cc] = col_ok[cc] ? krow[threadIdx.x + cc * KS_THREADS] : 0;
+#pragma unroll
+        for (int b = 0; b < KS_TILE; b++) {
+            const int d = (b < (int)tile) ? (int)digits[(size_t)b * rows + r] : 0;
+#pragma unroll
+            for (int cc = 0; cc < KS_COLS; cc++) {
+                // |d| <= 2^(base_log-1): a 64 x 32-bit product, added or subtracted
+                const unsigned __int128 p = (unsigned __int128)kv[cc] * (unsigned)(d < 0 ? -d : d);
+                acc[b][cc] += d < 0 ? -(__int128)p : (__int128)p;
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < KS_TILE; b++) {
+        if (b >= (int)tile) break;
+#pragma unroll
+        for (int cc = 0; cc < KS_COLS; cc++) {
+            const uint32_t col = threadIdx.x + cc * KS_THREADS;
+            if (col > n) continue;
+            u64 v = reduce_neg_i128(acc[b][cc]);
+            if (col == n) v = gl::add(v, in[(size_t)(first + b) * (big_n + 1) + big_n]);
+            out[(size_t)(first + b) * (n + 1) + col] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_lincomb(const u64 *__restrict__ store, const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ idx,
+              const i64 *__restrict__ coef, const u64 *__restrict__ const_body, u64 *__restrict__ out, uint32_t width) {
+    const uint32_t row = blockIdx.x;
+    const uint32_t e0 = row_ptr[row], e1 = row_ptr[row + 1];
+    for (uint32_t x = threadIdx.x; x < width; x += blockDim.x) {
+        u64 acc = 0;
+        for (uint32_t e = e0; e < e1; e++) {
+            const i64 cf = coef[e];
+            const u64 s = store[(size_t)idx[e] * width + x];
+            u64 term;
+            if (cf == 1) term = s;
+            else if (cf == -1) term = gl::neg(s);
+            else term = gl::mul(gl::from_i64(cf), s);
+            acc = gl::add(acc, term);
+        }
+        if (x == width - 1) acc = gl::add(acc, const_body[row]);
+        out[(size_t)row * width + x] = acc;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------- launchers
+namespace bmi {
+
+#define BMI_LAUNCH_CHECK()                      \
+    do {                                        \
+        hipError_t e__ = hipGetLastError();     \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+int launch_bsk_to_ntt(const u64 *std_polys, u64 *ntt_polys, const u64 *g_tw, uint32_t n_polys, hipStream_t s) {
+    hipLaunchKernelGGL(k_bsk_to_ntt, dim3((n_polys + 3) / 4), dim3(256), 0, s, std_polys, ntt_polys, g_tw, n_polys);
+    BMI_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_negacyclic_mul(const u64 *a, const u64 *b, u64 *c, const u64 *g_tw, uint32_t count, hipStream_t s) {
+    hipLaunchKernelGGL(k_negacyclic_mul, dim3((count + 3) / 4), dim3(256), 0, s, a, b, c, g_tw, count);
+    BMI_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const u64 *bsk,
+                           const u64 *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+    if (count == 0) return 0;
+    constexpr int WAVES = BMI_TP_WAVES;
+    hipLaunchKernelGGL((k_blind_rotate_tp<WAVES>), dim3((count + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, s, small_cts,
+                       lut_ids, luts, bsk, g_tw, out, count, n);
+    BMI_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_keyswitch(const u64 *in, const u64 *ksk, u64 *out, uint32_t count, uint32_t n, uint32_t big_n,
+                     uint32_t levels, uint32_t base_log, uint32_t ks_stride, hipStream_t s) {
+    if (count == 0) return 0;
+    const size_t lds = (size_t)KS_TILE * big_n * levels;
+    hipLaunchKernelGGL(k_keyswitch, dim3((count + KS_TILE - 1) / KS_TILE), dim3(KS_THREADS), lds, s, in, ksk, out, count,
+                       n, big_n, levels, base_log, ks_stride);
+    BMI_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *idx, const i64 *coef,
+                   const u64 *const_body, u64 *out, uint32_t count, uint32_t width, hipStream_t s) {
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(k_lincomb, dim3(count), dim3(256), 0, s, store, row_ptr, idx, coef, const_body, out, width);
+    BMI_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace bmi

@@ -1,0 +1,121 @@
+/*
+ * bmi_tfhe.h — C ABI of the MI355X-native TFHE programmable-bootstrap engine
+ * (libbmi_tfhe.so) that sits behind the QFloat / qfloat_matrix_inverse API of
+ * zama-ai/bounty-matrix-inversion.
+ *
+ * The reference reaches its FHE runtime only through concrete-python's Circuit object
+ * (file:line relative to /root/reference):
+ *      fhe.Compiler(...).compile(inputset)   matrix_inversion/main.py:53-66
+ *      circuit.keygen()                      matrix_inversion/main.py:177
+ *      circuit.encrypt(arrays, signs)        matrix_inversion/main.py:73-76
+ *      circuit.run(args)                     matrix_inversion/main.py:78-81   <- every PBS executes here
+ *      circuit.decrypt(result)               matrix_inversion/main.py:83-86
+ * and, inside the traced circuit body, through table look-ups on encrypted scalars
+ * (every non-linear operator on a Tracer; the one explicit LUT is
+ * matrix_inversion/base_p_arrays.py:359-365).  Each entry point below names the call it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; bmi_last_error() gives the text.
+ *   - plain pointers and sizes only.  Pointers named d_* are DEVICE pointers (HIP), all
+ *     others are host pointers.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - ciphertext modulus q = 2^64 - 2^32 + 1; words are canonical (< q).
+ *   - a "big" LWE ciphertext has k*N+1 words (mask, then body); a "small" one n+1 words.
+ *   - messages are signed integers m encoded as m * 2^delta_log (mod q).
+ *   - a context is single-caller (no internal locking); work on a stream is asynchronous
+ *     until bmi_sync() or a call that returns data to the host.
+ */
+#ifndef BMI_TFHE_H
+#define BMI_TFHE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bmi_ctx bmi_ctx;
+
+typedef struct {
+    uint32_t n;           /* small LWE dimension (630) */
+    uint32_t log_N;       /* log2 polynomial size (10) */
+    uint32_t k;           /* GLWE dimension (1) */
+    uint32_t bs_levels;   /* l: bootstrap decomposition levels (3) */
+    uint32_t bs_base_log; /* bootstrap decomposition base log (15) */
+    uint32_t ks_levels;   /* keyswitch levels (8) */
+    uint32_t ks_base_log; /* keyswitch base log (4) */
+    uint32_t reserved;
+    double lwe_noise;     /* std-dev / q of keyswitch-key encryptions */
+    double glwe_noise;    /* std-dev / q of bootstrap-key rows and fresh big-key encryptions */
+} bmi_params;
+
+/* The north-star parameter set of BASELINE.json (n=630, N=1024, k=1, l=3). */
+int bmi_default_params(bmi_params *out);
+
+/* replaces fhe.Compiler(...).compile(...) (main.py:53-66): fixes the crypto parameters, binds a GPU. */
+int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out);
+void bmi_ctx_destroy(bmi_ctx *ctx);
+/* ctx may be NULL: returns the last error of a failed bmi_ctx_create on this thread. */
+const char *bmi_last_error(const bmi_ctx *ctx);
+int bmi_get_params(const bmi_ctx *ctx, bmi_params *out);
+
+/* replaces circuit.keygen() (main.py:177).  Deterministic in `seed` (the reference's analogue is the
+ * insecure key cache, qfloat_matrix_inversion.py:997-998).  Generates both secret keys, the bootstrap
+ * key (uploaded and transformed to the NTT domain on the GPU) and the keyswitch key. */
+int bmi_keygen(bmi_ctx *ctx, uint64_t seed);
+/* Test hook: copies out the secret keys and the standard-domain evaluation keys.
+ * Sizes: sk_small[n], sk_big[k*N], bsk[n*(k+1)*l*(k+1)*N], ksk[k*N*ks_levels*(n+1)]; any may be NULL. */
+int bmi_export_keys(const bmi_ctx *ctx, uint64_t *sk_small, uint64_t *sk_big, uint64_t *bsk, uint64_t *ksk);
+
+/* replaces circuit.encrypt (main.py:76): big-key LWE encryptions of msgs[i] * 2^delta_log. */
+int bmi_encrypt(bmi_ctx *ctx, const int64_t *msgs, uint32_t count, uint32_t delta_log, uint64_t *ct_out);
+/* replaces circuit.decrypt (main.py:86): msgs[i] = round(phase / 2^delta_log), signed. */
+int bmi_decrypt(const bmi_ctx *ctx, const uint64_t *ct_in, uint32_t count, uint32_t delta_log, int64_t *msgs);
+/* raw phases (for noise measurements) */
+int bmi_phase(const bmi_ctx *ctx, const uint64_t *ct_in, uint32_t count, uint64_t *phase);
+
+/* replaces a table look-up definition (fhe.univariate, base_p_arrays.py:365, and every non-linear
+ * Tracer operator).  table[m + 2^(msg_bits-1)] = f(m) for signed m in [-2^(msg_bits-1), 2^(msg_bits-1));
+ * the looked-up value is returned encoded as f(m) * 2^out_delta_log.  The input ciphertext of a PBS
+ * using this LUT must encode m * 2^(63-msg_bits).  Returns the id used by the batch calls. */
+int bmi_lut_register(bmi_ctx *ctx, const int64_t *table, uint32_t msg_bits, uint32_t out_delta_log, uint32_t *lut_id);
+/* the N-coefficient test polynomial built for a LUT (host copy; test hook) */
+int bmi_lut_get(const bmi_ctx *ctx, uint32_t lut_id, uint64_t *test_vector);
+
+/* ---- the hot path: replaces circuit.run (main.py:81) -------------------------------------------- */
+/* Programmable bootstrap of `count` big-key ciphertexts, Concrete order:
+ *   keyswitch (big -> small) -> modulus switch to 2N -> blind rotation -> sample extraction.
+ * d_in/d_out: [count][k*N+1] device words (may alias); d_lut_ids: [count] device uint32. */
+int bmi_pbs_batch(bmi_ctx *ctx, const uint64_t *d_in, const uint32_t *d_lut_ids, uint32_t count, uint64_t *d_out,
+                  void *stream);
+/* the two stages, separately (d_small: [count][n+1]) */
+int bmi_keyswitch_batch(bmi_ctx *ctx, const uint64_t *d_in, uint32_t count, uint64_t *d_small, void *stream);
+int bmi_blind_rotate_batch(bmi_ctx *ctx, const uint64_t *d_small, const uint32_t *d_lut_ids, uint32_t count,
+                           uint64_t *d_out, void *stream);
+/* Leveled (PBS-free) linear ops on big-key ciphertexts, CSR form:
+ *   out[i] = const_body[i] + sum_{e in [row_ptr[i], row_ptr[i+1])} coef[e] * store[idx[e]]
+ * replaces + - and constant * on Tracers and np.sum / slicing (qfloat.py:811-826, 901, 1015). */
+int bmi_lincomb_batch(bmi_ctx *ctx, const uint64_t *d_store, const uint32_t *d_row_ptr, const uint32_t *d_idx,
+                      const int64_t *d_coef, const uint64_t *d_const_body, uint32_t count, uint64_t *d_out,
+                      void *stream);
+/* Host-buffer convenience forms (what a ctypes/cgo binding over numpy buffers would call):
+ * copy in, run on the context's own stream, copy out, synchronise. */
+int bmi_pbs_batch_host(bmi_ctx *ctx, const uint64_t *in, const uint32_t *lut_ids, uint32_t count, uint64_t *out);
+int bmi_keyswitch_batch_host(bmi_ctx *ctx, const uint64_t *in, uint32_t count, uint64_t *small_out);
+int bmi_blind_rotate_batch_host(bmi_ctx *ctx, const uint64_t *small_in, const uint32_t *lut_ids, uint32_t count,
+                                uint64_t *out);
+/* negacyclic product of two polynomials through the GPU NTT (test hook for the transform) */
+int bmi_negacyclic_mul_host(bmi_ctx *ctx, const uint64_t *a, const uint64_t *b, uint32_t count, uint64_t *c);
+
+int bmi_sync(bmi_ctx *ctx, void *stream);
+
+/* Selects the blind-rotation kernel: 0 = auto (by batch size), 1 = throughput (one wavefront per
+ * ciphertext), 2 = latency (one workgroup of 8 wavefronts per ciphertext). */
+int bmi_set_kernel_variant(bmi_ctx *ctx, int variant);
+
+/* bytes of device memory held by the keys (bootstrap key NTT-domain, keyswitch key) */
+int bmi_key_bytes(const bmi_ctx *ctx, uint64_t *bsk_bytes, uint64_t *ksk_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMI_TFHE_H */

@@ -1,0 +1,197 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): every stage of the HIP PBS path must match
+the exact CPU oracle BIT FOR BIT on identical keys, inputs and LUTs (integer arithmetic: no tolerance).
+All calls go through the C ABI (include/bmi_tfhe.h) via bmi_amd.tfhe."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+Q = 0xFFFFFFFF00000001
+SEED = 0x5EED
+
+
+def rand_q(rng, shape):
+    v = rng.integers(0, 2**63, shape, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, shape, dtype=np.uint64)
+    return np.where(v >= np.uint64(Q), v - np.uint64(Q), v)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bmi_amd import tfhe
+    e = tfhe.Engine()
+    e.keygen(SEED)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def ora(eng):
+    from oracle import tfhe_oracle as to
+    sk_small, sk_big, bsk, ksk = eng.export_keys()
+    P = to.default_params()
+    ctx = to.Ctx(P, bsk, ksk)
+    return to, P, ctx, sk_small, sk_big, bsk, ksk
+
+
+def test_negacyclic_product_matches_oracle(eng, ora):
+    to = ora[0]
+    rng = np.random.default_rng(1)
+    a, b = rand_q(rng, (9, 1024)), rand_q(rng, (9, 1024))
+    # edge rows: zeros, ones, X^(N-1) * X = -1, max values
+    a[0] = 0
+    a[1] = 1
+    a[2] = 0; a[2, 1023] = 1
+    b[2] = 0; b[2, 1] = 1
+    a[3] = Q - 1; b[3] = Q - 1
+    got = eng.negacyclic_mul_host(a, b)
+    for i in range(a.shape[0]):
+        assert np.array_equal(got[i], to.negacyclic(10, a[i], b[i])), i
+    assert np.array_equal(got[4], to.negacyclic(10, a[4], b[4], schoolbook=True))
+    assert int(got[2, 0]) == Q - 1 and not got[2, 1:].any()
+
+
+def test_keygen_matches_oracle_keygen(eng, ora):
+    """Same seed, same RNG specification -> identical keys (covers the host keygen's negacyclic A*S)."""
+    to, P, _, sk_small, sk_big, bsk, ksk = ora
+    K = to.keygen(P, SEED)
+    assert np.array_equal(K.sk_small, sk_small) and np.array_equal(K.sk_big, sk_big)
+    assert np.array_equal(K.ksk, ksk)
+    assert np.array_equal(K.bsk, bsk)
+
+
+def test_encrypt_decrypt_roundtrip_and_oracle_phase(eng, ora):
+    to, P, _, _, sk_big, _, _ = ora
+    msgs = np.arange(-8, 8)
+    ct = eng.encrypt(msgs, 59)
+    assert list(eng.decrypt(ct, 59)) == list(msgs)
+    assert np.array_equal(eng.phase(ct), to.lwe_phase(sk_big, ct))
+    assert list(to.decode(to.lwe_phase(sk_big, ct), 59)) == list(msgs)
+
+
+def test_lut_test_vector_matches_oracle(eng, ora):
+    to = ora[0]
+    rng = np.random.default_rng(3)
+    for p in (1, 2, 3, 4, 6):
+        table = rng.integers(-(1 << (p - 1)), 1 << (p - 1), 1 << p)
+        lid = eng.lut_register(table, p, 63 - p)
+        assert np.array_equal(eng.lut_get(lid), to.make_test_vector(10, p, table, 63 - p))
+
+
+def test_keyswitch_bit_exact(eng, ora):
+    to, P, ctx, sk_small, _, _, _ = ora
+    rng = np.random.default_rng(4)
+    msgs = rng.integers(-8, 8, 19)  # not a multiple of the kernel tile: exercises the ragged tail
+    ct = eng.encrypt(msgs, 59)
+    ct[3, :1024] = rand_q(rng, 1024)        # arbitrary masks are valid inputs too
+    ct[4, :1024] = Q - 1                    # extreme words
+    ct[5, :1024] = Q // 2
+    ct[6, :1024] = Q // 2 + 1
+    ct[7, :] = 0
+    got = eng.keyswitch_host(ct)
+    want = ctx.keyswitch(ct)
+    assert np.array_equal(got, want)
+    ok = [0, 1, 2] + list(range(8, 19))
+    assert list(to.decode(to.lwe_phase(sk_small, got[ok]), 59)) == list(msgs[ok])
+
+
+def test_blind_rotate_bit_exact(eng, ora):
+    to, P, ctx, _, sk_big, _, _ = ora
+    rng = np.random.default_rng(5)
+    tables = [np.arange(-8, 8), rng.integers(-8, 8, 16)]
+    ids = [eng.lut_register(t, 4, 59) for t in tables]
+    tvs = np.stack([eng.lut_get(i) for i in ids])
+    msgs = rng.integers(-8, 8, 6)
+    small = ctx.keyswitch(eng.encrypt(msgs, 59))
+    small = np.concatenate([small, rand_q(rng, (1, 631)), np.zeros((1, 631), np.uint64)])  # random + all-zero ciphertexts
+    sel = np.array([0, 1, 0, 1, 0, 1, 1, 0], np.uint32)
+    got = eng.blind_rotate_host(small, np.array(ids, np.uint32)[sel])
+    want = ctx.blind_rotate(small, tvs, sel)
+    assert np.array_equal(got, want)
+    dec = to.decode(to.lwe_phase(sk_big, got[:6]), 59)
+    assert list(dec) == [int(tables[s][m + 8]) for s, m in zip(sel[:6], msgs)]
+
+
+def test_pbs_bit_exact_and_evaluates_every_entry(eng, ora):
+    to, P, ctx, _, sk_big, _, _ = ora
+    rng = np.random.default_rng(6)
+    table = rng.integers(-8, 8, 16)
+    sq = np.array([(m * m) // 4 % 8 for m in range(-8, 8)])
+    ids = [eng.lut_register(table, 4, 59), eng.lut_register(sq, 4, 59)]
+    tvs = np.stack([eng.lut_get(i) for i in ids])
+    msgs = np.concatenate([np.arange(-8, 8), np.arange(-8, 8)])
+    sel = np.array([0] * 16 + [1] * 16, np.uint32)
+    ct = eng.encrypt(msgs, 59)
+    got = eng.pbs_host(ct, np.array(ids, np.uint32)[sel])
+    want = ctx.pbs(ct, tvs, sel)
+    assert np.array_equal(got, want)
+    dec = eng.decrypt(got, 59)
+    assert list(dec[:16]) == list(table) and list(dec[16:]) == list(sq)
+    # a second bootstrap of the outputs (noise stays bounded; still bit-exact)
+    got2 = eng.pbs_host(got, np.array([ids[1]] * 32, np.uint32))
+    assert np.array_equal(got2, ctx.pbs(got, tvs, np.ones(32, np.uint32)))
+    assert list(eng.decrypt(got2, 59)) == [int(sq[m + 8]) for m in dec]
+
+
+def test_small_message_space_luts(eng):
+    # p = 1..3 use wider boxes (input scaled by 2^(4-p) by the caller)
+    for p in (1, 2, 3):
+        M = 1 << p
+        msgs = np.arange(-M // 2, M // 2)
+        table = (msgs * 3 + 1) % M - M // 2
+        lid = eng.lut_register(table, p, 59)
+        ct = eng.encrypt(msgs, 63 - p)
+        out = eng.pbs_host(ct, np.full(M, lid, np.uint32))
+        assert list(eng.decrypt(out, 59)) == list(table)
+
+
+def test_lincomb_device_matches_oracle(eng, ora):
+    import torch
+    to, P, _, _, sk_big, _, _ = ora
+    msgs = np.array([1, -2, 3, 0, 2])
+    ct = eng.encrypt(msgs, 59)
+    row_ptr = np.array([0, 2, 5, 5, 8], np.uint32)
+    idx = np.array([0, 1, 2, 3, 0, 4, 4, 1], np.uint32)
+    coef = np.array([2, -1, 1, 1, -1, 3, -7, 1], np.int64)
+    consts = to.encode([1, 0, -4, 0], 59)
+    want = to.lincomb(P.big, ct, row_ptr, idx, coef, consts)
+    dev = torch.device("cuda:0")
+    d = lambda a, dt: torch.from_numpy(a.view(dt) if a.dtype != dt else a).to(dev)
+    d_ct = d(ct.view(np.int64), np.int64)
+    d_rp = d(row_ptr.view(np.int32), np.int32)
+    d_ix = d(idx.view(np.int32), np.int32)
+    d_cf = d(coef, np.int64)
+    d_cs = d(consts.view(np.int64), np.int64)
+    d_out = torch.zeros((4, P.big), dtype=torch.int64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    eng.lincomb(d_ct, d_rp, d_ix, d_cf, d_cs, 4, d_out, s)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)
+    assert list(eng.decrypt(got, 59)) == [5, 2, -4, -10]
+
+
+def test_pbs_device_pointers_and_noise_budget(eng, ora):
+    """Device-resident call (torch tensors as plain device memory) + output noise inside the budget."""
+    import torch
+    to, P, ctx, _, sk_big, _, _ = ora
+    rng = np.random.default_rng(8)
+    B = 300  # spans several workgroups, ragged last group
+    msgs = rng.integers(-8, 8, B)
+    ident = eng.lut_register(np.arange(-8, 8), 4, 59)
+    ct = eng.encrypt(msgs, 59)
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(ct.view(np.int64)).to(dev)
+    d_ids = torch.full((B,), ident, dtype=torch.int32, device=dev)
+    d_out = torch.empty_like(d_in)
+    s = torch.cuda.current_stream().cuda_stream
+    eng.pbs(d_in, d_ids, B, d_out, s)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy().view(np.uint64)
+    assert list(eng.decrypt(out, 59)) == list(msgs)
+    # spot-check bit-exactness on a sample (oracle is ~30 ms per PBS per core)
+    pick = rng.choice(B, 12, replace=False)
+    tv = eng.lut_get(ident)[None, :]
+    assert np.array_equal(out[pick], ctx.pbs(ct[pick], tv, np.zeros(12, np.uint32)))
+    ph = eng.phase(out)
+    err = np.array([((int(x) - (int(m) << 59)) + Q // 2) % Q - Q // 2 for x, m in zip(ph, msgs)], dtype=np.float64)
+    assert np.max(np.abs(err)) < 2.0 ** 50  # half a box is 2^58
