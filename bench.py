@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — PBS throughput of the MI355X-native TFHE engine (BASELINE.json metric "PBS/sec per GPU").
+
+One "step" = one pass of the hot path (keyswitch -> mod-switch -> blind rotation -> sample extraction)
+over one batch of B synthetic ciphertexts per GPU, inputs already resident in HBM, at the north-star
+parameter set (n=630, N=1024, k=1, l=3).  The batch shards over GPUs with no data-path collective
+(independent ciphertexts; keys replicated) -> "scaling": "weak".
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` follows the north star's definition (bootstrap-key bytes per PBS,
+no-reuse convention, against peak HBM bandwidth) for the dominant kernel (blind rotation), whose launch
+duration is measured live with events on the launch stream; `alu` adds the integer-ALU view the path is
+really bound by.  `cpu_baseline` times the oracle (a scalar-per-thread C port, OpenMP over the
+batch) on this box's host cores, on a bounded sample of the same ciphertexts (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "bounty-matrix-inversion_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+BSK_BYTES_PER_PBS = 630 * 4 * 3 * 1024 * 8  # 61,931,520 (SURVEY.md §8d / BASELINE.md §3)
+MODMUL_PER_PBS = 33_546_240                # SURVEY.md §8d (radix-2 count, the reference figure)
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("BMI_BENCH_BATCH", "8192")),
+                    help="ciphertexts per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inverse", action="store_true", help="also time the encrypted 2x2 inverse (config 2)")
+    args = ap.parse_args()
+
+    import torch
+    from bmi_amd import tfhe
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    eng = tfhe.Engine(device=local_rank)
+    eng.keygen(0x5EED)  # keys replicated on every GPU (same seed)
+    P = eng.P
+    B = args.batch
+    rng = np.random.default_rng(1234 + rank)
+    msgs = rng.integers(-8, 8, B)
+    ident = eng.lut_register(np.arange(-8, 8), 4, 59)
+    rnd_table = np.random.default_rng(99).integers(-8, 8, 16)
+    rlut = eng.lut_register(rnd_table, 4, 59)
+    ct = eng.encrypt(msgs, 59)
+    lut_sel = (np.arange(B) & 1).astype(np.int32)
+    d_in = torch.from_numpy(ct.view(np.int64)).to(dev)
+    d_ids = torch.from_numpy(np.where(lut_sel == 0, ident, rlut).astype(np.int32)).to(dev)
+    d_small = torch.empty((B, P.small), dtype=torch.int64, device=dev)
+    d_out = torch.empty_like(d_in)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(events=None):
+        eng.keyswitch(d_in, B, d_small, stream)
+        if events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        eng.blind_rotate(d_small, d_ids, B, d_out, stream)
+        if events is not None:
+            e1.record()
+            events.append((e0, e1))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(events)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    br_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+    # correctness of what was timed: every output decrypts to LUT[m]
+    out = d_out.cpu().numpy().view(np.uint64)
+    dec = eng.decrypt(out, 59)
+    want = np.where(lut_sel == 0, msgs, rnd_table[msgs + 8])
+    verified = bool(np.array_equal(dec, want))
+
+    total_pbs = B * world * args.steps
+    value = total_pbs / elapsed
+    achieved_gbs = BSK_BYTES_PER_PBS * B / (br_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("batch") == B:
+                traffic = tj.get("bytes_per_launch")
+        except Exception:
+            traffic = None
+    res = {
+        "metric": "PBS/sec per GPU (whole-job PBS/s = value)", "value": value, "unit": "PBS/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64 (mod 2^64-2^32+1)", "data": "synthetic",
+        "config": {"workload": f"pbs_batch: B={B} LWE ciphertexts per GPU per step, TFHE n=630 N=1024 k=1 l=3 "
+                               f"(Bg=2^15, ks 8x4 bits), 4-bit signed messages, 2 LUTs (identity, random)",
+                   "batch_per_gpu": B, "pbs_per_gpu_per_s": value / world, "verified_decrypt": verified,
+                   "derived_reference_pbs_per_s_64core_cpu": "35-69 (derived, BASELINE.md §1)"},
+        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "k_blind_rotate_tp", "kernel_ms": br_ms,
+                     "algorithmic_bytes_per_pbs": BSK_BYTES_PER_PBS,
+                     "alu": {"modmul_per_s": MODMUL_PER_PBS * B / (br_ms * 1e-3), "modmul_per_pbs": MODMUL_PER_PBS}},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import tfhe_oracle as to
+        sk_small, sk_big, bsk, ksk = eng.export_keys()
+        octx = to.Ctx(to.default_params(), bsk, ksk)
+        tvs = np.stack([eng.lut_get(ident), eng.lut_get(rlut)])
+        threads = to.num_threads()
+        t1 = time.perf_counter()
+        probe = octx.pbs(ct[:threads], tvs, lut_sel[:threads].astype(np.uint32))
+        per = (time.perf_counter() - t1)
+        sample = int(max(threads, min(B, threads * max(1, round(args.cpu_seconds / max(per, 1e-3))))))
+        t1 = time.perf_counter()
+        ref = octx.pbs(ct[:sample], tvs, lut_sel[:sample].astype(np.uint32))
+        cpu_s = time.perf_counter() - t1
+        bit_exact = bool(np.array_equal(ref, out[:sample]) and np.array_equal(probe, out[:threads]))
+        res["cpu_baseline"] = {"value": sample / cpu_s, "unit": "PBS/s", "cores": threads, "kind": "port",
+                               "sample": f"first {sample} ciphertexts of the same batch, same keys/LUTs, oracle/tfhe_oracle.c "
+                                         f"(exact NTT PBS, OpenMP over the batch), {cpu_s:.1f} s",
+                               "gpu_matches_bit_for_bit": bit_exact,
+                               "concrete": "Concrete not present (import concrete fails: not installed, no network)"}
+        res["config"]["verified_bit_exact_vs_oracle"] = bit_exact
+
+    if args.inverse and rank == 0:
+        try:
+            from bmi_amd import inverse_bench
+            res["config"]["inverse"] = inverse_bench.run(eng)
+        except Exception as e:  # reported, never hidden
+            res["config"]["inverse"] = {"error": repr(e)}
+
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+    if not verified:
+        raise SystemExit("bench outputs failed decrypt verification")
+
+
+if __name__ == "__main__":
+    main()
