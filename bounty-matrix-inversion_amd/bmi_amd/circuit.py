@@ -1,0 +1,338 @@
+"""Circuit IR: the host-side scheduler that turns QFloat arithmetic into batched PBS levels.
+
+The reference traces its Python code with concrete-python's `Tracer` and lets Concrete compile and run the
+graph (matrix_inversion/main.py:53-66,81).  Here the same role is played by:
+
+  * `Lin`     — a symbolic encrypted scalar: an integer linear combination  const + sum coef_i * leaf_i  of
+                *leaves* (circuit inputs and PBS outputs) with a guaranteed value interval [lo, hi].
+                + - and constant * stay linear (no PBS), exactly as on a Tracer.
+  * `Circuit` — records every table look-up (`lut`, `lut2`, `mul`) as a PBS node whose input is a `Lin`,
+                assigns each node its ASAP level (1 + the deepest leaf it reads) and exposes, per level, the
+                CSR description (row_ptr / idx / coef / const) the GPU executor feeds to
+                bmi_lincomb_batch + bmi_pbs_batch.  Identical look-ups are shared (CSE).
+  * `simulate`— plaintext evaluation of the recorded graph (the analogue of `circuit.simulate`,
+                main.py:107); it also checks every interval claim, so it doubles as the range checker.
+
+Encoding: every ciphertext carries a signed message m at scale 2^(63 - MSG_BITS) (MSG_BITS = 4: a PBS input
+must lie in [-8, 7]; between PBS, values may range over [-16, 15]).  A look-up whose input interval is
+narrower than 16 values is evaluated with a coarser message space (input multiplied by 2^(4-p)), which
+widens the decision boxes and makes mod-switch failures vanishingly rare.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+MSG_BITS = 4
+DELTA_LOG = 63 - MSG_BITS  # 59
+
+
+class RangeError(ValueError):
+    pass
+
+
+class Lin:
+    __slots__ = ("c", "terms", "const", "lo", "hi")
+
+    def __init__(self, c, terms, const, lo, hi):
+        self.c, self.terms, self.const, self.lo, self.hi = c, terms, const, lo, hi
+
+    # ---- linear algebra (no PBS) -----------------------------------------------------------------
+    def _coerce(self, o):
+        if isinstance(o, Lin):
+            return o
+        if isinstance(o, (int, np.integer, bool, np.bool_)):
+            return Lin(self.c, {}, int(o), int(o), int(o))
+        return None
+
+    def __add__(self, o):
+        o = self._coerce(o)
+        if o is None:
+            return NotImplemented
+        if not o.terms:
+            return Lin(self.c, self.terms, self.const + o.const, self.lo + o.const, self.hi + o.const)
+        if not self.terms:
+            return Lin(self.c, o.terms, self.const + o.const, o.lo + self.const, o.hi + self.const)
+        a, b = (self.terms, o.terms) if len(self.terms) >= len(o.terms) else (o.terms, self.terms)
+        t = dict(a)
+        for k, v in b.items():
+            nv = t.get(k, 0) + v
+            if nv:
+                t[k] = nv
+            else:
+                del t[k]
+        r = Lin(self.c, t, self.const + o.const, self.lo + o.lo, self.hi + o.hi)
+        if not t:
+            r.lo = r.hi = r.const
+        return r
+
+    __radd__ = __add__
+
+    def __neg__(self):
+        return Lin(self.c, {k: -v for k, v in self.terms.items()}, -self.const, -self.hi, -self.lo)
+
+    def __sub__(self, o):
+        o = self._coerce(o)
+        if o is None:
+            return NotImplemented
+        return self + (-o)
+
+    def __rsub__(self, o):
+        return (-self) + o
+
+    def __mul__(self, o):
+        if isinstance(o, Lin):
+            return self.c.mul(self, o)
+        if isinstance(o, (int, np.integer, bool, np.bool_)):
+            k = int(o)
+            if k == 0:
+                return self.c.const(0)
+            if k == 1:
+                return self
+            lo, hi = (self.lo * k, self.hi * k) if k > 0 else (self.hi * k, self.lo * k)
+            return Lin(self.c, {t: v * k for t, v in self.terms.items()}, self.const * k, lo, hi)
+        return NotImplemented
+
+    __rmul__ = __mul__
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    @property
+    def is_const(self):
+        return not self.terms
+
+    def assume(self, lo, hi):
+        """Tighten the interval with knowledge the interval arithmetic cannot derive (checked by simulate)."""
+        lo, hi = max(lo, self.lo), min(hi, self.hi)
+        if lo > hi:
+            raise RangeError(f"empty interval after assume: [{lo}, {hi}]")
+        if self.is_const:
+            return self
+        r = Lin(self.c, self.terms, self.const, lo, hi)
+        self.c.claims.append((self.c._snapshot(r), lo, hi))
+        return r
+
+    def lut(self, fn):
+        return self.c.lut(self, fn)
+
+    def lt0(self):
+        return self.c.lut(self, _LT0)
+
+    def ge0(self):
+        return self.c.lut(self, _GE0)
+
+    def gt0(self):
+        return self.c.lut(self, _GT0)
+
+    def eq0(self):
+        return self.c.lut(self, _EQ0)
+
+    def ne0(self):
+        return self.c.lut(self, _NE0)
+
+    def __repr__(self):
+        return f"Lin(const={self.const}, {len(self.terms)} terms, [{self.lo},{self.hi}])"
+
+
+def _LT0(v):
+    return int(v < 0)
+
+
+def _GE0(v):
+    return int(v >= 0)
+
+
+def _GT0(v):
+    return int(v > 0)
+
+
+def _EQ0(v):
+    return int(v == 0)
+
+
+def _NE0(v):
+    return int(v != 0)
+
+
+class Circuit:
+    def __init__(self):
+        self.n_inputs = 0
+        self.leaf_level = []     # per leaf
+        self.leaf_lo = []
+        self.leaf_hi = []
+        self.nodes = []          # PBS nodes, in creation order: (terms tuple, const, lut_index, out_leaf)
+        self.luts = []           # (p, table tuple)
+        self._lut_index = {}
+        self._cse = {}
+        self.claims = []         # (snapshot, lo, hi) interval claims to be verified by simulate()
+        self.outputs = []        # snapshots of output Lins
+        self.stats = {"pbs": 0, "cse_hits": 0, "const_folds": 0}
+
+    # ---- construction ----------------------------------------------------------------------------
+    def input(self, lo, hi):
+        leaf = len(self.leaf_level)
+        if leaf != self.n_inputs:
+            raise ValueError("declare all inputs before the first look-up")
+        self.n_inputs += 1
+        self.leaf_level.append(0)
+        self.leaf_lo.append(lo)
+        self.leaf_hi.append(hi)
+        return Lin(self, {leaf: 1}, 0, lo, hi)
+
+    def const(self, v):
+        return Lin(self, {}, int(v), int(v), int(v))
+
+    def _snapshot(self, x):
+        return (tuple(sorted(x.terms.items())), x.const)
+
+    def level_of(self, x):
+        return max((self.leaf_level[t] for t in x.terms), default=0)
+
+    def lut(self, x, fn):
+        """Univariate table look-up f(x): one PBS (or a constant fold)."""
+        if not isinstance(x, Lin):
+            return self.const(fn(int(x)))
+        if x.is_const:
+            self.stats["const_folds"] += 1
+            return self.const(fn(x.const))
+        width = x.hi - x.lo + 1
+        if width > (1 << MSG_BITS):
+            raise RangeError(f"look-up input interval [{x.lo}, {x.hi}] wider than {1 << MSG_BITS} values")
+        vals = [int(fn(v)) for v in range(x.lo, x.hi + 1)]
+        olo, ohi = min(vals), max(vals)
+        if olo == ohi:
+            self.stats["const_folds"] += 1
+            return self.const(olo)
+        if not (-(1 << MSG_BITS) <= olo and ohi < (1 << MSG_BITS)):
+            raise RangeError(f"look-up output interval [{olo}, {ohi}] does not fit the message space")
+        p = 1
+        while (1 << p) < width:
+            p += 1
+        half = 1 << (p - 1)
+        off = x.lo + half  # message m = x - off in [-half, half)
+        # table over m; entries outside the reachable interval repeat the nearest reachable value
+        table = tuple(vals[min(max(m + half, 0), width - 1)] for m in range(-half, half))
+        key = (p, table)
+        li = self._lut_index.get(key)
+        if li is None:
+            li = len(self.luts)
+            self.luts.append(key)
+            self._lut_index[key] = li
+        scale = 1 << (MSG_BITS - p)
+        pin = (x - off) * scale
+        snap = self._snapshot(pin)
+        ck = (snap, li)
+        leaf = self._cse.get(ck)
+        if leaf is None:
+            leaf = len(self.leaf_level)
+            self.leaf_level.append(self.level_of(x) + 1)
+            self.leaf_lo.append(olo)
+            self.leaf_hi.append(ohi)
+            self.nodes.append((snap[0], snap[1], li, leaf))
+            self._cse[ck] = leaf
+            self.stats["pbs"] += 1
+        else:
+            self.stats["cse_hits"] += 1
+        return Lin(self, {leaf: 1}, 0, olo, ohi)
+
+    def lut2(self, x, y, fn):
+        """Bivariate look-up f(x, y) as ONE PBS on the packed value (x - xlo) * ny + (y - ylo)."""
+        if not isinstance(x, Lin):
+            x = self.const(x)
+        if not isinstance(y, Lin):
+            y = self.const(y)
+        if x.is_const and y.is_const:
+            return self.const(fn(x.const, y.const))
+        if x.is_const:
+            return self.lut(y, lambda v, a=x.const: fn(a, v))
+        if y.is_const:
+            return self.lut(x, lambda v, b=y.const: fn(v, b))
+        nx, ny = x.hi - x.lo + 1, y.hi - y.lo + 1
+        if nx * ny > (1 << MSG_BITS):
+            raise RangeError(f"bivariate look-up needs {nx}x{ny} > {1 << MSG_BITS} packed values")
+        xlo, ylo = x.lo, y.lo
+        z = (x - xlo) * ny + (y - ylo)
+        z.lo, z.hi = 0, nx * ny - 1
+        return self.lut(z, lambda v: fn(v // ny + xlo, v % ny + ylo))
+
+    def mul(self, x, y):
+        """ciphertext x ciphertext product: packed bivariate PBS when the ranges allow it, otherwise the
+        quarter-square identity xy = floor((x+y)^2/4) - floor((x-y)^2/4) (two PBS)."""
+        if not isinstance(x, Lin):
+            return y * x
+        if not isinstance(y, Lin):
+            return x * y
+        if x.is_const:
+            return y * x.const
+        if y.is_const:
+            return x * y.const
+        nx, ny = x.hi - x.lo + 1, y.hi - y.lo + 1
+        if nx * ny <= (1 << MSG_BITS):
+            return self.lut2(x, y, lambda a, b: a * b)
+        if nx + ny - 1 <= (1 << MSG_BITS):
+            return self.lut(x + y, lambda s: (s * s) // 4) - self.lut(x - y, lambda d: (d * d) // 4)
+        raise RangeError(f"product of intervals [{x.lo},{x.hi}] x [{y.lo},{y.hi}] does not fit")
+
+    def select(self, bit, x, y):
+        """bit ? x : y  (bit in {0,1}) = y + bit * (x - y), one PBS."""
+        r = y + self.mul(bit, x - y)
+        lo = min(_lo(x), _lo(y))
+        hi = max(_hi(x), _hi(y))
+        return r.assume(lo, hi) if isinstance(r, Lin) else r
+
+    def set_outputs(self, lins):
+        self.outputs = [self._snapshot(x if isinstance(x, Lin) else self.const(x)) for x in lins]
+        self.out_ranges = [(_lo(x), _hi(x)) for x in lins]
+
+    # ---- schedule --------------------------------------------------------------------------------
+    def levels(self):
+        """PBS nodes grouped by ASAP level: list (level 1..D) of lists of node indices."""
+        depth = max(self.leaf_level, default=0)
+        out = [[] for _ in range(depth)]
+        for i, (_, _, _, leaf) in enumerate(self.nodes):
+            out[self.leaf_level[leaf] - 1].append(i)
+        return out
+
+    def summary(self):
+        lv = self.levels()
+        widths = [len(x) for x in lv]
+        return {"inputs": self.n_inputs, "pbs": len(self.nodes), "depth": len(lv), "luts": len(self.luts),
+                "max_width": max(widths, default=0), "mean_width": float(np.mean(widths)) if widths else 0.0,
+                "median_width": float(np.median(widths)) if widths else 0.0, **self.stats}
+
+    # ---- plaintext evaluation (the analogue of circuit.simulate, main.py:107) -----------------------
+    def simulate(self, inputs, check=True):
+        inputs = [int(v) for v in inputs]
+        if len(inputs) != self.n_inputs:
+            raise ValueError("wrong number of inputs")
+        val = [0] * len(self.leaf_level)
+        for i, v in enumerate(inputs):
+            if check and not (self.leaf_lo[i] <= v <= self.leaf_hi[i]):
+                raise RangeError(f"input {i} = {v} outside its declared interval [{self.leaf_lo[i]}, {self.leaf_hi[i]}]")
+            val[i] = v
+        half_space = 1 << (MSG_BITS - 1)
+        for terms, const, li, leaf in self.nodes:
+            p, table = self.luts[li]
+            x = const + sum(cf * val[t] for t, cf in terms)
+            scale = 1 << (MSG_BITS - p)
+            if check and not (-half_space <= x < half_space):
+                raise RangeError(f"PBS input {x} outside the message space")
+            if check and x % scale:
+                raise RangeError("PBS input not a multiple of its scale")
+            m = x // scale
+            out = table[m + (1 << (p - 1))]
+            if check and not (self.leaf_lo[leaf] <= out <= self.leaf_hi[leaf]):
+                raise RangeError("look-up output outside its interval")
+            val[leaf] = out
+        if check:
+            for (terms, const), lo, hi in self.claims:
+                x = const + sum(cf * val[t] for t, cf in terms)
+                if not (lo <= x <= hi):
+                    raise RangeError(f"interval claim [{lo}, {hi}] violated by value {x}")
+        return [const + sum(cf * val[t] for t, cf in terms) for terms, const in self.outputs]
+
+
+def _lo(x):
+    return x.lo if isinstance(x, Lin) else int(x)
+
+
+def _hi(x):
+    return x.hi if isinstance(x, Lin) else int(x)

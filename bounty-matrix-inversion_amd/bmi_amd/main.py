@@ -1,0 +1,122 @@
+"""EncryptedMatrixInversion — the drop-in counterpart of the reference's API wrapper
+(matrix_inversion/main.py:17-116): same constructor arguments and the same
+quantize / encrypt / evaluate / decrypt / dequantize / run methods (+ keygen, which the reference reaches
+as `circuit.keygen()`, main.py:177).  `evaluate` runs every PBS on the MI355X through libbmi_tfhe.so and
+raises if the library or the GPU is missing; `run(..., simulate=True)` evaluates the traced circuit in
+plaintext, exactly like the reference's `circuit.simulate` branch (main.py:106-109)."""
+from __future__ import annotations
+
+import time
+from typing import Tuple
+
+import numpy as np
+
+from .circuit import Circuit, DELTA_LOG
+from .qfloat import QFloat
+from .qfloat_matrix_inversion import (float_matrix_to_qfloat_arrays, qfloat_and_signs_arrays_to_float_matrix,
+                                      qfloat_matrix_inverse)
+
+
+def trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base=2, true_division=False, tensorize=False):
+    """Builds the PBS circuit of qfloat_matrix_inverse (the analogue of fhe.Compiler(...).compile, main.py:53-66).
+    Inputs are declared in the order: all n^2 * len digits (row-major), then the n^2 signs.
+    Digit intervals: leading digit [0, 2*base - 1] (from_float does not reduce it), others
+    [0, base - 1]; signs [-1, 1]."""
+    c = Circuit()
+    top = 2 * qfloat_base - 1
+    arrays = [[c.input(0, top if j == 0 else qfloat_base - 1) for j in range(qfloat_len)] for _ in range(n * n)]
+    signs = [c.input(-1, 1) for _ in range(n * n)]
+    QFloat.reset_stats()
+    out = qfloat_matrix_inverse(arrays, signs, n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize)
+    c.set_outputs([x for row in out for x in row])
+    return c
+
+
+class EncryptedMatrixInversion:
+    shape: Tuple[int, int]
+
+    def __init__(self, n, sampler=None, qfloat_base=2, qfloat_len=32, qfloat_ints=16, true_division=False,
+                 tensorize=False, engine=None, device=0):
+        self.shape = (n, n)
+        self.qfloat_base, self.qfloat_len, self.qfloat_ints = qfloat_base, qfloat_len, qfloat_ints
+        self.true_division, self.tensorize = true_division, tensorize
+        # The reference calls sampler() 100 times to let Concrete measure value ranges (main.py:41-47);
+        # here ranges are derived by interval analysis, so the sampler is only validated.
+        if sampler is not None:
+            s = sampler()
+            assert isinstance(s, np.ndarray) and np.issubdtype(s.dtype, np.floating) and s.shape == self.shape
+        t0 = time.time()
+        self.circuit = trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize)
+        self.trace_seconds = time.time() - t0
+        self.engine = engine
+        self.device = device
+        self._exec = None
+
+    # ---- key generation / engine -------------------------------------------------------------------
+    def _engine(self):
+        if self.engine is None:
+            from . import tfhe  # raises BmiError when libbmi_tfhe.so or the GPU is missing: no CPU fallback
+            self.engine = tfhe.Engine(device=self.device)
+        return self.engine
+
+    def keygen(self, seed=0x5EED):
+        self._engine().keygen(seed)
+
+    def _executor(self):
+        if self._exec is None:
+            from .executor import Executor
+            self._exec = Executor(self.circuit, self._engine())
+        return self._exec
+
+    # ---- the reference's six methods -----------------------------------------------------------------
+    def quantize(self, matrix: np.ndarray):
+        return float_matrix_to_qfloat_arrays(matrix, self.qfloat_len, self.qfloat_ints, self.qfloat_base)
+
+    def _flat_inputs(self, quantized_matrix, qfloats_signs):
+        q = np.asarray(quantized_matrix, dtype=np.int64)
+        s = np.asarray(qfloats_signs, dtype=np.int64)
+        n2 = self.shape[0] * self.shape[1]
+        if q.shape != (n2, self.qfloat_len) or s.shape != (n2,):
+            raise ValueError("quantized matrix / signs have the wrong shape")
+        flat = np.concatenate([q.reshape(-1), s])
+        c = self.circuit
+        for i, v in enumerate(flat):
+            if not (c.leaf_lo[i] <= v <= c.leaf_hi[i]):
+                raise ValueError(f"input {i} = {v} outside the interval [{c.leaf_lo[i]}, {c.leaf_hi[i]}] the circuit "
+                                 "was traced for (matrix entry too large for qfloat_ints?)")
+        return flat
+
+    def encrypt(self, quantized_matrix: np.ndarray, qfloats_signs: np.ndarray) -> np.ndarray:
+        flat = self._flat_inputs(quantized_matrix, qfloats_signs)
+        return self._engine().encrypt(flat, DELTA_LOG)
+
+    def evaluate(self, encrypted_quantized_matrix: np.ndarray) -> np.ndarray:
+        return self._executor().run(encrypted_quantized_matrix)
+
+    def decrypt(self, encrypted_quantized_inverted_matrix: np.ndarray) -> np.ndarray:
+        n2 = self.shape[0] * self.shape[1]
+        m = self._engine().decrypt(encrypted_quantized_inverted_matrix, DELTA_LOG)
+        return m.reshape(n2, self.qfloat_len + 1)
+
+    def dequantize(self, quantized_inverted_matrix: np.ndarray) -> np.ndarray:
+        return qfloat_and_signs_arrays_to_float_matrix(quantized_inverted_matrix, self.qfloat_ints, self.qfloat_base)
+
+    def simulate(self, quantized_matrix, qfloats_signs) -> np.ndarray:
+        n2 = self.shape[0] * self.shape[1]
+        flat = self._flat_inputs(quantized_matrix, qfloats_signs)
+        return np.array(self.circuit.simulate(flat), dtype=np.int64).reshape(n2, self.qfloat_len + 1)
+
+    def run(self, matrix: np.ndarray, simulate=False) -> np.ndarray:
+        assert np.issubdtype(matrix.dtype, np.floating)
+        assert matrix.shape == self.shape
+        quantized_matrix, qfloats_signs = self.quantize(matrix)
+        if not simulate:
+            enc = self.encrypt(quantized_matrix, qfloats_signs)
+            enc_inv = self.evaluate(enc)
+            quantized_inverted_matrix = self.decrypt(enc_inv)
+        else:
+            quantized_inverted_matrix = self.simulate(quantized_matrix, qfloats_signs)
+        inverted_matrix = self.dequantize(quantized_inverted_matrix)
+        assert np.issubdtype(inverted_matrix.dtype, np.floating)
+        assert inverted_matrix.shape == self.shape
+        return inverted_matrix

@@ -61,6 +61,7 @@ _SIGS = {
     "bmi_blind_rotate_batch_host": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
     "bmi_negacyclic_mul_host": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
     "bmi_sync": [C.c_void_p, C.c_void_p],
+    "bmi_reserve": [C.c_void_p, C.c_uint32],
     "bmi_set_kernel_variant": [C.c_void_p, C.c_int],
     "bmi_key_bytes": [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
 }
@@ -264,6 +265,9 @@ class Engine:
     def lincomb(self, d_store, d_row_ptr, d_idx, d_coef, d_const, count, d_out, stream=0):
         self._ck(self.lib.bmi_lincomb_batch(self.h, _ptr(d_store), _ptr(d_row_ptr), _ptr(d_idx), _ptr(d_coef),
                                             _ptr(d_const), count, _ptr(d_out), C.c_void_p(stream)), "bmi_lincomb_batch")
+
+    def reserve(self, max_count):
+        self._ck(self.lib.bmi_reserve(self.h, int(max_count)), "bmi_reserve")
 
     def sync(self, stream=0):
         self._ck(self.lib.bmi_sync(self.h, C.c_void_p(stream)), "bmi_sync")

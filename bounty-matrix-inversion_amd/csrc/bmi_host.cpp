@@ -448,6 +448,13 @@ int bmi_lincomb_batch(bmi_ctx *c, const uint64_t *d_store, const uint32_t *d_row
     return rc ? fail(c, -2, std::string("lincomb launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
 }
 
+int bmi_reserve(bmi_ctx *c, uint32_t max_count) {
+    if (!c) return -1;
+    HIP_OK(c, hipSetDevice(c->device));
+    HIP_OK(c, hipDeviceSynchronize());
+    return ensure_small(c, max_count);
+}
+
 int bmi_sync(bmi_ctx *c, void *stream) {
     if (!c) return -1;
     HIP_OK(c, hipStreamSynchronize((hipStream_t)stream));

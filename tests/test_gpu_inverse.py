@@ -1,0 +1,71 @@
+"""Encrypted QFloat operations and the encrypted 2x2 inverse on the MI355X (BASELINE config 2), end to end
+through the C ABI: quantize -> encrypt -> evaluate (every PBS on the GPU) -> decrypt -> dequantize.
+Decrypted digits/signs must equal the reference's plaintext QFloat output (golden fixtures): bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    with open(os.path.join(G, name)) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bmi_amd import tfhe
+    e = tfhe.Engine()
+    e.keygen(0x5EED)
+    yield e
+    e.close()
+
+
+def test_encrypted_qfloat_ops_on_gpu(eng):
+    """a + b, a * b, a > b on encrypted QFloats (pattern of tests/test_qfloat_fhe.py:186-246, exact digits)."""
+    from bmi_amd.circuit import Circuit, DELTA_LOG
+    from bmi_amd.executor import Executor
+    from bmi_amd.qfloat import QFloat
+    c = load("qfloat_ops.json")["pairs"]
+    c = next(x for x in c if x["base"] == 2 and x["len"] <= 22)
+    circ = Circuit()
+
+    def enc(g):
+        d = [circ.input(0, 3 if i == 0 else 1) for i in range(len(g["array"]))]
+        s = circ.input(-1, 1)
+        return QFloat(d, g["ints"], 2, True, s), list(g["array"]) + [g["sign"]]
+
+    a, va = enc(c["q1"])
+    b, vb = enc(c["q2"])
+    add, mul, gt = a + b, a * b, a > b
+    circ.set_outputs(list(add.array) + [add.sign] + list(mul.array) + [mul.sign] + [gt])
+    vals = va + vb
+    want = circ.simulate(vals)
+    ex = Executor(circ, eng)
+    out = eng.decrypt(ex.run(eng.encrypt(vals, DELTA_LOG)), DELTA_LOG)
+    assert list(out) == want
+    ln = c["len"]
+    assert list(out[:ln]) == c["add"]["array"] and out[ln] == c["add"]["sign"]
+    assert list(out[ln + 1:2 * ln + 1]) == c["mul"]["array"] and out[2 * ln + 1] == c["mul"]["sign"]
+    assert out[-1] == c["gt"]
+
+
+@pytest.mark.parametrize("tag", ["survey_2x2", "baseline_n2_len20_ints8"])
+def test_encrypted_2x2_inverse_matches_reference_golden(eng, tag):
+    from bmi_amd.main import EncryptedMatrixInversion
+    c = next(x for x in load("inverse.json") if x["tag"] == tag)
+    emi = EncryptedMatrixInversion(2, None, 2, c["len"], c["ints"], False, False, engine=eng)
+    M = np.array(c["M"]).reshape(2, 2)
+    q, s = emi.quantize(M)
+    enc = emi.encrypt(q, s)
+    assert enc.shape == (84, 1025)
+    out = emi.decrypt(emi.evaluate(enc))
+    assert out.tolist() == c["out"]                       # digits and signs identical to the reference's
+    assert emi.dequantize(out).flatten().tolist() == c["float"]
+    got = emi.run(M)                                      # the one-call form (main.py:93-116)
+    assert got.flatten().tolist() == c["float"]
+    assert np.max(np.abs(got - np.linalg.inv(M))) < 0.01
