@@ -64,8 +64,10 @@ def main():
     eng.keygen(0x5EED)  # keys replicated on every GPU (same seed)
     P = eng.P
     B = args.batch
-    rng = np.random.default_rng(1234 + rank)
-    msgs = rng.integers(-8, 8, B)
+    from bmi_amd.shard import shard_range
+    # the whole job's batch is B * world ciphertexts (weak scaling); rank r owns a contiguous range of it
+    lo, hi = shard_range(B * world, rank, world)
+    msgs = np.random.default_rng(1234).integers(-8, 8, B * world)[lo:hi]
     ident = eng.lut_register(np.arange(-8, 8), 4, 59)
     rnd_table = np.random.default_rng(99).integers(-8, 8, 16)
     rlut = eng.lut_register(rnd_table, 4, 59)
