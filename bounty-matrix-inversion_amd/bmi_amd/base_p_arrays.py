@@ -134,34 +134,87 @@ def any_positive(c, xs):
         xs = flags
 
 
+def _sign3(v):
+    return (v > 0) - (v < 0)
+
+
+def _comb(h, l):
+    """borrow-lookahead operator on signals in {-1: generate, 0: propagate, +1: kill}: the more significant
+    signal wins unless it propagates"""
+    return h if h else l
+
+
+def _prefix_borrows(c, sig, first_bit):
+    """Kogge-Stone parallel prefix over signals sig[0..m-1] (index 0 = least significant).  Returns
+    bits[i] = 1 iff a borrow leaves position i, i.e. the combined signal of positions 0..i is 'generate'.
+    Depth ceil(log2 m) look-up levels instead of m; every node is one packed 3x3 bivariate look-up."""
+    m = len(sig)
+    bits = [None] * m
+    bits[0] = first_bit
+    S = list(sig)
+    d = 1
+    while d < m:
+        newS = list(S)
+        for i in range(d, m):
+            hi, lo = S[i], S[i - d]
+            if i < 2 * d:  # positions d..2d-1 become final at this level
+                bits[i] = lut2(c, hi, lo, lambda h, l: int(_comb(h, l) == -1))
+            if i + 2 * d < m or (i >= 2 * d):  # still needed as an operand (or not final yet)
+                newS[i] = lut2(c, hi, lo, _comb)
+        S = newS
+        d *= 2
+    return bits
+
+
 def base_p_subtraction(c, a, b, p, overflow=False):
-    """reference base_p_arrays.py:108-139: borrow-chain a - b, right-aligned; one look-up per digit
-    (the borrow); the digit itself is linear: t + p * borrow."""
+    """reference base_p_arrays.py:108-139: a - b with borrows, right-aligned, and (overflow=True) the flag a < b
+    as defined there for unequal sizes.  Same integers as the reference's sequential borrow chain, computed
+    by borrow look-ahead: per digit the signal sign(a_i - b_i) (a borrow leaves digit i iff the signals of
+    digits 0..i combine to 'generate'), a log-depth parallel prefix, then digit_i = a_i - b_i - bin_i + p*bout_i
+    (linear).  Valid for any integer digits (non-binary leading digits included)."""
     m = min(len(a), len(b))
     out = [0] * len(a)
-    borrow = 0
-    for k in range(1, m + 1):
-        t = a[-k] - b[-k] - borrow
-        borrow = lut(c, t, lambda v: int(v < 0))
-        d = t + p * borrow
-        if isinstance(d, Lin) and isinstance(t, Lin):
-            vals = [v + p * (v < 0) for v in range(t.lo, t.hi + 1)]
+    extra = len(b) - len(a)
+    deltas = [a[-k] - b[-k] for k in range(1, m + 1)]  # least significant first
+    if all(not isinstance(d, Lin) for d in deltas) and (not overflow or extra == 0 or all(
+            not isinstance(x, Lin) for x in (a[:-extra] if extra < 0 else b[:extra]))):
+        # compile-time constants: the plain chain
+        borrow = 0
+        for k in range(m):
+            t = deltas[k] - borrow
+            borrow = int(t < 0)
+            out[-k - 1] = t + p * borrow
+        if not overflow:
+            return out
+        if extra == 0:
+            return out, borrow
+        if extra < 0:
+            out[:-extra] = a[:-extra]
+            return out, borrow & int(sum(int(x) for x in a[:-extra]) == 0)
+        return out, borrow | int(sum(int(x) for x in b[:extra]) > 0)
+    sig = [lut(c, d, _sign3) for d in deltas]
+    pseudo = None
+    if overflow and extra < 0:
+        # a < b  <=>  borrow out and the extra leading digits of a sum to zero: a 'propagate / kill' position on top
+        pseudo = 1 - sum_is_zero(c, a[:-extra])        # 0 = propagate (all zero), 1 = kill
+        out[:-extra] = a[:-extra]
+    elif overflow and extra > 0:
+        pseudo = -1 * sum_is_positive(c, b[:extra])     # 0 = propagate, -1 = generate
+    if pseudo is not None:
+        sig = sig + [pseudo]
+    bits = _prefix_borrows(c, sig, lut(c, deltas[0], lambda v: int(v < 0)))
+    for k in range(m):
+        bin_k = bits[k - 1] if k > 0 else 0
+        t = deltas[k] - bin_k
+        d = t + p * bits[k]
+        if isinstance(d, Lin):
+            tlo, thi = lo_of(t), hi_of(t)
+            vals = [v + p * (v < 0) for v in range(tlo, thi + 1)]
             d = d.assume(min(vals), max(vals))
-        out[-k] = d
+        out[-k - 1] = d
     if not overflow:
         return out
-    extra = len(b) - len(a)
-    if extra == 0:
-        lt = borrow
-    elif extra < 0:
-        # a < b  <=>  borrow and the extra leading digits of a are all zero
-        zero = sum_is_zero(c, a[:-extra])
-        lt = lut2(c, borrow, zero, lambda bo, z: bo & z)
-        out[:-extra] = a[:-extra]
-    else:
-        pos = sum_is_positive(c, b[:extra])
-        lt = lut2(c, borrow, pos, lambda bo, z: bo | z)
-    return out, lt
+    return out, bits[-1]
 
 
 def base_p_division(c, dividend, divisor, p):
@@ -182,12 +235,27 @@ def base_p_division(c, dividend, divisor, p):
 
 
 def is_greater_or_equal(c, a, b):
-    """reference base_p_arrays.py:245-260."""
+    """reference base_p_arrays.py:245-260: 1 - (borrow out of a - b), by borrow look-ahead (log depth)."""
     m = min(len(a), len(b))
-    borrow = 0
-    for k in range(1, m + 1):
-        borrow = lut(c, a[-k] - b[-k] - borrow, lambda v: int(v < 0))
-    return 1 - borrow
+    deltas = [a[-k] - b[-k] for k in range(1, m + 1)]
+    if all(not isinstance(d, Lin) for d in deltas):
+        borrow = 0
+        for d in deltas:
+            borrow = int(d - borrow < 0)
+        return 1 - borrow
+    sig = [lut(c, d, _sign3) for d in deltas]
+    # tree reduction of the combined signal (most significant wins unless it propagates)
+    first = lut(c, deltas[0], lambda v: int(v < 0))
+    if m == 1:
+        return 1 - first
+    while len(sig) > 2:
+        nxt = []
+        for i in range(0, len(sig) - 1, 2):
+            nxt.append(lut2(c, sig[i + 1], sig[i], _comb))
+        if len(sig) % 2:
+            nxt.append(sig[-1])
+        sig = nxt
+    return 1 - lut2(c, sig[1], sig[0], lambda h, l: int(_comb(h, l) == -1))
 
 
 def is_equal(c, a, b):
@@ -221,22 +289,33 @@ def carry_propagate_nonneg(c, columns, p):
 
     `columns[i]` is the list of terms of column i (each a Lin/int with lo >= 0).  Because every term is
     non-negative, truncation toward zero equals floor and the result is the plain base-p representation of
-    sum_i column_i * p^(L-1-i) mod p^L, so the sum may be reassociated freely: columns whose total exceeds
-    what one 4-bit look-up can hold are first compressed in parallel (each bin of terms -> its base-p
-    digits, pushed to the columns on the left), then one sequential chain of L look-ups finishes."""
+    sum_i column_i * p^(L-1-i) mod p^L, so the sum may be reassociated freely:
+      1. columns are compressed in parallel (each bin of terms whose sum fits one 4-bit look-up -> its base-p
+         digits, pushed to the columns on the left) until every column sums to at most 2(p-1), i.e. two
+         operands remain;
+      2. the final two-operand addition is a carry look-ahead: signal per column (>= p: generate, == p-1:
+         propagate, else kill), log-depth parallel prefix, digit_i = col_i + cin_i - p * cout_i (linear).
+    Depth ~ (3-4 compression rounds) + 1 + log2(L) instead of L."""
     L = len(columns)
     cols = [[t for t in col if not (not isinstance(t, Lin) and int(t) == 0)] for col in columns]
     for col in cols:
         for t in col:
             if lo_of(t) < 0:
                 raise RangeError("carry_propagate_nonneg needs non-negative terms")
-    # chain capacity: c = column + carry <= CAP with carry <= floor(CAP / p)
-    carry_cap = CAP // p
-    col_cap = CAP - carry_cap
-    while True:
-        over = [i for i in range(L) if sum(hi_of(t) for t in cols[i]) > col_cap]
-        if not over:
+    if all(not isinstance(t, Lin) for col in cols for t in col):
+        out, carry = [0] * L, 0
+        for i in range(L - 1, -1, -1):
+            s = carry + sum(int(t) for t in cols[i])
+            out[i], carry = s % p, s // p
+        return out
+    target = 2 * (p - 1)
+    for _round in range(12):
+        if all(sum(hi_of(t) for t in col) <= target for col in cols):
             break
+        # Compress every column that holds more than one digit's worth: a column left alone at the target would
+        # be pushed over it again by the digits arriving from its right neighbour (a ripple of one column per
+        # round); compressing all of them together is the carry-save step and converges in ~log rounds.
+        over = [i for i in range(L) if sum(hi_of(t) for t in cols[i]) > p - 1]
         new_cols = [list(col) if i not in over else [] for i, col in enumerate(cols)]
         for i in over:
             for terms, h in _pack_bins(cols[i], CAP):
@@ -247,25 +326,31 @@ def carry_propagate_nonneg(c, columns, p):
                     new_cols[i].append(s)
                     continue
                 j, w = 0, 1
-                while w <= h:  # digit j of the bin sum goes to column i - j
+                while w <= h:  # digit j of the bin sum goes to column i - j (dropped beyond column 0)
                     if i - j >= 0:
                         new_cols[i - j].append(lut(c, s, lambda v, w=w: (v // w) % p))
                     j += 1
                     w *= p
         cols = new_cols
-    out = [0] * L
-    carry = 0
-    for i in range(L - 1, -1, -1):
-        s = carry
-        for t in cols[i]:
+    else:
+        raise RangeError("column compression did not converge")
+    sums = []
+    for col in cols:
+        s = 0
+        for t in col:
             s = s + t
-        carry = lut(c, s, lambda v: v // p) if i > 0 else 0
-        if isinstance(s, Lin):
-            d = (s - p * carry) if i > 0 else lut(c, s, lambda v: v % p)
-            out[i] = d.assume(0, p - 1) if isinstance(d, Lin) else d
-        else:
-            out[i] = s % p
-            carry = (s // p) if i > 0 else 0
+        sums.append(s)
+    # carry look-ahead over positions L-1 (least significant) .. 0
+    lsb_first = sums[::-1]
+    sig = [lut(c, s, lambda v: -1 if v >= p else (0 if v == p - 1 else 1)) for s in lsb_first]
+    bits = _prefix_borrows(c, sig, lut(c, lsb_first[0], lambda v: int(v >= p)))
+    out = [0] * L
+    for k in range(L):
+        cin = bits[k - 1] if k > 0 else 0
+        d = lsb_first[k] + cin - p * bits[k]
+        if isinstance(d, Lin):
+            d = d.assume(0, p - 1)
+        out[L - 1 - k] = d
     return out
 
 

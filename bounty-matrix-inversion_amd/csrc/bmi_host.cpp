@@ -92,6 +92,9 @@ struct bmi_ctx {
     uint32_t *d_io_ids = nullptr;
     size_t io_cap = 0;
     int variant = 0;
+    uint32_t lat_threshold = 512;
+    uint32_t ks_slices = 64, ks_split_max = 64;
+    void *d_ks_partial = nullptr;
     mutable std::string err;
 };
 
@@ -213,7 +216,7 @@ void bmi_ctx_destroy(bmi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (void *p : {(void *)c->d_bsk, (void *)c->d_ksk, (void *)c->d_tw, (void *)c->d_luts, (void *)c->d_small,
-                    (void *)c->d_io_a, (void *)c->d_io_b, (void *)c->d_io_ids})
+                    (void *)c->d_io_a, (void *)c->d_io_b, (void *)c->d_io_ids, c->d_ks_partial})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -414,8 +417,14 @@ int bmi_set_kernel_variant(bmi_ctx *c, int variant) {
 int bmi_keyswitch_batch(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64_t *d_small, void *stream) {
     if (!c || (count && (!d_in || !d_small))) return -1;
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
-    int rc = bmi::launch_keyswitch(d_in, c->d_ksk, d_small, count, c->P.n, c->big_n, c->P.ks_levels, c->P.ks_base_log,
-                                   c->ks_stride, (hipStream_t)stream);
+    HIP_OK(c, hipSetDevice(c->device));
+    // small batches: split the 8192-row walk over KS_SLICES workgroups per tile (its length is the latency)
+    const bool split = (c->variant == 2 || (c->variant == 0 && count <= c->ks_split_max)) && count <= c->ks_split_max;
+    if (split && !c->d_ks_partial)
+        HIP_OK(c, hipMalloc(&c->d_ks_partial, (size_t)c->ks_slices * c->ks_split_max * c->ks_stride * 16));
+    int rc = bmi::launch_keyswitch(d_in, c->d_ksk, d_small, split ? c->d_ks_partial : nullptr, split ? c->ks_slices : 1,
+                                   count, c->P.n, c->big_n, c->P.ks_levels, c->P.ks_base_log, c->ks_stride,
+                                   (hipStream_t)stream);
     return rc ? fail(c, -2, std::string("keyswitch launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
 }
 
@@ -423,8 +432,14 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
                            uint64_t *d_out, void *stream) {
     if (!c || (count && (!d_small || !d_lut_ids || !d_out))) return -1;
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
-    int rc = bmi::launch_blind_rotate_tp(d_small, d_lut_ids, c->d_luts, c->d_bsk, c->d_tw, d_out, count, c->P.n,
-                                         (hipStream_t)stream);
+    HIP_OK(c, hipSetDevice(c->device));
+    // variant 0 = auto: the latency kernel (one workgroup per ciphertext) while the batch cannot fill the chip
+    // with one-wave-per-ciphertext work, the throughput kernel beyond that.
+    const bool latency = c->variant == 2 || (c->variant == 0 && count <= c->lat_threshold);
+    int rc = latency ? bmi::launch_blind_rotate_lat(d_small, d_lut_ids, c->d_luts, c->d_bsk, c->d_tw, d_out, count, c->P.n,
+                                                    (hipStream_t)stream)
+                     : bmi::launch_blind_rotate_tp(d_small, d_lut_ids, c->d_luts, c->d_bsk, c->d_tw, d_out, count, c->P.n,
+                                                   (hipStream_t)stream);
     return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
 }
 
@@ -452,6 +467,8 @@ int bmi_reserve(bmi_ctx *c, uint32_t max_count) {
     if (!c) return -1;
     HIP_OK(c, hipSetDevice(c->device));
     HIP_OK(c, hipDeviceSynchronize());
+    if (!c->d_ks_partial)
+        HIP_OK(c, hipMalloc(&c->d_ks_partial, (size_t)c->ks_slices * c->ks_split_max * c->ks_stride * 16));
     return ensure_small(c, max_count);
 }
 

@@ -88,7 +88,7 @@ __device__ __forceinline__ void decompose3x15(u64 a, int (&d)[3]) {
 // Accumulator (2 polynomials) lives in registers; LDS holds the twiddles (shared by the workgroup),
 // one transpose/rotation tile per wave and the mod-switched mask of the wave's ciphertext.
 template <int WAVES>
-__global__ void __launch_bounds__(64 * WAVES)
+__global__ void __launch_bounds__(64 * WAVES, 2)
     k_blind_rotate_tp(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
                       const u64 *__restrict__ luts, const u64 *__restrict__ bsk, const u64 *__restrict__ g_tw,
                       u64 *__restrict__ out, uint32_t count, uint32_t n) {
@@ -176,6 +176,104 @@ __global__ void __launch_bounds__(64 * WAVES)
     });
 }
 
+// LATENCY blind rotation: one workgroup of 8 wavefronts per ciphertext.  Per CMUX:
+//   phase A  waves 0..5: wave r = (component c, level lev) builds its digit polynomial from the LDS accumulator
+//            (rotation + decomposition) and forward-transforms it; the result stays in the wave's LDS tile.
+//            Every thread meanwhile prefetches its 24 bootstrap-key words for phase B.
+//   phase B  all 512 threads: 2 x 1024 output slots, 4 per thread, 6 multiply-accumulates each -> LDS.
+//   phase C  waves 0,1: inverse transform of one output polynomial each, accumulated into the LDS accumulator.
+// LDS: twiddles | acc[2][1024] | 6 tiles | Y[2][1024] | mod-switched mask.  ~101 KB -> one workgroup per CU.
+constexpr int LAT_THREADS = 512;
+constexpr int LAT_LDS_WORDS = TW_WORDS + 2 * N + 6 * SCRATCH_WORDS + 2 * N + 160;
+
+__global__ void __launch_bounds__(LAT_THREADS)
+    k_blind_rotate_lat(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
+                       const u64 *__restrict__ luts, const u64 *__restrict__ bsk, const u64 *__restrict__ g_tw,
+                       u64 *__restrict__ out, uint32_t count, uint32_t n) {
+    extern __shared__ u64 lds[];
+    u64 *acc = lds + TW_WORDS;                  // [2][N], natural coefficient order
+    u64 *tiles = acc + 2 * N;                   // [6][SCRATCH_WORDS]
+    u64 *Y = tiles + 6 * SCRATCH_WORDS;         // [2][N], evaluation layout
+    uint16_t *at = reinterpret_cast<uint16_t *>(Y + 2 * N);
+    stage_twiddles(lds, g_tw);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t ct = blockIdx.x;
+    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
+    for (uint32_t i = tid; i <= n; i += LAT_THREADS) at[i] = (uint16_t)gl::modswitch(lwe[i], LOG_N + 1);
+    __syncthreads();
+    {
+        const u64 *tv = luts + (size_t)lut_ids[ct] * N;
+        const uint32_t bt = at[n];
+        for (int m = tid; m < N; m += LAT_THREADS) {
+            const uint32_t e = (m + bt) & (2 * N - 1);
+            const u64 v = tv[e & (N - 1)];
+            acc[m] = 0;
+            acc[N + m] = (e & N) ? gl::neg(v) : v;
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t a_t = at[i];
+        if (a_t == 0) continue;  // uniform over the workgroup
+        const u64 *bsk_i = bsk + (size_t)i * 12 * N;
+        // prefetch for phase B: slot = tid + 512 m -> (oc, idx); rows r = 0..5
+        u64 b[4][6];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int slot = tid + LAT_THREADS * m, oc = slot >> LOG_N, idx = slot & (N - 1);
+#pragma unroll
+            for (int r = 0; r < 6; r++) b[m][r] = bsk_i[(size_t)(r * 2 + oc) * N + idx];
+        }
+        if (wave < 6) {
+            const int c = wave / 3, lev = wave - 3 * c;
+            const u64 *a = acc + c * N;
+            u64 x[16];
+            static_for<0, 16>([&](auto J) {
+                const uint32_t mm = lane + 64 * J;
+                const uint32_t e = (mm + 2 * N - a_t) & (2 * N - 1);
+                u64 v = a[e & (N - 1)];
+                v = (e & N) ? gl::neg(v) : v;
+                int d[3];
+                decompose3x15(gl::sub(v, a[mm]), d);
+                x[J] = gl::from_i64((i64)(lev == 0 ? d[0] : (lev == 1 ? d[1] : d[2])));
+            });
+            u64 *tile = tiles + wave * SCRATCH_WORDS;
+            forward(x, lane, lds, tile);
+            wave_sync();
+            static_for<0, 16>([&](auto V) { tile[eval_offset(lane, V)] = x[V]; });
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int slot = tid + LAT_THREADS * m, idx = slot & (N - 1);
+            u64 y = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) y = gl::add(y, gl::mul(tiles[r * SCRATCH_WORDS + idx], b[m][r]));
+            Y[slot] = y;
+        }
+        __syncthreads();
+        if (wave < 2) {
+            u64 x[16];
+            static_for<0, 16>([&](auto V) { x[V] = Y[wave * N + eval_offset(lane, V)]; });
+            u64 *tile = tiles + wave * SCRATCH_WORDS;
+            inverse(x, lane, lds, tile);
+            u64 *a = acc + wave * N;
+            static_for<0, 16>([&](auto J) { a[lane + 64 * J] = gl::add(a[lane + 64 * J], x[J]); });
+        }
+        __syncthreads();
+    }
+    u64 *o = out + (size_t)ct * (N + 1);
+    for (int m = tid; m < N; m += LAT_THREADS) {
+        if (m == 0) {
+            o[0] = acc[0];
+            o[N] = acc[N];
+        } else {
+            o[N - m] = gl::neg(acc[m]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Keyswitch: out = (0,...,0,b) - sum_j sum_lev dec_lev(a_j) * KSK[j][lev].  One workgroup handles KS_TILE
 // ciphertexts; thread t owns output columns t, t+256, t+512.  Digits are staged in LDS (int8).
@@ -192,18 +290,25 @@ __device__ __forceinline__ u64 reduce_neg_i128(__int128 a) {
     return negative ? gl::neg(r) : r;
 }
 
+// SPLIT = false: one workgroup walks all rows and writes the finished small ciphertexts (throughput form).
+// SPLIT = true : blockIdx.y selects a slice of the coefficients; the workgroup writes its 128-bit partial sums
+//                and k_keyswitch_reduce finishes (latency form for small batches: the row walk is the latency).
+template <bool SPLIT>
 __global__ void __launch_bounds__(KS_THREADS)
-    k_keyswitch(const u64 *__restrict__ in, const u64 *__restrict__ ksk, u64 *__restrict__ out, uint32_t count,
-                uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride) {
-    extern __shared__ signed char digits[];  // [KS_TILE][big_n * levels]
+    k_keyswitch(const u64 *__restrict__ in, const u64 *__restrict__ ksk, u64 *__restrict__ out,
+                unsigned __int128 *__restrict__ partial, uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels,
+                uint32_t base_log, uint32_t ks_stride, uint32_t coefs_per_slice) {
+    extern __shared__ signed char digits[];  // [KS_TILE][slice coefficients * levels]
     const uint32_t first = blockIdx.x * KS_TILE;
     const uint32_t tile = min((uint32_t)KS_TILE, count - first);
-    const uint32_t rows = big_n * levels;
+    const uint32_t j0 = SPLIT ? blockIdx.y * coefs_per_slice : 0;
+    const uint32_t nj = SPLIT ? min(coefs_per_slice, big_n - j0) : big_n;
+    const uint32_t rows = nj * levels;
     const uint32_t shift = 64 - levels * base_log;
     const i64 B = (i64)1 << base_log, half = B >> 1;
-    for (uint32_t idx = threadIdx.x; idx < tile * big_n; idx += KS_THREADS) {
-        const uint32_t b = idx / big_n, j = idx % big_n;
-        const i64 c = gl::centered(in[(size_t)(first + b) * (big_n + 1) + j]);
+    for (uint32_t idx = threadIdx.x; idx < tile * nj; idx += KS_THREADS) {
+        const uint32_t b = idx / nj, j = idx % nj;
+        const i64 c = gl::centered(in[(size_t)(first + b) * (big_n + 1) + j0 + j]);
         i64 r = (c >> shift) + ((c >> (shift - 1)) & 1);
         signed char *d = digits + (size_t)b * rows + (size_t)j * levels;
         for (int lev = (int)levels - 1; lev >= 1; lev--) {
@@ -225,8 +330,10 @@ __global__ void __launch_bounds__(KS_THREADS)
 #pragma unroll
     for (int cc = 0; cc < KS_COLS; cc++) col_ok[cc] = threadIdx.x + cc * KS_THREADS <= n;
 
+    const u64 *kbase = ksk + (size_t)j0 * levels * ks_stride;
+#pragma unroll 4
     for (uint32_t r = 0; r < rows; r++) {
-        const u64 *krow = ksk + (size_t)r * ks_stride;
+        const u64 *krow = kbase + (size_t)r * ks_stride;
         u64 kv[KS_COLS];
 #pragma unroll
         for (int cc = 0; cc < KS_COLS; cc++) kv[cc] = col_ok[cc] ? krow[threadIdx.x + cc * KS_THREADS] : 0;
@@ -248,10 +355,27 @@ __global__ void __launch_bounds__(KS_THREADS)
         for (int cc = 0; cc < KS_COLS; cc++) {
             const uint32_t col = threadIdx.x + cc * KS_THREADS;
             if (col > n) continue;
-            u64 v = reduce_neg_i128(acc[b][cc]);
-            if (col == n) v = gl::add(v, in[(size_t)(first + b) * (big_n + 1) + big_n]);
-            out[(size_t)(first + b) * (n + 1) + col] = v;
+            if constexpr (SPLIT) {
+                partial[((size_t)blockIdx.y * count + first + b) * ks_stride + col] = (unsigned __int128)acc[b][cc];
+            } else {
+                u64 v = reduce_neg_i128(acc[b][cc]);
+                if (col == n) v = gl::add(v, in[(size_t)(first + b) * (big_n + 1) + big_n]);
+                out[(size_t)(first + b) * (n + 1) + col] = v;
+            }
         }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    k_keyswitch_reduce(const u64 *__restrict__ in, const unsigned __int128 *__restrict__ partial, u64 *__restrict__ out,
+                       uint32_t count, uint32_t n, uint32_t big_n, uint32_t ks_stride, uint32_t slices) {
+    const uint32_t ct = blockIdx.x;
+    for (uint32_t col = threadIdx.x; col <= n; col += blockDim.x) {
+        __int128 a = 0;
+        for (uint32_t s = 0; s < slices; s++) a += (__int128)partial[((size_t)s * count + ct) * ks_stride + col];
+        u64 v = reduce_neg_i128(a);
+        if (col == n) v = gl::add(v, in[(size_t)ct * (big_n + 1) + big_n]);
+        out[(size_t)ct * (n + 1) + col] = v;
     }
 }
 
@@ -310,12 +434,41 @@ int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const 
     return 0;
 }
 
-int launch_keyswitch(const u64 *in, const u64 *ksk, u64 *out, uint32_t count, uint32_t n, uint32_t big_n,
-                     uint32_t levels, uint32_t base_log, uint32_t ks_stride, hipStream_t s) {
+int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const u64 *bsk,
+                            const u64 *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
     if (count == 0) return 0;
-    const size_t lds = (size_t)KS_TILE * big_n * levels;
-    hipLaunchKernelGGL(k_keyswitch, dim3((count + KS_TILE - 1) / KS_TILE), dim3(KS_THREADS), lds, s, in, ksk, out, count,
-                       n, big_n, levels, base_log, ks_stride);
+    static bool attr_set = false;
+    const size_t lds = (size_t)LAT_LDS_WORDS * sizeof(u64);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate_lat),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_blind_rotate_lat, dim3(count), dim3(LAT_THREADS), lds, s, small_cts, lut_ids, luts, bsk, g_tw, out,
+                       count, n);
+    BMI_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_keyswitch(const u64 *in, const u64 *ksk, u64 *out, void *partial, uint32_t slices, uint32_t count,
+                     uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride, hipStream_t s) {
+    if (count == 0) return 0;
+    const dim3 tiles((count + KS_TILE - 1) / KS_TILE);
+    if (slices <= 1 || partial == nullptr) {
+        const size_t lds = (size_t)KS_TILE * big_n * levels;
+        hipLaunchKernelGGL(k_keyswitch<false>, tiles, dim3(KS_THREADS), lds, s, in, ksk, out,
+                           (unsigned __int128 *)nullptr, count, n, big_n, levels, base_log, ks_stride, big_n);
+        BMI_LAUNCH_CHECK();
+        return 0;
+    }
+    const uint32_t per = (big_n + slices - 1) / slices;
+    const size_t lds = (size_t)KS_TILE * per * levels;
+    hipLaunchKernelGGL(k_keyswitch<true>, dim3(tiles.x, slices), dim3(KS_THREADS), lds, s, in, ksk, out,
+                       (unsigned __int128 *)partial, count, n, big_n, levels, base_log, ks_stride, per);
+    BMI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_keyswitch_reduce, dim3(count), dim3(256), 0, s, in, (const unsigned __int128 *)partial, out, count,
+                       n, big_n, ks_stride, slices);
     BMI_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Quick A/B timing of the blind-rotation kernels on the GPU box (not the official bench)."""
+import os, sys, time, json
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "bounty-matrix-inversion_amd"))
+import numpy as np, torch
+from bmi_amd import tfhe
+from oracle import tfhe_oracle as to
+
+def main():
+    batches = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,64,4096").split(",")]
+    variants = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1").split(",")]
+    eng = tfhe.Engine(); eng.keygen(0x5EED)
+    sk_small, sk_big, bsk, ksk = eng.export_keys()
+    octx = to.Ctx(to.default_params(), bsk, ksk)
+    lid = eng.lut_register(np.random.default_rng(9).integers(-8, 8, 16), 4, 59)
+    tv = eng.lut_get(lid)[None, :]
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    for B in batches:
+        msgs = np.random.default_rng(B).integers(-8, 8, B)
+        ct = eng.encrypt(msgs, 59)
+        small = eng.keyswitch_host(ct)
+        d_small = torch.from_numpy(small.view(np.int64)).to(dev)
+        d_ids = torch.full((B,), lid, dtype=torch.int32, device=dev)
+        d_out = torch.empty((B, 1025), dtype=torch.int64, device=dev)
+        d_in = torch.from_numpy(ct.view(np.int64)).to(dev)
+        d_ks = torch.empty((B, 631), dtype=torch.int64, device=dev)
+        nchk = min(B, 4)
+        want = octx.blind_rotate(small[:nchk], tv, np.zeros(nchk, np.uint32))
+        for v in variants:
+            eng.set_kernel_variant(v)
+            eng.blind_rotate(d_small, d_ids, B, d_out, s); torch.cuda.synchronize()
+            ok = np.array_equal(d_out[:nchk].cpu().numpy().view(np.uint64), want)
+            reps = 3 if B >= 1024 else 5
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps): eng.blind_rotate(d_small, d_ids, B, d_out, s)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            e0.record()
+            for _ in range(reps): eng.keyswitch(d_in, B, d_ks, s)
+            e1.record(); torch.cuda.synchronize()
+            ks = e0.elapsed_time(e1) / reps
+            print(json.dumps({"B": B, "variant": v, "br_ms": round(ms, 3), "ks_ms": round(ks, 3), "pbs_per_s": round(B / ((ms + ks) * 1e-3), 1), "bit_exact": bool(ok)}), flush=True)
+
+main()
