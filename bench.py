@@ -42,7 +42,7 @@ def main():
                     help="ciphertexts per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inverse", action="store_true", help="also time the encrypted 2x2 inverse (config 2)")
+    ap.add_argument("--inverse", action="store_true", help="also time the encrypted 2x2 and 3x3 inverses (configs 2, 3)")
     args = ap.parse_args()
 
     import torch

@@ -1,0 +1,46 @@
+"""Wall-clock of the encrypted n x n inverse (BASELINE.json metric, second half), used by `bench.py --inverse`.
+Matrices: np.random.seed(1234 + n); M = randn(n, n) * 100.  Reports compile (trace + upload),
+encrypt, evaluate (all PBS on the GPU), decrypt, and checks the decrypted result against the circuit's own
+plaintext simulation (identical integers) and against numpy's inverse."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from .main import EncryptedMatrixInversion
+
+CONFIGS = {2: (20, 8), 3: (30, 12), 4: (40, 16)}
+
+
+def run(engine, sizes=(2, 3)):
+    out = {}
+    for n in sizes:
+        ln, ints = CONFIGS[n]
+        np.random.seed(1234 + n)
+        M = np.random.randn(n, n) * 100
+        t0 = time.time()
+        emi = EncryptedMatrixInversion(n, None, 2, ln, ints, False, False, engine=engine)
+        emi._executor()
+        t_compile = time.time() - t0
+        q, s = emi.quantize(M)
+        t0 = time.time()
+        enc = emi.encrypt(q, s)
+        t_enc = time.time() - t0
+        emi.evaluate(enc)  # warm-up (first launches, LUT uploads)
+        t0 = time.time()
+        res = emi.evaluate(enc)
+        t_eval = time.time() - t0
+        t0 = time.time()
+        dec = emi.decrypt(res)
+        t_dec = time.time() - t0
+        sim = emi.simulate(q, s)
+        summ = emi.circuit.summary()
+        out[f"{n}x{n}"] = {
+            "len": ln, "ints": ints, "evaluate_s": round(t_eval, 3), "compile_s": round(t_compile, 3),
+            "encrypt_s": round(t_enc, 3), "decrypt_s": round(t_dec, 3), "pbs": summ["pbs"], "depth": summ["depth"],
+            "ms_per_level": round(t_eval / max(summ["depth"], 1) * 1e3, 3),
+            "matches_plaintext_circuit": bool(np.array_equal(dec, sim)),
+            "max_abs_err_vs_numpy": float(np.max(np.abs(emi.dequantize(dec) - np.linalg.inv(M)))),
+        }
+    return out
