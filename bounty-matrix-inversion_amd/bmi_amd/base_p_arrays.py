@@ -218,8 +218,22 @@ def base_p_subtraction(c, a, b, p, overflow=False):
 
 
 def base_p_division(c, dividend, divisor, p):
-    """reference base_p_arrays.py:173-203: restoring long division, MSD first.  Per step and trial:
-    one borrow chain with overflow flag, then a select per remainder digit (one packed PBS each)."""
+    """reference base_p_arrays.py:173-203: restoring long division, MSD first; quotient has dividend.size digits.
+
+    For canonical binary operands (every digit in [0, 1], which is what the inverse feeds it: the operands of
+    every division are outputs of `tidy`/`invert`) the quotient digits are the binary expansion of
+    floor(dividend / divisor) (all ones when the divisor is zero), so any exact division algorithm returns the
+    same array; the radix-4 form below retires two quotient bits per step and halves the circuit depth.
+    Anything else (other bases, non-binary leading digits) runs the reference's bit-serial algorithm."""
+    if p == 2 and all(0 <= lo_of(x) and hi_of(x) <= 1 for x in list(dividend) + list(divisor)) and len(divisor) >= 2 \
+            and any(isinstance(x, Lin) for x in list(dividend) + list(divisor)):
+        return _division_radix4(c, list(dividend), list(divisor))
+    return _division_bitserial(c, dividend, divisor, p)
+
+
+def _division_bitserial(c, dividend, divisor, p):
+    """The reference's algorithm, step for step (remainder window of divisor.size + 1 digits, p - 1 trial
+    subtractions per digit); per trial: one borrow look-ahead, then one packed select per remainder digit."""
     quo = [0] * len(dividend)
     rem = [dividend[0]]
     for k in range(len(dividend)):
@@ -231,6 +245,57 @@ def base_p_division(c, dividend, divisor, p):
             ge = 1 - lt
             rem = [c.select(lt, r, d) if isinstance(lt, Lin) else (r if lt else d) for r, d in zip(rem, diff)]
             quo[k] = quo[k] + ge
+    return quo
+
+
+def _add_binary(c, a, b):
+    """a + b for equal-length canonical binary digit lists (MSD first), carry out of the top dropped"""
+    cols = [[x, y] for x, y in zip(a, b)]
+    return carry_propagate_nonneg(c, cols, 2)
+
+
+def _division_radix4(c, dividend, divisor):
+    """floor(dividend / divisor) in binary, two quotient bits per step: the partial remainder (always < divisor,
+    so it fits m digits) is extended by two dividend digits and compared with D, 2D and 3D in parallel (three
+    borrow look-aheads); sel = number of failed comparisons picks the new remainder with one 4-way mux per
+    digit.  A zero divisor makes every comparison succeed: all quotient bits are 1, as in the reference."""
+    n, m = len(dividend), len(divisor)
+    w = m + 2
+    D1 = [0, 0] + divisor
+    D2 = [0] + divisor + [0]
+    D3 = _add_binary(c, D1, D2)
+    quo = [0] * n
+    rem = [0] * m  # m digits, MSD first
+    k = 0
+    if n % 2:  # odd length: one bit-serial step first (remainder is zero, so this only tests dividend[0] >= D)
+        r1 = rem + [dividend[0]]
+        diff, lt = base_p_subtraction(c, r1, [0] + divisor, 2, True)
+        quo[0] = 1 - lt
+        sel1 = [c.select(lt, r, d) if isinstance(lt, Lin) else (r if lt else d) for r, d in zip(r1, diff)]
+        rem = sel1[1:]
+        k = 1
+    while k < n:
+        r4 = rem + [dividend[k], dividend[k + 1]]  # 4 * rem + 2 * N_k + N_{k+1}, w digits
+        d1, lt1 = base_p_subtraction(c, r4, D1, 2, True)
+        d2, lt2 = base_p_subtraction(c, r4, D2, 2, True)
+        d3, lt3 = base_p_subtraction(c, r4, D3, 2, True)
+        sel = lt1 + lt2 + lt3  # 0: >= 3D, 1: >= 2D, 2: >= D, 3: < D   (lt1 <= lt2 <= lt3)
+        if isinstance(sel, Lin):
+            sel = sel.assume(0, 3)
+            quo[k] = c.lut(sel, lambda s: int(s <= 1))
+            quo[k + 1] = c.lut(sel, lambda s: int(s % 2 == 0))
+            new = []
+            for i in range(2, w):  # the new remainder is < D: only its low m digits can be non-zero
+                cands = (d3[i], d2[i], d1[i], r4[i])
+                acc = 0
+                for kk, x in enumerate(cands):
+                    acc = acc + lut2(c, sel, x, lambda s, v, kk=kk: v if s == kk else 0)
+                new.append(acc.assume(0, 1) if isinstance(acc, Lin) else acc)
+            rem = new
+        else:
+            quo[k], quo[k + 1] = int(sel <= 1), int(sel % 2 == 0)
+            rem = list((d3, d2, d1, r4)[sel][2:])
+        k += 2
     return quo
 
 

@@ -92,9 +92,9 @@ struct bmi_ctx {
     uint32_t *d_io_ids = nullptr;
     size_t io_cap = 0;
     int variant = 0;
-    uint32_t lat_threshold = 512;
-    uint32_t ks_slices = 64, ks_split_max = 64;
+    uint32_t lat_threshold = 768;  // 3 rounds of 256 one-workgroup PBS still beat one 66 ms round of the one-wave-per-PBS kernel
     void *d_ks_partial = nullptr;
+    size_t ks_partial_bytes = 0;
     mutable std::string err;
 };
 
@@ -418,13 +418,26 @@ int bmi_keyswitch_batch(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64
     if (!c || (count && (!d_in || !d_small))) return -1;
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
     HIP_OK(c, hipSetDevice(c->device));
-    // small batches: split the 8192-row walk over KS_SLICES workgroups per tile (its length is the latency)
-    const bool split = (c->variant == 2 || (c->variant == 0 && count <= c->ks_split_max)) && count <= c->ks_split_max;
-    if (split && !c->d_ks_partial)
-        HIP_OK(c, hipMalloc(&c->d_ks_partial, (size_t)c->ks_slices * c->ks_split_max * c->ks_stride * 16));
-    int rc = bmi::launch_keyswitch(d_in, c->d_ksk, d_small, split ? c->d_ks_partial : nullptr, split ? c->ks_slices : 1,
-                                   count, c->P.n, c->big_n, c->P.ks_levels, c->P.ks_base_log, c->ks_stride,
-                                   (hipStream_t)stream);
+    // The row walk (k*N*levels rows) of one workgroup is the latency of a small batch, so it is split over
+    // `slices` workgroups per tile of 8 ciphertexts (partial 128-bit sums + a reduce kernel) until the launch
+    // has ~1024 workgroups; large batches fill the chip with one slice.
+    const uint32_t tiles = (count + 7) / 8;
+    uint32_t slices = 1;
+    if (c->variant != 1)
+        while (slices < 64 && tiles * slices * 2 <= 1024) slices *= 2;
+    const size_t need = (size_t)slices * count * c->ks_stride * 16;
+    if (slices > 1 && need > c->ks_partial_bytes) {
+        if (c->d_ks_partial) {
+            HIP_OK(c, hipDeviceSynchronize());
+            HIP_OK(c, hipFree(c->d_ks_partial));
+            c->d_ks_partial = nullptr;
+        }
+        const size_t cap = std::max(need, (size_t)96 << 20);
+        HIP_OK(c, hipMalloc(&c->d_ks_partial, cap));
+        c->ks_partial_bytes = cap;
+    }
+    int rc = bmi::launch_keyswitch(d_in, c->d_ksk, d_small, slices > 1 ? c->d_ks_partial : nullptr, slices, count, c->P.n,
+                                   c->big_n, c->P.ks_levels, c->P.ks_base_log, c->ks_stride, (hipStream_t)stream);
     return rc ? fail(c, -2, std::string("keyswitch launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
 }
 
@@ -467,8 +480,10 @@ int bmi_reserve(bmi_ctx *c, uint32_t max_count) {
     if (!c) return -1;
     HIP_OK(c, hipSetDevice(c->device));
     HIP_OK(c, hipDeviceSynchronize());
-    if (!c->d_ks_partial)
-        HIP_OK(c, hipMalloc(&c->d_ks_partial, (size_t)c->ks_slices * c->ks_split_max * c->ks_stride * 16));
+    if (!c->d_ks_partial) {
+        c->ks_partial_bytes = (size_t)96 << 20;  // covers every split configuration (<= 1024 workgroups x 8 ciphertexts)
+        HIP_OK(c, hipMalloc(&c->d_ks_partial, c->ks_partial_bytes));
+    }
     return ensure_small(c, max_count);
 }
 
