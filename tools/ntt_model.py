@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Index/twiddle model of the wave-level 1024-point negacyclic NTT used by the HIP kernels
 (csrc/ntt_wave.hpp): 16 registers x 64 lanes, passes 16 (regs) -> 16 (regs, after an LDS
-transpose) -> 4 (quad lanes).  Pure-Python exact arithmetic; validates the decomposition
+transpose) -> 4 (regs, after a second transpose inside each group of 4 lanes).  Pure-Python exact arithmetic; validates the decomposition
 against the definition A[k] = sum_n a[n] psi^(n(2k+1)) and prints the root to hard-code."""
 import random
 
@@ -28,10 +28,6 @@ def dft(xs, root):
     return [sum(xs[j] * pow(root, j * k, Q) for j in range(n)) % Q for k in range(n)]
 
 
-def br2(t):
-    return ((t & 1) << 1) | (t >> 1)
-
-
 def fwd(a):
     """returns out[thread][reg] with the frequency index each slot holds"""
     # P1: lane l, reg j holds a[l + 64 j]; twist by rho^j = 2^(6j); 16-pt DFT root 2^12 -> reg k1
@@ -49,17 +45,19 @@ def fwd(a):
             x = [Z[t + 4 * u][k1] for u in range(16)]
             X = dft(x, pow(2, 12, Q))
             V[4 * k1 + t] = [X[v] * pow(8, t * v, Q) % Q for v in range(16)]
-    # P3: 4-pt DFT across the quad (root 2^48); lane t of the quad ends with s = br2(t)
+    # T2 + P3: inside each group of 4 lanes (same k1) transpose so that lane (k1, g) holds register 4*vl + tt =
+    # V[k1][tt][v = 4*vl + g]; then four 4-point DFTs over tt in registers (root 2^48): register 4*vl + s
     out = [[0] * 16 for _ in range(64)]
     freq = [[0] * 16 for _ in range(64)]
     for k1 in range(16):
-        for v in range(16):
-            x = [V[4 * k1 + t][v] for t in range(4)]
-            X = dft(x, pow(2, 48, Q))
-            for t in range(4):
-                s = br2(t)
-                out[4 * k1 + t][v] = X[s]
-                freq[4 * k1 + t][v] = k1 + 16 * v + 256 * s
+        for g in range(4):
+            for vl in range(4):
+                v = 4 * vl + g
+                x = [V[4 * k1 + tt][v] for tt in range(4)]
+                X = dft(x, pow(2, 48, Q))
+                for s in range(4):
+                    out[4 * k1 + g][4 * vl + s] = X[s]
+                    freq[4 * k1 + g][4 * vl + s] = k1 + 16 * v + 256 * s
     return out, freq
 
 
