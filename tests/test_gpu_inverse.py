@@ -88,3 +88,23 @@ def test_encrypted_3x3_inverse_matches_reference_golden(eng):
     assert out.tolist() == c["out"]
     print(f"encrypted 3x3 (len 30, ints 12): {wall:.1f} s, {emi.circuit.summary()}")
     assert wall < 60.0
+
+
+def test_encrypted_4x4_inverse_matches_reference_golden(eng):
+    """BASELINE config 4 (4x4, len 40, ints 16) on ONE MI355X: 323 k PBS, depth 1,858.  (BASELINE shards this
+    config's PBS over 8 GPUs; the inverse's levels are narrower than one GPU's latency-kernel capacity, so a
+    single GPU is the faster placement - DESIGN.md §6.)"""
+    import time
+    from bmi_amd.main import EncryptedMatrixInversion
+    c = next(x for x in load("inverse.json") if x["tag"] == "baseline_n4_len40_ints16")
+    emi = EncryptedMatrixInversion(4, None, 2, 40, 16, False, False, engine=eng)
+    M = np.array(c["M"]).reshape(4, 4)
+    q, s = emi.quantize(M)
+    enc = emi.encrypt(q, s)
+    emi._executor()
+    t0 = time.time()
+    res = emi.evaluate(enc)
+    wall = time.time() - t0
+    out = emi.decrypt(res)
+    assert out.tolist() == c["out"]
+    print(f"encrypted 4x4 (len 40, ints 16): {wall:.1f} s, {emi.circuit.summary()}")

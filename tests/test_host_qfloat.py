@@ -228,8 +228,6 @@ CASES = [c for c in load("inverse.json") if c["n"] <= 4 and c["base"] == 2]
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["tag"])
 def test_traced_inverse_matches_reference_golden(case):
     c = case
-    if c["n"] == 4 and os.environ.get("BMI_SLOW_TESTS", "0") != "1":
-        pytest.skip("4x4 trace takes ~1 min; set BMI_SLOW_TESTS=1")
     emi = EncryptedMatrixInversion(c["n"], None, c["base"], c["len"], c["ints"], c["true_division"], c["tensorize"])
     M = np.array(c["M"]).reshape(c["n"], c["n"])
     q, s = emi.quantize(M)
