@@ -166,6 +166,40 @@ def _prefix_borrows(c, sig, first_bit):
     return bits
 
 
+def _window3_borrows(c, deltas):
+    """Borrow look-ahead for digit differences in {-1, 0, 1} (binary operands): the first level reads windows
+    of THREE adjacent positions in one look-up each - sign(4 d_i + 2 d_{i-1} + d_{i-2}) is the combined signal
+    of positions i-2..i and the argument spans 15 values - then Kogge-Stone doubling with distances 3, 6, 12...
+    One level fewer than signals-then-prefix.  Returns bits[i] = borrow out of position i."""
+    m = len(deltas)
+    S = [None] * m
+    bits = [None] * m
+    for i in range(m):
+        w = deltas[i] * 4
+        if i >= 1:
+            w = w + deltas[i - 1] * 2
+        if i >= 2:
+            w = w + deltas[i - 2]
+        if i <= 2:
+            bits[i] = lut(c, w, lambda v: int(v < 0))   # the window reaches position 0: final
+        if i + 3 < m or i > 2:
+            S[i] = lut(c, w, _sign3)
+    d = 3
+    while d < m:
+        newS = list(S)
+        for i in range(d, m):
+            if bits[i] is not None and not (i + 2 * d < m):
+                continue
+            hi, lo = S[i], S[i - d]
+            if i < 2 * d and bits[i] is None:  # window now reaches position 0
+                bits[i] = lut2(c, hi, lo, lambda h, l: int(_comb(h, l) == -1))
+            if i >= 2 * d or i + 2 * d < m:
+                newS[i] = lut2(c, hi, lo, _comb)
+        S = newS
+        d *= 2
+    return bits
+
+
 def base_p_subtraction(c, a, b, p, overflow=False):
     """reference base_p_arrays.py:108-139: a - b with borrows, right-aligned, and (overflow=True) the flag a < b
     as defined there for unequal sizes.  Same integers as the reference's sequential borrow chain, computed
@@ -192,7 +226,6 @@ def base_p_subtraction(c, a, b, p, overflow=False):
             out[:-extra] = a[:-extra]
             return out, borrow & int(sum(int(x) for x in a[:-extra]) == 0)
         return out, borrow | int(sum(int(x) for x in b[:extra]) > 0)
-    sig = [lut(c, d, _sign3) for d in deltas]
     pseudo = None
     if overflow and extra < 0:
         # a < b  <=>  borrow out and the extra leading digits of a sum to zero: a 'propagate / kill' position on top
@@ -200,9 +233,13 @@ def base_p_subtraction(c, a, b, p, overflow=False):
         out[:-extra] = a[:-extra]
     elif overflow and extra > 0:
         pseudo = -1 * sum_is_positive(c, b[:extra])     # 0 = propagate, -1 = generate
-    if pseudo is not None:
-        sig = sig + [pseudo]
-    bits = _prefix_borrows(c, sig, lut(c, deltas[0], lambda v: int(v < 0)))
+    if pseudo is None and all(-1 <= lo_of(d) and hi_of(d) <= 1 for d in deltas):
+        bits = _window3_borrows(c, deltas)
+    else:
+        sig = [lut(c, d, _sign3) for d in deltas]
+        if pseudo is not None:
+            sig = sig + [pseudo]
+        bits = _prefix_borrows(c, sig, lut(c, deltas[0], lambda v: int(v < 0)))
     for k in range(m):
         bin_k = bits[k - 1] if k > 0 else 0
         t = deltas[k] - bin_k
@@ -407,8 +444,13 @@ def carry_propagate_nonneg(c, columns, p):
         sums.append(s)
     # carry look-ahead over positions L-1 (least significant) .. 0
     lsb_first = sums[::-1]
-    sig = [lut(c, s, lambda v: -1 if v >= p else (0 if v == p - 1 else 1)) for s in lsb_first]
-    bits = _prefix_borrows(c, sig, lut(c, lsb_first[0], lambda v: int(v >= p)))
+    if p == 2 and all(0 <= lo_of(x) and hi_of(x) <= 2 for x in lsb_first):
+        # carry out of a window <=> the most significant non-'propagate' column generates: with e = 1 - col in
+        # {-1: generate, 0: propagate, 1: kill} this is exactly the borrow look-ahead on e (windows of three)
+        bits = _window3_borrows(c, [1 - x for x in lsb_first])
+    else:
+        sig = [lut(c, x, lambda v: -1 if v >= p else (0 if v == p - 1 else 1)) for x in lsb_first]
+        bits = _prefix_borrows(c, sig, lut(c, lsb_first[0], lambda v: int(v >= p)))
     out = [0] * L
     for k in range(L):
         cin = bits[k - 1] if k > 0 else 0
@@ -419,20 +461,80 @@ def carry_propagate_nonneg(c, columns, p):
     return out
 
 
+def _signed_chain(c, digits_lsb_first, p, carry_in):
+    """sequential truncating carry chain over a block (least significant first); returns (carries, carry_out)
+    where carries[i] is the carry OUT of position i"""
+    carries = []
+    carry = carry_in
+    for d in digits_lsb_first:
+        s = d + carry
+        carry = lut(c, s, lambda v: (abs(v) // p) * ((v > 0) - (v < 0)))
+        carries.append(carry)
+    return carries
+
+
+def _mux3(c, sel, cands):
+    """cands[sel + 1] for an encrypted sel in {-1, 0, 1}: three packed bivariate look-ups, one level"""
+    if not isinstance(sel, Lin):
+        return cands[int(sel) + 1]
+    acc = 0
+    for k, x in zip((-1, 0, 1), cands):
+        acc = acc + lut2(c, sel, x, lambda s_, v, k=k: v if s_ == k else 0)
+    lo = min(lo_of(x) for x in cands)
+    hi = max(hi_of(x) for x in cands)
+    return acc.assume(lo, hi) if isinstance(acc, Lin) else acc
+
+
+SIGNED_BLOCK = 6
+
+
 def carry_propagate_signed(c, digits, p):
-    """reference QFloat.base_tidy (qfloat.py:607-626) on mixed-sign digits: carry = trunc(c / p) toward
-    zero, digit = c - carry * p; one fused look-up per digit (abs, //, sign and the product are all
-    functions of the same c).  Used where the inputs are narrow (sums of two digit arrays)."""
-    out = list(digits)
-    carry = 0
-    for i in range(len(out) - 1, -1, -1):
-        s = out[i] + carry
-        if isinstance(s, Lin):
-            carry = lut(c, s, lambda v: (abs(v) // p) * ((v > 0) - (v < 0)))
-            d = s - p * carry
-            vals = [v - p * ((abs(v) // p) * ((v > 0) - (v < 0))) for v in range(s.lo, s.hi + 1)]
-            out[i] = d.assume(min(vals), max(vals)) if isinstance(d, Lin) else d
-        else:
+    """reference QFloat.base_tidy (qfloat.py:607-626) on mixed-sign digits: carry = trunc(c / p) toward zero,
+    digit = c - carry * p (abs, //, sign and the product are all functions of the same c: one fused look-up).
+    Same integers as the reference's right-to-left loop, evaluated as a carry-SELECT adder: the digits are cut
+    into blocks; every block runs its short chain for each possible incoming carry (-1, 0, +1) in parallel, then
+    the true carries ripple block to block through 3-way muxes.  Depth ~ block + #blocks instead of L.  Falls
+    back to the plain chain when a digit is too wide for the carry to stay in {-1, 0, 1}."""
+    L = len(digits)
+    if c is None or all(not isinstance(d, Lin) for d in digits):
+        out = list(digits)
+        carry = 0
+        for i in range(L - 1, -1, -1):
+            s = out[i] + carry
             carry = (abs(s) // p) * ((s > 0) - (s < 0))
             out[i] = s - p * carry
+        return out
+    lsb = list(digits[::-1])  # position 0 = least significant
+    narrow = all(-(2 * p - 2) <= lo_of(d) and hi_of(d) <= 2 * p - 2 for d in lsb[:-1])
+    carries = [None] * L
+    if not narrow or L <= SIGNED_BLOCK + 2:
+        carries = _signed_chain(c, lsb, p, 0)
+    else:
+        # positions 0 .. L-2 by carry-select; the leading digit (possibly wider: non-binary leading digits of the
+        # inputs) is finished with one ordinary step - its carry out is dropped anyway
+        body = L - 1
+        blocks = [list(range(a, min(a + SIGNED_BLOCK, body))) for a in range(0, body, SIGNED_BLOCK)]
+        cin = 0
+        for bi, blk in enumerate(blocks):
+            seg = [lsb[i] for i in blk]
+            if bi == 0:
+                cs = _signed_chain(c, seg, p, 0)
+                for i, v in zip(blk, cs):
+                    carries[i] = v
+            else:
+                cand = [_signed_chain(c, seg, p, k) for k in (-1, 0, 1)]  # independent of cin: scheduled early
+                for j, i in enumerate(blk):
+                    carries[i] = _mux3(c, cin, [cand[0][j], cand[1][j], cand[2][j]])
+            cin = carries[blk[-1]]
+        carries[L - 1] = _signed_chain(c, [lsb[L - 1]], p, cin)[0]
+    out = [0] * L
+    for i in range(L):
+        cin_i = carries[i - 1] if i > 0 else 0
+        s = lsb[i] + cin_i
+        d = s - p * carries[i]
+        if isinstance(d, Lin):
+            slo, shi = lo_of(s), hi_of(s)
+            vals = [v - p * ((abs(v) // p) * ((v > 0) - (v < 0))) for v in range(slo, shi + 1)]
+            d = d.assume(min(vals), max(vals))
+        out[L - 1 - i] = d
     return out
