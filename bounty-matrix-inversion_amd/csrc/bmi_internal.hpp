@@ -5,8 +5,8 @@
 
 #include "goldilocks.hpp"
 
-#ifndef BMI_TP_WAVES
-#define BMI_TP_WAVES 4  // ciphertexts (= wavefronts) per workgroup in the throughput blind rotation
+#ifndef BMI_TP_CTS
+#define BMI_TP_CTS 2  // ciphertexts (= wavefront pairs) per workgroup in the throughput blind rotation
 #endif
 
 namespace bmi {

@@ -1,8 +1,9 @@
 // HIP kernels (gfx950 / CDNA4) of the TFHE programmable-bootstrap engine.
 //
 //   k_bsk_to_ntt        standard-domain GGSW rows -> NTT (evaluation) domain, lane-layout, once per keygen
-//   k_blind_rotate_tp   THROUGHPUT variant: one wavefront = one ciphertext; mod-switch, n CMUXes
+//   k_blind_rotate_tp   THROUGHPUT variant: one pair of wavefronts = one ciphertext; mod-switch, n CMUXes
 //                       (decompose -> 6 forward NTTs -> 12 pointwise MACs -> 2 inverse NTTs), sample extraction
+//   k_blind_rotate_lat  LATENCY variant: one workgroup of 8 wavefronts = one ciphertext
 //   k_keyswitch         big-key LWE -> small-key LWE (signed base-2^4 decomposition, 128-bit accumulators)
 //   k_lincomb           leveled linear combinations of ciphertexts (CSR)
 //   k_negacyclic_mul    test hook: c = a * b mod (X^N + 1, q) through the wave NTT
@@ -84,96 +85,116 @@ __device__ __forceinline__ void decompose3x15(u64 a, int (&d)[3]) {
     d[2] = d2;
 }
 
-// THROUGHPUT blind rotation: one wavefront per ciphertext, WAVES ciphertexts per workgroup.
-// Accumulator (2 polynomials) lives in registers; LDS holds the twiddles (shared by the workgroup),
-// one transpose/rotation tile per wave and the mod-switched mask of the wave's ciphertext.
-template <int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, 2)
+// THROUGHPUT blind rotation: one PAIR of wavefronts per ciphertext, CTS ciphertexts per workgroup.
+// Wave c of the pair owns GLWE component c: its accumulator polynomial ACC_c (registers), the three digit
+// polynomials decomposed from it, and output polynomial c of the external product.  Per CMUX and level the
+// wave transforms its digit polynomial, publishes the result in its LDS tile, and both waves multiply-
+// accumulate their own and the partner's transform with the bootstrap-key rows of their output polynomial;
+// then each wave inverse-transforms its own sum.  ~128 live registers per lane (no spills at 2 waves/SIMD,
+// which saturates the integer VALU on gfx950); two workgroup barriers per level order the tile hand-off.
+// (A first version kept a whole ciphertext - both accumulators, both sums - in one wave: 251 registers, and
+// it spilled once the arithmetic moved to 32-bit limbs.)
+template <int CTS>
+__global__ void __launch_bounds__(128 * CTS, 2)
     k_blind_rotate_tp(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
                       const u64 *__restrict__ luts, const u64 *__restrict__ bsk, const u64 *__restrict__ g_tw,
                       u64 *__restrict__ out, uint32_t count, uint32_t n) {
-    constexpr int AT_WORDS = 160;  // 640 x uint16
-    __shared__ u64 lds[TW_WORDS + WAVES * (SCRATCH_WORDS + AT_WORDS)];
+    constexpr int AT_WORDS = 160;  // 640 x uint16 per ciphertext
+    __shared__ u64 lds[TW_WORDS + 2 * CTS * SCRATCH_WORDS + CTS * AT_WORDS];
     stage_twiddles(lds, g_tw);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t ct = blockIdx.x * WAVES + wave;
-    if (ct >= count) return;  // whole wave leaves; no workgroup barrier follows
-    u64 *scratch = lds + TW_WORDS + wave * (SCRATCH_WORDS + AT_WORDS);
-    uint16_t *at = reinterpret_cast<uint16_t *>(scratch + SCRATCH_WORDS);
+    const int ctl = wave >> 1, c = wave & 1;
+    // the last workgroup may hold a ciphertext slot beyond the batch: it computes on slot count-1 again
+    // (all waves must reach every barrier) and simply does not write a result
+    const uint32_t ct_raw = blockIdx.x * CTS + ctl;
+    const bool live = ct_raw < count;
+    const uint32_t ct = live ? ct_raw : count - 1;
+    u64 *tile = lds + TW_WORDS + wave * SCRATCH_WORDS;
+    const u64 *ptile = lds + TW_WORDS + (wave ^ 1) * SCRATCH_WORDS;
+    uint16_t *at = reinterpret_cast<uint16_t *>(lds + TW_WORDS + 2 * CTS * SCRATCH_WORDS + ctl * AT_WORDS);
     const u64 *lwe = small_cts + (size_t)ct * (n + 1);
 
-    // modulus switch of the whole small ciphertext (mask + body) to Z_{2N}
-    for (uint32_t i = lane; i <= n; i += 64) at[i] = (uint16_t)gl::modswitch(lwe[i], LOG_N + 1);
-    wave_sync();
+    // modulus switch of the small ciphertext (mask + body) to Z_{2N}; both waves of the pair share the array
+    for (uint32_t i = lane + 64 * c; i <= n; i += 128) at[i] = (uint16_t)gl::modswitch(lwe[i], LOG_N + 1);
+    __syncthreads();
 
-    // ACC = X^(-b~) * (0, tv)
-    u64 acc[2][16];
+    // ACC = X^(-b~) * (0, tv): component 0 starts at zero, component 1 at the rotated test polynomial
+    u64 acc[16];
     {
         const u64 *tv = luts + (size_t)lut_ids[ct] * N;
         const uint32_t bt = at[n];
         static_for<0, 16>([&](auto J) {
             const uint32_t e = (lane + 64 * J + bt) & (2 * N - 1);
             const u64 v = tv[e & (N - 1)];
-            acc[0][J] = 0;
-            acc[1][J] = (e & N) ? gl::neg(v) : v;
+            acc[J] = c ? ((e & N) ? gl::neg(v) : v) : 0;
         });
     }
 
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t a_t = at[i];
-        if (a_t == 0) continue;  // wave-uniform: X^0 * ACC - ACC = 0 adds exactly zero
-        u64 accn[2][16];
-        static_for<0, 16>([&](auto V) { accn[0][V] = 0; accn[1][V] = 0; });
+        const uint32_t a_t = at[i];  // a_t == 0 adds exactly zero; not skipped so that barriers stay uniform
         const u64 *bsk_i = bsk + (size_t)i * 12 * N;
-        static_for<0, 2>([&](auto C) {
-            constexpr int c = C;
-            // diff = X^(a~) * ACC_c - ACC_c, through the wave's LDS tile (natural order)
-            wave_sync();
-            static_for<0, 16>([&](auto J) { scratch[lane + 64 * J] = acc[c][J]; });
-            wave_sync();
-            int dig[3][16];
+        // diff = X^(a~) * ACC_c - ACC_c through the wave's own tile (natural order), then its three digits,
+        // packed: dlo = d2 | d1 << 16 (16-bit signed fields), dhi = d0
+        wave_sync();
+        static_for<0, 16>([&](auto J) { tile[lane + 64 * J] = acc[J]; });
+        wave_sync();
+        int dlo[16], dhi[16];
+        static_for<0, 16>([&](auto J) {
+            const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
+            u64 v = tile[e & (N - 1)];
+            v = (e & N) ? gl::neg(v) : v;
+            int d[3];
+            decompose3x15(gl::sub(v, acc[J]), d);
+            dlo[J] = (d[2] & 0xFFFF) | (d[1] << 16);
+            dhi[J] = d[0];
+        });
+        u64 accn[16];
+        static_for<0, 3>([&](auto LEV) {
+            constexpr int lev = LEV;
+            u64 x[16];
             static_for<0, 16>([&](auto J) {
-                const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
-                u64 v = scratch[e & (N - 1)];
-                v = (e & N) ? gl::neg(v) : v;
-                int d[3];
-                decompose3x15(gl::sub(v, acc[c][J]), d);
-                dig[0][J] = d[0]; dig[1][J] = d[1]; dig[2][J] = d[2];
+                const int dg = lev == 0 ? dhi[J] : (lev == 1 ? (dlo[J] >> 16) : (int)(short)dlo[J]);
+                x[J] = gl::from_i64((i64)dg);
             });
-            static_for<0, 3>([&](auto LEV) {
-                constexpr int lev = LEV;
-                u64 x[16];
-                static_for<0, 16>([&](auto J) { x[J] = gl::from_i64((i64)dig[lev][J]); });
-                forward(x, lane, lds, scratch);
-                const u64 *row = bsk_i + (size_t)(c * 3 + lev) * 2 * N;
-                static_for<0, 8>([&](auto VP) {
-                    const ulonglong2 b0 = reinterpret_cast<const ulonglong2 *>(row)[VP * 64 + lane];
-                    const ulonglong2 b1 = reinterpret_cast<const ulonglong2 *>(row + N)[VP * 64 + lane];
-                    accn[0][2 * VP] = gl::add(accn[0][2 * VP], gl::mul(x[2 * VP], b0.x));
-                    accn[0][2 * VP + 1] = gl::add(accn[0][2 * VP + 1], gl::mul(x[2 * VP + 1], b0.y));
-                    accn[1][2 * VP] = gl::add(accn[1][2 * VP], gl::mul(x[2 * VP], b1.x));
-                    accn[1][2 * VP + 1] = gl::add(accn[1][2 * VP + 1], gl::mul(x[2 * VP + 1], b1.y));
-                });
+            forward(x, lane, lds, tile);
+            wave_sync();
+            static_for<0, 16>([&](auto V) { tile[eval_offset(lane, V)] = x[V]; });
+            __syncthreads();  // both transforms of this level are published
+            // rows (component, level) x output polynomial c: own row from registers, partner's from its tile
+            const u64 *row_own = bsk_i + ((size_t)(c * 3 + lev) * 2 + c) * N;
+            const u64 *row_par = bsk_i + ((size_t)((c ^ 1) * 3 + lev) * 2 + c) * N;
+            static_for<0, 8>([&](auto VP) {
+                const ulonglong2 bo = reinterpret_cast<const ulonglong2 *>(row_own)[VP * 64 + lane];
+                const ulonglong2 bp = reinterpret_cast<const ulonglong2 *>(row_par)[VP * 64 + lane];
+                const ulonglong2 xp = reinterpret_cast<const ulonglong2 *>(ptile)[VP * 64 + lane];
+                u64 s0 = gl::add(gl::mul(x[2 * VP], bo.x), gl::mul(xp.x, bp.x));
+                u64 s1 = gl::add(gl::mul(x[2 * VP + 1], bo.y), gl::mul(xp.y, bp.y));
+                if constexpr (lev == 0) {
+                    accn[2 * VP] = s0;
+                    accn[2 * VP + 1] = s1;
+                } else {
+                    accn[2 * VP] = gl::add(accn[2 * VP], s0);
+                    accn[2 * VP + 1] = gl::add(accn[2 * VP + 1], s1);
+                }
             });
+            __syncthreads();  // the partner has read this tile: it may be overwritten
         });
-        static_for<0, 2>([&](auto OC) {
-            constexpr int oc = OC;
-            inverse(accn[oc], lane, lds, scratch);
-            static_for<0, 16>([&](auto J) { acc[oc][J] = gl::add(acc[oc][J], accn[oc][J]); });
-        });
+        inverse(accn, lane, lds, tile);
+        static_for<0, 16>([&](auto J) { acc[J] = gl::add(acc[J], accn[J]); });
     }
 
-    // sample extraction of coefficient 0: a_out[0] = A[0], a_out[t] = -A[N - t], b_out = B[0]
+    // sample extraction of coefficient 0: a_out[0] = A[0], a_out[t] = -A[N - t] (wave 0), b_out = B[0] (wave 1)
+    if (!live) return;
     u64 *o = out + (size_t)ct * (N + 1);
-    static_for<0, 16>([&](auto J) {
-        const uint32_t m = lane + 64 * J;
-        if (m == 0) {
-            o[0] = acc[0][J];
-            o[N] = acc[1][J];
-        } else {
-            o[N - m] = gl::neg(acc[0][J]);
-        }
-    });
+    if (c == 0) {
+        static_for<0, 16>([&](auto J) {
+            const uint32_t m = lane + 64 * J;
+            if (m == 0) o[0] = acc[J];
+            else o[N - m] = gl::neg(acc[J]);
+        });
+    } else if (lane == 0) {
+        o[N] = acc[0];
+    }
 }
 
 // LATENCY blind rotation: one workgroup of 8 wavefronts per ciphertext.  Per CMUX:
@@ -427,8 +448,8 @@ int launch_negacyclic_mul(const u64 *a, const u64 *b, u64 *c, const u64 *g_tw, u
 int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const u64 *bsk,
                            const u64 *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
     if (count == 0) return 0;
-    constexpr int WAVES = BMI_TP_WAVES;
-    hipLaunchKernelGGL((k_blind_rotate_tp<WAVES>), dim3((count + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, s, small_cts,
+    constexpr int CTS = BMI_TP_CTS;
+    hipLaunchKernelGGL((k_blind_rotate_tp<CTS>), dim3((count + CTS - 1) / CTS), dim3(128 * CTS), 0, s, small_cts,
                        lut_ids, luts, bsk, g_tw, out, count, n);
     BMI_LAUNCH_CHECK();
     return 0;

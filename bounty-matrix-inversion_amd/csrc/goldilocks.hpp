@@ -20,17 +20,73 @@ typedef int64_t i64;
 constexpr u64 P = 0xFFFFFFFF00000001ULL;
 constexpr u64 EPS = 0xFFFFFFFFULL;  // 2^64 mod P
 
+// ---- 32-bit limb helpers.  Measured on gfx950 (tools/microbench/valu_cost.hip, wall clock, chip-wide):
+// plain 32-bit ALU ops issue at ~1 per 2 cycles per SIMD, but EVERYTHING this arithmetic is made of is half
+// rate (~1 per 4 cycles): 64-bit forms (v_lshl_add_u64, v_lshlrev_b64, v_cmp_*_u64), v_mad_u64_u32 / v_mul_*,
+// carry-producing or -consuming adds (v_add_co_u32, v_addc_co_u32, v_subb_co_u32), v_cndmask and DPP moves;
+// two waves per SIMD saturate the pipe.  A modular add therefore costs about the same written with 64-bit
+// compares or with hardware carries (both were built and timed); the carry form below needs no compares and
+// composes better with the reductions, so it is the one kept.
+GL_HD uint32_t lo32(u64 x) { return (uint32_t)x; }
+GL_HD uint32_t hi32(u64 x) { return (uint32_t)(x >> 32); }
+GL_HD u64 mk64(uint32_t lo, uint32_t hi) { return ((u64)hi << 32) | (u64)lo; }
+
+#if defined(__clang__)
+GL_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t cin, uint32_t &cout) { return __builtin_addc(a, b, cin, &cout); }
+GL_HD uint32_t subc32(uint32_t a, uint32_t b, uint32_t bin, uint32_t &bout) { return __builtin_subc(a, b, bin, &bout); }
+#else
+GL_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t cin, uint32_t &cout) {
+    u64 t = (u64)a + b + cin;
+    cout = (uint32_t)(t >> 32);
+    return (uint32_t)t;
+}
+GL_HD uint32_t subc32(uint32_t a, uint32_t b, uint32_t bin, uint32_t &bout) {
+    u64 t = (u64)a - b - bin;
+    bout = (uint32_t)(t >> 63);
+    return (uint32_t)t;
+}
+#endif
+
+// x + (flag ? EPS : 0) on halves, returning the carry out
+GL_HD u64 add_eps_if(u64 x, uint32_t flag, uint32_t &cout) {
+    uint32_t c;
+    const uint32_t m = flag ? 0xFFFFFFFFu : 0u;
+    const uint32_t l = addc32(lo32(x), m, 0u, c);
+    const uint32_t h = addc32(hi32(x), 0u, c, cout);
+    return mk64(l, h);
+}
+// x - (flag ? EPS : 0) on halves
+GL_HD u64 sub_eps_if(u64 x, uint32_t flag) {
+    uint32_t b, b2;
+    const uint32_t m = flag ? 0xFFFFFFFFu : 0u;
+    const uint32_t l = subc32(lo32(x), m, 0u, b);
+    const uint32_t h = subc32(hi32(x), 0u, b, b2);
+    return mk64(l, h);
+}
+// canonical representative of a value in [0, 2^64): x >= P  <=>  x + EPS carries
+GL_HD u64 canon(u64 x) {
+    uint32_t c1, c2;
+    const uint32_t l = addc32(lo32(x), 0xFFFFFFFFu, 0u, c1);
+    const uint32_t h = addc32(hi32(x), 0u, c1, c2);
+    return c2 ? mk64(l, h) : x;
+}
+
 GL_HD u64 add(u64 a, u64 b) {
-    u64 s = a + b;
-    if (s < a || s >= P) s += EPS;  // s - P (mod 2^64)
-    return s;
+    uint32_t c1, c2, c3, c4;
+    const uint32_t s0 = addc32(lo32(a), lo32(b), 0u, c1);
+    const uint32_t s1 = addc32(hi32(a), hi32(b), c1, c2);
+    const uint32_t t0 = addc32(s0, 0xFFFFFFFFu, 0u, c3);  // s + EPS = s - P (mod 2^64); carries iff s >= P
+    const uint32_t t1 = addc32(s1, 0u, c3, c4);
+    const bool sel = (c2 | c4) != 0;
+    return mk64(sel ? t0 : s0, sel ? t1 : s1);
 }
 GL_HD u64 sub(u64 a, u64 b) {
-    u64 d = a - b;
-    if (a < b) d -= EPS;  // d + P (mod 2^64)
-    return d;
+    uint32_t b1, b2;
+    const uint32_t d0 = subc32(lo32(a), lo32(b), 0u, b1);
+    const uint32_t d1 = subc32(hi32(a), hi32(b), b1, b2);
+    return sub_eps_if(mk64(d0, d1), b2);  // borrow: + P = - EPS (mod 2^64)
 }
-GL_HD u64 neg(u64 a) { return a ? P - a : 0; }
+GL_HD u64 neg(u64 a) { return sub(0, a); }
 
 GL_HD u64 mulhi64(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -40,31 +96,42 @@ GL_HD u64 mulhi64(u64 a, u64 b) {
 #endif
 }
 
-// x * EPS for a 32-bit x, without a multiplier: (x << 32) - x
-// x * EPS for a 32-bit x.  Measured on gfx950: the 64x32 multiply-add (v_mad_u64_u32) is cheaper here than the
-// shift/subtract form with its extra carry-dependent instructions.
+// x * EPS for a 32-bit x (the 64x32 multiply-add is as cheap as the shift/subtract form on gfx950)
 GL_HD u64 times_eps32(u64 x32) { return x32 * EPS; }
 
-// (hi * 2^64 + lo) mod P, any hi/lo
+// (hi * 2^64 + lo) mod P, any hi/lo:  2^64 = EPS, 2^96 = -1
 GL_HD u64 reduce128(u64 hi, u64 lo) {
-    u64 hh = hi >> 32, hl = hi & EPS;
-    u64 t0 = lo - hh;
-    if (lo < hh) t0 -= EPS;  // 2^96 = -1: subtract hh, fix the borrow with +P
-    u64 t1 = times_eps32(hl);  // 2^64 = EPS
-    u64 r = t0 + t1;
-    if (r < t1) r += EPS;
-    if (r >= P) r -= P;
-    return r;
+    uint32_t b1, b2, c;
+    // t0 = lo - hi_hi  (+P on borrow)
+    const uint32_t l0 = subc32(lo32(lo), hi32(hi), 0u, b1);
+    const uint32_t l1 = subc32(hi32(lo), 0u, b1, b2);
+    const u64 t0 = sub_eps_if(mk64(l0, l1), b2);
+    // + hi_lo * EPS  (+EPS on carry)
+    const u64 t1 = times_eps32(lo32(hi));
+    uint32_t c1, c2;
+    const uint32_t r0 = addc32(lo32(t0), lo32(t1), 0u, c1);
+    const uint32_t r1 = addc32(hi32(t0), hi32(t1), c1, c2);
+    const u64 r = add_eps_if(mk64(r0, r1), c2, c);
+    return canon(r);
 }
 // (hi32 * 2^64 + lo) mod P for hi32 < 2^32 (one fold, no borrow step)
-GL_HD u64 reduce96(u64 hi32, u64 lo) {
-    u64 t1 = times_eps32(hi32);
-    u64 r = lo + t1;
-    if (r < t1) r += EPS;
-    if (r >= P) r -= P;
-    return r;
+GL_HD u64 reduce96(u64 hi32v, u64 lo) {
+    const u64 t1 = times_eps32(hi32v);
+    uint32_t c1, c2, c;
+    const uint32_t r0 = addc32(lo32(lo), lo32(t1), 0u, c1);
+    const uint32_t r1 = addc32(hi32(lo), hi32(t1), c1, c2);
+    const u64 r = add_eps_if(mk64(r0, r1), c2, c);
+    return canon(r);
 }
-GL_HD u64 mul(u64 a, u64 b) { return reduce128(mulhi64(a, b), a * b); }
+// 64 x 64 -> 128 schoolbook on 32-bit halves: four 32x32+64 multiply-adds (v_mad_u64_u32), then the fold
+GL_HD u64 mul(u64 a, u64 b) {
+    const uint32_t a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+    const u64 p00 = (u64)a0 * b0;
+    const u64 m1 = (u64)a0 * b1 + hi32(p00);   // < 2^64: (2^32-1)^2 + 2^32 - 1
+    const u64 m2 = (u64)a1 * b0 + lo32(m1);
+    const u64 hi = (u64)a1 * b1 + hi32(m1) + hi32(m2);
+    return reduce128(hi, mk64(lo32(p00), lo32(m2)));
+}
 
 // x * 2^S mod P for a compile-time S in [0, 192)
 template <int S>

@@ -7,10 +7,10 @@
 #include <vector>
 
 #define REP 64
-#define ITER 200
+#define ITER 2000
 
 template <int T>
-__global__ void __launch_bounds__(512) k(uint64_t *out, uint64_t seed) {
+__global__ void __launch_bounds__(1024) k(uint64_t *out, uint64_t seed) {
     uint64_t a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
     uint64_t b = seed * 31 + 7;
     uint32_t c0 = (uint32_t)a0, c1 = (uint32_t)a1, c2 = c0 * 3, c3 = c1 * 5;
@@ -78,17 +78,25 @@ void run(const char *name, int threads) {
     uint64_t *d;
     const int blocks = 256;
     hipMalloc(&d, (blocks * threads + 1) * 8);
-    hipLaunchKernelGGL(k<T>, dim3(blocks), dim3(threads), 0, 0, d, 12345ull);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k<T>, dim3(blocks), dim3(threads), 0, 0, d, 12345ull);
     hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 10; r++) hipLaunchKernelGGL(k<T>, dim3(blocks), dim3(threads), 0, 0, d, 12345ull);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
     uint64_t cyc;
     hipMemcpy(&cyc, d + blocks * threads, 8, hipMemcpyDeviceToHost);
-    printf("%-44s waves/SIMD=%d  %.2f cycles/instr (per wave)\n", name, threads / 256, (double)cyc / (ITER * REP));
+    double winstr = (double)blocks * (threads / 64) * ITER * REP * 10;
+    printf("%-40s waves/SIMD=%d  %.2f ticks/instr/wave   wall %.3f ms   %.1f G wave-instr/s  (%.2f per SIMD-cycle @2.4GHz)\n", name,
+           threads / 256, (double)cyc / (ITER * REP), ms / 10, winstr / (ms * 1e-3) / 1e9, winstr / (ms * 1e-3) / (1024 * 2.4e9));
     hipFree(d);
 }
 
 int main() {
-    for (int th : {256, 512}) {
+    for (int th : {256, 512, 768, 1024}) {
         run<2>("v_add_u32 (independent)", th);
         run<7>("v_add_u32 (dependent chain)", th);
         run<0>("v_lshl_add_u64 (independent)", th);
