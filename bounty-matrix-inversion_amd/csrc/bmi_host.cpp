@@ -82,7 +82,7 @@ struct bmi_ctx {
     bool have_keys = false;
     u64 seed = 0, enc_counter = 0;
     std::vector<u64> sk_small, sk_big, bsk_std, ksk;
-    u64 *d_bsk = nullptr, *d_ksk = nullptr, *d_tw = nullptr, *d_luts = nullptr;
+    u64 *d_bsk = nullptr, *d_ksk = nullptr, *d_ks_bias = nullptr, *d_tw = nullptr, *d_luts = nullptr;
     uint32_t n_luts = 0, lut_cap = 0;
     std::vector<std::vector<u64>> luts_host;
     // growable device scratch
@@ -215,7 +215,7 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
 void bmi_ctx_destroy(bmi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (void *p : {(void *)c->d_bsk, (void *)c->d_ksk, (void *)c->d_tw, (void *)c->d_luts, (void *)c->d_small,
+    for (void *p : {(void *)c->d_bsk, (void *)c->d_ksk, (void *)c->d_ks_bias, (void *)c->d_tw, (void *)c->d_luts, (void *)c->d_small,
                     (void *)c->d_io_a, (void *)c->d_io_b, (void *)c->d_io_ids, c->d_ks_partial})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -301,6 +301,18 @@ int bmi_keygen(bmi_ctx *c, uint64_t seed) {
     HIP_OK(c, hipMemset(c->d_ksk, 0, ksk_rows * c->ks_stride * sizeof(u64)));
     HIP_OK(c, hipMemcpy2D(c->d_ksk, c->ks_stride * sizeof(u64), c->ksk.data(), (n + 1) * sizeof(u64),
                           (n + 1) * sizeof(u64), ksk_rows, hipMemcpyHostToDevice));
+    // bias vector of the unsigned-digit keyswitch: (B/2) * sum_rows ksk[row][col]
+    {
+        std::vector<u64> bias(c->ks_stride, 0);
+        const u64 half = (u64)1 << (P.ks_base_log - 1);
+        for (size_t r = 0; r < ksk_rows; r++) {
+            const u64 *row = c->ksk.data() + r * (n + 1);
+            for (uint32_t x = 0; x <= n; x++) bias[x] = gl::add(bias[x], row[x]);
+        }
+        for (uint32_t x = 0; x <= n; x++) bias[x] = gl::mul(bias[x], half);
+        if (!c->d_ks_bias) HIP_OK(c, hipMalloc(&c->d_ks_bias, c->ks_stride * sizeof(u64)));
+        HIP_OK(c, hipMemcpy(c->d_ks_bias, bias.data(), c->ks_stride * sizeof(u64), hipMemcpyHostToDevice));
+    }
     c->have_keys = true;
     return 0;
 }
@@ -436,7 +448,7 @@ int bmi_keyswitch_batch(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64
         HIP_OK(c, hipMalloc(&c->d_ks_partial, cap));
         c->ks_partial_bytes = cap;
     }
-    int rc = bmi::launch_keyswitch(d_in, c->d_ksk, d_small, slices > 1 ? c->d_ks_partial : nullptr, slices, count, c->P.n,
+    int rc = bmi::launch_keyswitch(d_in, c->d_ksk, c->d_ks_bias, d_small, slices > 1 ? c->d_ks_partial : nullptr, slices, count, c->P.n,
                                    c->big_n, c->P.ks_levels, c->P.ks_base_log, c->ks_stride, (hipStream_t)stream);
     return rc ? fail(c, -2, std::string("keyswitch launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
 }

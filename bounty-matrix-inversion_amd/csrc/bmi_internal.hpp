@@ -20,8 +20,10 @@ int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const 
 int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const u64 *bsk,
                             const u64 *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s);
 // slices > 1 (with a partial buffer of slices * count * ks_stride 16-byte words): latency form for small batches
-int launch_keyswitch(const u64 *in, const u64 *ksk, u64 *out, void *partial, uint32_t slices, uint32_t count,
-                     uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride, hipStream_t s);
+// ks_bias[col] = (B/2) * sum over all rows of ksk[row][col] mod q (the digits are staged unsigned, d + B/2)
+int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
+                     uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,
+                     hipStream_t s);
 int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *idx, const i64 *coef,
                    const u64 *const_body, u64 *out, uint32_t count, uint32_t width, hipStream_t s);
 }  // namespace bmi
