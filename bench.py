@@ -54,13 +54,20 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal knobs (not used by the driver): BMI_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 and
+    # BMI_BENCH_BACKEND=gloo replaces RCCL, so that the N > 1 code path can be exercised on a one-GPU box.
+    dev_index = 0 if os.environ.get("BMI_BENCH_SHARE_DEVICE") == "1" else local_rank
+    backend = os.environ.get("BMI_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
-    eng = tfhe.Engine(device=local_rank)
+    eng = tfhe.Engine(device=dev_index)
     eng.keygen(0x5EED)  # keys replicated on every GPU (same seed)
     P = eng.P
     B = args.batch
@@ -105,7 +112,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     br_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))

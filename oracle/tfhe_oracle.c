@@ -56,7 +56,29 @@ typedef struct {
 static inline u64 addq(u64 a, u64 b) { u64 s = a + b; return (s < a || s >= Q) ? s - Q : s; }
 static inline u64 subq(u64 a, u64 b) { return a >= b ? a - b : a + (Q - b); }
 static inline u64 negq(u64 a) { return a ? Q - a : 0; }
-static inline u64 mulq(u64 a, u64 b) { return (u64)(((u128)a * b) % Q); }
+/* 128-bit product folded with 2^64 = 2^32 - 1 and 2^96 = -1 (mod q); checked against the plain `% Q` form in
+ * ora_selftest_mulq (the baseline should not be handicapped by a 128-bit division per multiply). */
+static inline u64 mulq(u64 a, u64 b) {
+    u128 p = (u128)a * b;
+    u64 lo = (u64)p, hi = (u64)(p >> 64), hh = hi >> 32, hl = hi & 0xFFFFFFFFull;
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= 0xFFFFFFFFull;
+    u64 t1 = hl * 0xFFFFFFFFull;
+    u64 r = t0 + t1;
+    if (r < t1) r += 0xFFFFFFFFull;
+    return r >= Q ? r - Q : r;
+}
+int ora_selftest_mulq(u64 seed, uint32_t iters) {
+    u64 x = seed | 1;
+    for (uint32_t i = 0; i < iters; i++) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        u64 a = x % Q;
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        u64 b = (i & 7) == 0 ? Q - 1 - (x & 3) : x % Q;
+        if (mulq(a, b) != (u64)(((u128)a * b) % Q)) return 0;
+    }
+    return 1;
+}
 static u64 powq(u64 b, u64 e) { u64 r = 1; while (e) { if (e & 1) r = mulq(r, b); b = mulq(b, b); e >>= 1; } return r; }
 static inline u64 from_i64(i64 v) { return v >= 0 ? (u64)v % Q : Q - ((u64)(-v) % Q); }
 static inline i64 centered(u64 a) { return a > (Q >> 1) ? (i64)(a - Q) : (i64)a; } /* (-q/2, q/2] */

@@ -27,6 +27,13 @@ def test_ntt_matches_schoolbook(logN):
     assert int(c[0]) == Q - 1 and not c[1:].any()
 
 
+def test_fast_mulq_matches_division():
+    import ctypes
+    lib = to.lib()
+    lib.ora_selftest_mulq.restype = ctypes.c_int
+    assert lib.ora_selftest_mulq(ctypes.c_uint64(12345), ctypes.c_uint32(2_000_000)) == 1
+
+
 def test_decompose_recomposes():
     for levels, bl in [(3, 15), (8, 4), (2, 8), (1, 23)]:
         for a in list(rand_q(200)) + [0, 1, Q - 1, Q // 2, Q // 2 + 1, (1 << 63) - 1]:
