@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — PBS throughput of the MI355X-native TFHE engine (BASELINE.json metric "PBS/sec per GPU").
 
+`value` = whole-job PBS/s (the first half of BASELINE.json's metric); the encrypted-inverse wall-clocks (the second
+half) are reported under config.encrypted_inverse_wall_clock at N = 1.
+
 One "step" = one pass of the hot path (keyswitch -> mod-switch -> blind rotation -> sample extraction)
 over one batch of B synthetic ciphertexts per GPU, inputs already resident in HBM, at the north-star
 parameter set (n=630, N=1024, k=1, l=3).  The batch shards over GPUs with no data-path collective
@@ -42,7 +45,9 @@ def main():
                     help="ciphertexts per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inverse", action="store_true", help="also time the encrypted 2x2 and 3x3 inverses (configs 2, 3)")
+    ap.add_argument("--no-inverse", action="store_true", help="skip the encrypted-inverse wall-clock leg")
+    ap.add_argument("--inverse-sizes", default="2,3", help="matrix sizes of the encrypted-inverse leg (N=1, rank 0); "
+                    "4 adds ~45 s (BASELINE configs 2, 3, 4)")
     args = ap.parse_args()
 
     import torch
@@ -136,7 +141,7 @@ def main():
         except Exception:
             traffic = None
     res = {
-        "metric": "PBS/sec per GPU (whole-job PBS/s = value)", "value": value, "unit": "PBS/s",
+        "metric": "PBS/sec per GPU + encrypted n x n inverse wall-clock (n=2,3,4)", "value": value, "unit": "PBS/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64 (mod 2^64-2^32+1)", "data": "synthetic",
@@ -172,12 +177,13 @@ def main():
                                "concrete": "Concrete not present (import concrete fails: not installed, no network)"}
         res["config"]["verified_bit_exact_vs_oracle"] = bit_exact
 
-    if args.inverse and rank == 0:
+    if not args.no_inverse and rank == 0 and world == 1:
         try:
             from bmi_amd import inverse_bench
-            res["config"]["inverse"] = inverse_bench.run(eng)
+            sizes = tuple(int(x) for x in args.inverse_sizes.split(",") if x)
+            res["config"]["encrypted_inverse_wall_clock"] = inverse_bench.run(eng, sizes)
         except Exception as e:  # reported, never hidden
-            res["config"]["inverse"] = {"error": repr(e)}
+            res["config"]["encrypted_inverse_wall_clock"] = {"error": repr(e)}
 
     if rank == 0:
         print(json.dumps(res))
