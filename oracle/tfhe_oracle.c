@@ -36,7 +36,16 @@ typedef uint64_t u64;
 typedef int64_t i64;
 typedef unsigned __int128 u128;
 
-#define Q 0xFFFFFFFF00000001ULL /* 2^64 - 2^32 + 1 */
+#define GOLD 0xFFFFFFFF00000001ULL /* 2^64 - 2^32 + 1 */
+#define P49 562949952700417ULL       /* 2^49 - 720895, = 1 mod 2^16 */
+
+/* The ciphertext modulus is a run-time choice between two NTT-friendly primes (set by ora_set_field, which every
+ * entry point taking parameters calls): q_bits = 64 -> Goldilocks, q_bits = 49 -> P49 (the set whose GPU kernels
+ * carry exact integers in f64).  "2^q_bits" plays the role of the torus size: gadget elements and message
+ * scalings are powers of two below it. */
+static u64 Q = GOLD;
+static uint32_t QBITS = 64;
+static u64 GEN = 7; /* generator of Z_q^* */
 
 /* Must mirror include/bmi_tfhe.h : bmi_params (same field order). */
 typedef struct {
@@ -47,10 +56,17 @@ typedef struct {
     uint32_t bs_base_log; /* Bg : bootstrap decomposition base log */
     uint32_t ks_levels;   /* keyswitch levels */
     uint32_t ks_base_log; /* keyswitch base log */
-    uint32_t reserved;
+    uint32_t q_bits;      /* 64: q = 2^64 - 2^32 + 1 ; 49: q = 2^49 - 720895 */
     double lwe_noise;  /* std-dev (fraction of q) of keyswitch-key encryptions */
     double glwe_noise; /* std-dev (fraction of q) of GLWE / fresh big-key encryptions */
 } ora_params;
+
+int ora_set_field(uint32_t q_bits) {
+    if (q_bits == 64) { Q = GOLD; QBITS = 64; GEN = 7; return 0; }
+    if (q_bits == 49) { Q = P49; QBITS = 49; GEN = 5; return 0; }
+    return -1;
+}
+u64 ora_modulus(void) { return Q; }
 
 /* ------------------------------------------------------------------ Z_q ---- */
 static inline u64 addq(u64 a, u64 b) { u64 s = a + b; return (s < a || s >= Q) ? s - Q : s; }
@@ -59,6 +75,7 @@ static inline u64 negq(u64 a) { return a ? Q - a : 0; }
 /* 128-bit product folded with 2^64 = 2^32 - 1 and 2^96 = -1 (mod q); checked against the plain `% Q` form in
  * ora_selftest_mulq (the baseline should not be handicapped by a 128-bit division per multiply). */
 static inline u64 mulq(u64 a, u64 b) {
+    if (Q != GOLD) return (u64)(((u128)a * b) % Q);
     u128 p = (u128)a * b;
     u64 lo = (u64)p, hi = (u64)(p >> 64), hh = hi >> 32, hl = hi & 0xFFFFFFFFull;
     u64 t0 = lo - hh;
@@ -75,7 +92,7 @@ int ora_selftest_mulq(u64 seed, uint32_t iters) {
         u64 a = x % Q;
         x ^= x << 13; x ^= x >> 7; x ^= x << 17;
         u64 b = (i & 7) == 0 ? Q - 1 - (x & 3) : x % Q;
-        if (mulq(a, b) != (u64)(((u128)a * b) % Q)) return 0;
+        if (mulq(a, b) != (u64)(((u128)a * b) % Q)) return 0; /* call with the Goldilocks field selected */
     }
     return 1;
 }
@@ -92,12 +109,12 @@ static inline u64 mix64(u64 z) {
 }
 static inline u64 stream_key(u64 seed, u64 stream) { return mix64(seed ^ (stream * 0xD6E8FEB86659FD93ULL)); }
 static inline u64 rnd_u64(u64 key, u64 idx) { return mix64(key + (idx + 1) * 0x9E3779B97F4A7C15ULL); }
-static inline u64 rnd_modq(u64 key, u64 idx) { u64 u = rnd_u64(key, idx); return u >= Q ? u - Q : u; }
+static inline u64 rnd_modq(u64 key, u64 idx) { u64 u = rnd_u64(key, idx); return QBITS == 64 ? (u >= Q ? u - Q : u) : u % Q; }
 static inline u64 rnd_gauss(u64 key, u64 idx, double sigma) { /* element of Z_q */
     double u1 = ((double)((rnd_u64(key, 2 * idx) >> 11) + 1)) * (1.0 / 9007199254740992.0);
     double u2 = ((double)(rnd_u64(key, 2 * idx + 1) >> 11)) * (1.0 / 9007199254740992.0);
     double g = sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
-    return from_i64(llround(g * sigma * 18446744073709551616.0));
+    return from_i64(llround(g * sigma * (QBITS == 64 ? 18446744073709551616.0 : (double)Q)));
 }
 enum { ST_SK_SMALL = 1, ST_SK_BIG = 2, ST_BSK_MASK = 3, ST_BSK_NOISE = 4, ST_KSK_MASK = 5, ST_KSK_NOISE = 6,
        ST_ENC_MASK = 7, ST_ENC_NOISE = 8 };
@@ -115,7 +132,7 @@ static uint32_t bitrev(uint32_t x, uint32_t bits) { uint32_t r = 0; for (uint32_
 static ntt_tab *ntt_make(uint32_t logN) {
     ntt_tab *t = (ntt_tab *)malloc(sizeof *t);
     t->logN = logN; t->N = 1u << logN;
-    u64 psi = powq(7, (Q - 1) / (2ull * t->N)); /* 7 generates Z_q^* */
+    u64 psi = powq(GEN, (Q - 1) / (2ull * t->N)); /* GEN generates Z_q^* */
     u64 ipsi = powq(psi, Q - 2);
     t->psi_br = (u64 *)malloc(t->N * sizeof(u64));
     t->ipsi_br = (u64 *)malloc(t->N * sizeof(u64));
@@ -174,9 +191,27 @@ void ora_negacyclic_ntt(uint32_t logN, const u64 *a, const u64 *b, u64 *c) {
  * (gadget element 2^(64 - base_log*(lev+1))).  Lower digits lie in [-B/2, B/2); the top
  * digit absorbs the last carry and lies in [-B/2, B/2], so sum_lev digit*gadget equals the
  * centred lift rounded to a multiple of 2^(64 - levels*base_log), exactly (no wrap). */
+/* round-half-to-even of x / 2^k (what v_rndne_f64 computes on the GPU) */
+static inline i64 rne_shift(i64 x, uint32_t k) {
+    i64 q = x >> k, rem = x - (q << k), half = (i64)1 << (k - 1);
+    if (rem > half || (rem == half && (q & 1))) q++;
+    return q;
+}
 void ora_decompose(u64 a, uint32_t levels, uint32_t base_log, i64 *digits) {
     i64 c = centered(a);
-    uint32_t shift = 64 - levels * base_log;
+    uint32_t shift = QBITS - levels * base_log;
+    if (QBITS != 64) {
+        /* 49-bit field: every rounding is round-half-to-even (the GPU does it with v_rndne_f64), digits lie in
+         * [-B/2, B/2] and recompose exactly to the rounded value */
+        i64 r = rne_shift(c, shift);
+        for (int lev = (int)levels - 1; lev >= 1; lev--) {
+            i64 rn = rne_shift(r, base_log);
+            digits[lev] = r - (rn << base_log);
+            r = rn;
+        }
+        digits[0] = r;
+        return;
+    }
     i64 r = (c >> shift) + ((c >> (shift - 1)) & 1); /* round half up, no 64-bit overflow */
     i64 B = (i64)1 << base_log, half = B >> 1;
     for (int lev = (int)levels - 1; lev >= 1; lev--) {
@@ -211,6 +246,7 @@ static void poly_rot(uint32_t N, const u64 *in, uint32_t e, u64 *out) {
  *   ksk[k*N][l_ks][n+1]    LWE_small( sk_big[j] * 2^(64-Bks*(lev+1)) ), body last
  */
 void ora_keygen(const ora_params *P, u64 seed, u64 *sk_small, u64 *sk_big, u64 *bsk, u64 *ksk) {
+    ora_set_field(P->q_bits);
     uint32_t n = P->n, N = 1u << P->log_N, k = P->k, l = P->bs_levels, lk = P->ks_levels;
     u64 k1 = stream_key(seed, ST_SK_SMALL), k2 = stream_key(seed, ST_SK_BIG);
     for (uint32_t i = 0; i < n; i++) sk_small[i] = rnd_u64(k1, i) & 1;
@@ -241,7 +277,7 @@ void ora_keygen(const ora_params *P, u64 seed, u64 *sk_small, u64 *sk_big, u64 *
             u64 *B = row + (size_t)k * N;
             for (uint32_t x = 0; x < N; x++) B[x] = addq(acc[x], rnd_gauss(ke, (u64)ir * N + x, P->glwe_noise));
             if (sk_small[i]) {
-                u64 g = (u64)1 << (64 - P->bs_base_log * (lev + 1));
+                u64 g = (u64)1 << (QBITS - P->bs_base_log * (lev + 1));
                 row[(size_t)comp * N] = addq(row[(size_t)comp * N], g);
             }
         }
@@ -259,7 +295,7 @@ void ora_keygen(const ora_params *P, u64 seed, u64 *sk_small, u64 *sk_big, u64 *
             row[c] = rnd_modq(kkm, (u64)jr * (n + 1) + c);
             if (sk_small[c]) b = addq(b, row[c]);
         }
-        if (sk_big[j]) b = addq(b, (u64)1 << (64 - P->ks_base_log * (lev + 1)));
+        if (sk_big[j]) b = addq(b, (u64)1 << (QBITS - P->ks_base_log * (lev + 1)));
         row[n] = b;
     }
 }
@@ -321,6 +357,7 @@ typedef struct {
 } ora_ctx;
 
 ora_ctx *ora_ctx_create(const ora_params *P, const u64 *bsk, const u64 *ksk) {
+    ora_set_field(P->q_bits);
     ora_ctx *c = (ora_ctx *)malloc(sizeof *c);
     c->P = *P; c->t = ntt_make(P->log_N); c->ksk = ksk;
     uint32_t N = 1u << P->log_N;

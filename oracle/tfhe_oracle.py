@@ -17,7 +17,7 @@ Q = 0xFFFFFFFF00000001
 class Params(C.Structure):
     _fields_ = [("n", C.c_uint32), ("log_N", C.c_uint32), ("k", C.c_uint32), ("bs_levels", C.c_uint32),
                 ("bs_base_log", C.c_uint32), ("ks_levels", C.c_uint32), ("ks_base_log", C.c_uint32),
-                ("reserved", C.c_uint32), ("lwe_noise", C.c_double), ("glwe_noise", C.c_double)]
+                ("q_bits", C.c_uint32), ("lwe_noise", C.c_double), ("glwe_noise", C.c_double)]
 
     @property
     def N(self):
@@ -28,12 +28,27 @@ class Params(C.Structure):
         return self.k * self.N + 1
 
 
+GOLD = 0xFFFFFFFF00000001
+P49 = 562949952700417
+MODULUS = {64: GOLD, 49: P49}
+
+
 def default_params(**kw):
-    """North-star set: n=630, N=1024, k=1, l=3 (BASELINE.json); the rest is this build's choice."""
-    d = dict(n=630, log_N=10, k=1, bs_levels=3, bs_base_log=15, ks_levels=8, ks_base_log=4, reserved=0,
+    """North-star set: n=630, N=1024, k=1, l=3 (BASELINE.json); the rest is this build's choice.
+    q_bits selects the ciphertext modulus: 64 -> 2^64 - 2^32 + 1, 49 -> 2^49 - 720895."""
+    d = dict(n=630, log_N=10, k=1, bs_levels=3, bs_base_log=15, ks_levels=8, ks_base_log=4, q_bits=64,
              lwe_noise=2.0 ** -25, glwe_noise=2.0 ** -44)
     d.update(kw)
+    if d["q_bits"] == 49 and "glwe_noise" not in kw:
+        d["glwe_noise"] = 2.0 ** -40   # 49-bit modulus: keep the absolute noise above the integer grid
     return Params(**d)
+
+
+def set_field(q_bits):
+    """selects the oracle's ciphertext modulus (global); returns it"""
+    if lib().ora_set_field(C.c_uint32(q_bits)) != 0:
+        raise ValueError("unsupported q_bits")
+    return MODULUS[q_bits]
 
 
 def build():
@@ -55,6 +70,7 @@ def lib():
         _lib.ora_ctx_create.restype = C.c_void_p
         _lib.ora_modswitch.restype = C.c_uint32
         _lib.ora_num_threads.restype = C.c_int
+        _lib.ora_modulus.restype = C.c_uint64
     return _lib
 
 
@@ -101,9 +117,14 @@ def modswitch(a, log2N):
     return int(lib().ora_modswitch(C.c_uint64(int(a)), C.c_uint32(log2N)))
 
 
+def modulus():
+    return int(lib().ora_modulus())
+
+
 def encode(msgs, delta_log):
-    """signed integers -> torus values m * 2^delta_log mod q"""
-    return np.array([(int(m) << delta_log) % Q for m in np.asarray(msgs).reshape(-1)], dtype=np.uint64)
+    """signed integers -> torus values m * 2^delta_log mod q (q = the currently selected field)"""
+    q = modulus()
+    return np.array([(int(m) << delta_log) % q for m in np.asarray(msgs).reshape(-1)], dtype=np.uint64)
 
 
 def lwe_encrypt(key, noise, seed, first, torus):

@@ -132,3 +132,77 @@ def test_lincomb():
     consts = to.encode([1, 0, -4], dl)
     out = to.lincomb(P.big, ct, row_ptr, idx, coef, consts)
     assert list(to.decode(to.lwe_phase(K.sk_big, out), dl)) == [5, 2, -4]
+
+
+# ----------------------------------------------------------------------------------------------------------
+# The second field: q = 2^49 - 720895 (q_bits = 49), the set whose GPU kernels carry exact integers in f64.
+@pytest.fixture
+def field49():
+    q = to.set_field(49)
+    yield q
+    to.set_field(64)
+
+
+def rand_q49(n, q):
+    return RNG.integers(0, q, n, dtype=np.uint64)
+
+
+def test_p49_is_an_ntt_prime_and_ntt_matches_schoolbook(field49):
+    q = field49
+    assert q == 562949952700417 and (q - 1) % (1 << 16) == 0 and pow(5, (q - 1) // 2, q) == q - 1
+    for logN in (3, 6, 8):
+        a, b = rand_q49(1 << logN, q), rand_q49(1 << logN, q)
+        assert np.array_equal(to.negacyclic(logN, a, b), to.negacyclic(logN, a, b, schoolbook=True))
+
+
+def test_p49_decompose_round_half_even(field49):
+    q = field49
+    for levels, bl in [(3, 15), (8, 4), (2, 8)]:
+        shift = 49 - levels * bl
+        for a in list(rand_q49(300, q)) + [0, 1, q - 1, q // 2, q // 2 + 1, (1 << shift) // 2, 3 * (1 << shift) // 2]:
+            d = to.decompose(a, levels, bl)
+            assert all(abs(int(x)) <= (1 << (bl - 1)) for x in d)
+            c = int(a) if int(a) <= q // 2 else int(a) - q
+            rec = sum(int(d[i]) << (49 - bl * (i + 1)) for i in range(levels))
+            assert abs(rec - c) <= 1 << (shift - 1)
+            # the rounded value is round-half-even of c / 2^shift
+            r, rem = divmod(c, 1 << shift)
+            if rem > (1 << (shift - 1)) or (rem == (1 << (shift - 1)) and r & 1):
+                r += 1
+            assert rec == r << shift
+
+
+@pytest.mark.parametrize("p", [1, 3, 4])
+def test_p49_pbs_evaluates_every_lut_entry(field49, p):
+    P = to.default_params(n=16, log_N=8, q_bits=49, lwe_noise=2.0 ** -36, glwe_noise=2.0 ** -40)
+    K = to.keygen(P, 21 + p)
+    assert (K.bsk < np.uint64(field49)).all() and (K.ksk < np.uint64(field49)).all()
+    ctx = to.Ctx(P, K.bsk, K.ksk)
+    M = 1 << p
+    msgs = np.arange(-M // 2, M // 2)
+    table = np.array([(5 * m * m + m + 2) % M - M // 2 for m in msgs], dtype=np.int64)
+    dl = 48 - p
+    tv = to.make_test_vector(P.log_N, p, table, dl)
+    ct = to.lwe_encrypt(K.sk_big, P.glwe_noise, 7, 0, to.encode(msgs, dl))
+    assert list(to.decode(to.lwe_phase(K.sk_big, ct), dl)) == list(msgs)
+    out = ctx.pbs(ct, tv, np.zeros(M, np.uint32))
+    assert list(to.decode(to.lwe_phase(K.sk_big, out), dl)) == list(table)
+
+
+def test_p49_pbs_default_params(field49):
+    P = to.default_params(q_bits=49)
+    K = to.keygen(P, 0x5EED)
+    ctx = to.Ctx(P, K.bsk, K.ksk)
+    dl = 44
+    msgs = np.array([-8, -3, 0, 5, 7])
+    ident = np.arange(-8, 8, dtype=np.int64)
+    tv = to.make_test_vector(10, 4, ident, dl)
+    ct = to.lwe_encrypt(K.sk_big, P.glwe_noise, 5, 0, to.encode(msgs, dl))
+    out = ctx.pbs(ct, tv, np.zeros(5, np.uint32))
+    assert list(to.decode(to.lwe_phase(K.sk_big, out), dl)) == list(msgs)
+    ph = to.lwe_phase(K.sk_big, out)
+    q = field49
+    for x, m in zip(ph, msgs):
+        e = (int(x) - (int(m) << dl)) % q
+        e = e - q if e > q // 2 else e
+        assert abs(e) < 2 ** (dl - 6)
