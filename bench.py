@@ -45,6 +45,9 @@ def main():
                     help="ciphertexts per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--q-bits", type=int, default=None, choices=[64, 49],
+                    help="ciphertext modulus: 64 = 2^64-2^32+1 (integer kernels), 49 = 2^49-720895 (f64 kernels); "
+                         "default: the library's default")
     ap.add_argument("--no-inverse", action="store_true", help="skip the encrypted-inverse wall-clock leg")
     ap.add_argument("--inverse-sizes", default="2,3", help="matrix sizes of the encrypted-inverse leg (N=1, rank 0); "
                     "4 adds ~45 s (BASELINE configs 2, 3, 4)")
@@ -72,18 +75,19 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    eng = tfhe.Engine(device=dev_index)
+    eng = tfhe.Engine(tfhe.default_params(q_bits=args.q_bits), device=dev_index)
     eng.keygen(0x5EED)  # keys replicated on every GPU (same seed)
     P = eng.P
+    DL = eng.delta_log()
     B = args.batch
     from bmi_amd.shard import shard_range
     # the whole job's batch is B * world ciphertexts (weak scaling); rank r owns a contiguous range of it
     lo, hi = shard_range(B * world, rank, world)
     msgs = np.random.default_rng(1234).integers(-8, 8, B * world)[lo:hi]
-    ident = eng.lut_register(np.arange(-8, 8), 4, 59)
+    ident = eng.lut_register(np.arange(-8, 8), 4, DL)
     rnd_table = np.random.default_rng(99).integers(-8, 8, 16)
-    rlut = eng.lut_register(rnd_table, 4, 59)
-    ct = eng.encrypt(msgs, 59)
+    rlut = eng.lut_register(rnd_table, 4, DL)
+    ct = eng.encrypt(msgs, DL)
     lut_sel = (np.arange(B) & 1).astype(np.int32)
     d_in = torch.from_numpy(ct.view(np.int64)).to(dev)
     d_ids = torch.from_numpy(np.where(lut_sel == 0, ident, rlut).astype(np.int32)).to(dev)
@@ -124,7 +128,7 @@ def main():
 
     # correctness of what was timed: every output decrypts to LUT[m]
     out = d_out.cpu().numpy().view(np.uint64)
-    dec = eng.decrypt(out, 59)
+    dec = eng.decrypt(out, DL)
     want = np.where(lut_sel == 0, msgs, rnd_table[msgs + 8])
     verified = bool(np.array_equal(dec, want))
 
@@ -144,14 +148,14 @@ def main():
         "metric": "PBS/sec per GPU + encrypted n x n inverse wall-clock (n=2,3,4)", "value": value, "unit": "PBS/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u64 (mod 2^64-2^32+1)", "data": "synthetic",
+        "vs_baseline": None, "dtype": ("u64 (mod 2^64-2^32+1)" if eng.q_bits == 64 else "exact integers mod 2^49-720895 carried in f64"), "data": "synthetic",
         "config": {"workload": f"pbs_batch: B={B} LWE ciphertexts per GPU per step, TFHE n=630 N=1024 k=1 l=3 "
-                               f"(Bg=2^15, ks 8x4 bits), 4-bit signed messages, 2 LUTs (identity, random)",
+                               f"(Bg=2^15, ks 8x4 bits), q_bits={eng.q_bits}, 4-bit signed messages, 2 LUTs (identity, random)",
                    "batch_per_gpu": B, "pbs_per_gpu_per_s": value / world, "verified_decrypt": verified,
                    "derived_reference_pbs_per_s_64core_cpu": "35-69 (derived, BASELINE.md §1)"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_blind_rotate_tp", "kernel_ms": br_ms,
+                     "kernel": "k_blind_rotate_tp" if eng.q_bits == 64 else "k_blind_rotate_tp49", "kernel_ms": br_ms,
                      "algorithmic_bytes_per_pbs": BSK_BYTES_PER_PBS,
                      "alu": {"modmul_per_s": MODMUL_PER_PBS * B / (br_ms * 1e-3), "modmul_per_pbs": MODMUL_PER_PBS}},
     }
@@ -159,7 +163,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import tfhe_oracle as to
         sk_small, sk_big, bsk, ksk = eng.export_keys()
-        octx = to.Ctx(to.default_params(), bsk, ksk)
+        octx = to.Ctx(to.default_params(q_bits=eng.q_bits), bsk, ksk)
         tvs = np.stack([eng.lut_get(ident), eng.lut_get(rlut)])
         threads = to.num_threads()
         t1 = time.perf_counter()

@@ -13,7 +13,7 @@ graph (matrix_inversion/main.py:53-66,81).  Here the same role is played by:
   * `simulate`— plaintext evaluation of the recorded graph (the analogue of `circuit.simulate`,
                 main.py:107); it also checks every interval claim, so it doubles as the range checker.
 
-Encoding: every ciphertext carries a signed message m at scale 2^(63 - MSG_BITS) (MSG_BITS = 4: a PBS input
+Encoding: every ciphertext carries a signed message m at scale 2^(q_bits - 1 - MSG_BITS) (MSG_BITS = 4: a PBS input
 must lie in [-8, 7]; between PBS, values may range over [-16, 15]).  A look-up whose input interval is
 narrower than 16 values is evaluated with a coarser message space (input multiplied by 2^(4-p)), which
 widens the decision boxes and makes mod-switch failures vanishingly rare.
@@ -23,7 +23,7 @@ from __future__ import annotations
 import numpy as np
 
 MSG_BITS = 4
-DELTA_LOG = 63 - MSG_BITS  # 59
+DELTA_LOG = 63 - MSG_BITS  # 59 for the 64-bit modulus; engines report theirs (tfhe.Engine.delta_log())
 
 
 class RangeError(ValueError):

@@ -10,14 +10,12 @@ from __future__ import annotations
 
 import numpy as np
 
-from .circuit import DELTA_LOG
-
-Q = 0xFFFFFFFF00000001
+from .circuit import MSG_BITS
 
 
-def _torus(v):
-    """signed integer -> v * 2^DELTA_LOG mod q, as an int64 bit pattern"""
-    t = (int(v) << DELTA_LOG) % Q
+def _torus(v, delta_log, q):
+    """signed integer -> v * 2^delta_log mod q, as an int64 bit pattern"""
+    t = (int(v) << delta_log) % q
     return t - (1 << 64) if t >= (1 << 63) else t
 
 
@@ -39,7 +37,9 @@ class Executor:
                 new_id[circuit.nodes[ni][3]] = nxt
                 nxt += 1
         self.n_leaves = nxt
-        lut_ids = [engine.lut_register(np.array(tab, dtype=np.int64), p, DELTA_LOG) for p, tab in circuit.luts]
+        self.delta_log = engine.delta_log(MSG_BITS)
+        q, dl = engine.modulus, self.delta_log
+        lut_ids = [engine.lut_register(np.array(tab, dtype=np.int64), p, dl) for p, tab in circuit.luts]
 
         def csr(rows):
             rp, ix, cf, cs = [0], [], [], []
@@ -48,7 +48,7 @@ class Executor:
                     ix.append(new_id[leaf])
                     cf.append(coef)
                 rp.append(len(ix))
-                cs.append(_torus(const))
+                cs.append(_torus(const, dl, q))
             t = lambda a, dt: torch.from_numpy(np.asarray(a, dtype=dt)).to(self.dev)  # noqa: E731
             return (t(rp, np.int32), t(ix if ix else [0], np.int32), t(cf if cf else [0], np.int64), t(cs, np.int64))
 

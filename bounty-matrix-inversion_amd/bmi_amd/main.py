@@ -11,7 +11,7 @@ from typing import Tuple
 
 import numpy as np
 
-from .circuit import Circuit, DELTA_LOG
+from .circuit import Circuit, MSG_BITS
 from .qfloat import QFloat
 from .qfloat_matrix_inversion import (float_matrix_to_qfloat_arrays, qfloat_and_signs_arrays_to_float_matrix,
                                       qfloat_matrix_inverse)
@@ -88,14 +88,14 @@ class EncryptedMatrixInversion:
 
     def encrypt(self, quantized_matrix: np.ndarray, qfloats_signs: np.ndarray) -> np.ndarray:
         flat = self._flat_inputs(quantized_matrix, qfloats_signs)
-        return self._engine().encrypt(flat, DELTA_LOG)
+        return self._engine().encrypt(flat, self._engine().delta_log(MSG_BITS))
 
     def evaluate(self, encrypted_quantized_matrix: np.ndarray) -> np.ndarray:
         return self._executor().run(encrypted_quantized_matrix)
 
     def decrypt(self, encrypted_quantized_inverted_matrix: np.ndarray) -> np.ndarray:
         n2 = self.shape[0] * self.shape[1]
-        m = self._engine().decrypt(encrypted_quantized_inverted_matrix, DELTA_LOG)
+        m = self._engine().decrypt(encrypted_quantized_inverted_matrix, self._engine().delta_log(MSG_BITS))
         return m.reshape(n2, self.qfloat_len + 1)
 
     def dequantize(self, quantized_inverted_matrix: np.ndarray) -> np.ndarray:

@@ -12,13 +12,14 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libbmi_tfhe.so")
-Q = 0xFFFFFFFF00000001
+Q = 0xFFFFFFFF00000001  # Goldilocks modulus (q_bits = 64)
+MODULUS = {64: 0xFFFFFFFF00000001, 49: 562949952700417}
 
 
 class Params(C.Structure):
     _fields_ = [("n", C.c_uint32), ("log_N", C.c_uint32), ("k", C.c_uint32), ("bs_levels", C.c_uint32),
                 ("bs_base_log", C.c_uint32), ("ks_levels", C.c_uint32), ("ks_base_log", C.c_uint32),
-                ("reserved", C.c_uint32), ("lwe_noise", C.c_double), ("glwe_noise", C.c_double)]
+                ("q_bits", C.c_uint32), ("lwe_noise", C.c_double), ("glwe_noise", C.c_double)]
 
     @property
     def N(self):
@@ -42,6 +43,7 @@ _lib = None
 _U64P = C.POINTER(C.c_uint64)
 _SIGS = {
     "bmi_default_params": [C.POINTER(Params)],
+    "bmi_default_params_for": [C.c_uint32, C.POINTER(Params)],
     "bmi_ctx_create": [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)],
     "bmi_get_params": [C.c_void_p, C.POINTER(Params)],
     "bmi_keygen": [C.c_void_p, C.c_uint64],
@@ -108,9 +110,13 @@ def load_library():
     return _lib
 
 
-def default_params(**kw):
+def default_params(q_bits=None, **kw):
+    """North-star parameter set; q_bits = 64 (Goldilocks) or 49 (f64 kernels), None = the library's default."""
     P = Params()
-    load_library().bmi_default_params(C.byref(P))
+    lib = load_library()
+    rc = lib.bmi_default_params(C.byref(P)) if q_bits is None else lib.bmi_default_params_for(int(q_bits), C.byref(P))
+    if rc != 0:
+        raise BmiError("unsupported q_bits")
     for k, v in kw.items():
         setattr(P, k, v)
     return P
@@ -144,6 +150,12 @@ class Engine:
         self.h = h
         self.device = device
         self._luts = {}
+        self.q_bits = self.P.q_bits or 64
+        self.modulus = MODULUS[self.q_bits]
+
+    def delta_log(self, msg_bits=4):
+        """scaling exponent of a signed msg_bits-bit message space: q_bits - 1 - msg_bits (59 / 44 for 4 bits)"""
+        return self.q_bits - 1 - msg_bits
 
     def close(self):
         if getattr(self, "h", None):

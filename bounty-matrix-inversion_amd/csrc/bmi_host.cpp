@@ -14,7 +14,9 @@
 
 #include "../../include/bmi_tfhe.h"
 #include "bmi_internal.hpp"
+#include "field49.hpp"
 #include "ntt_wave.hpp"
+#include "ntt_wave_f64.hpp"
 
 using gl::i64;
 using gl::u64;
@@ -29,36 +31,49 @@ inline u64 mix64(u64 z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
+// Arithmetic mod the context's ciphertext modulus on the host (keygen, encryption, LUT construction): plain
+// 128-bit remainders - none of this is on the hot path.
+struct Fq {
+    u64 q = gl::P;
+    uint32_t bits = 64;
+    u64 add(u64 a, u64 b) const { return (u64)(((unsigned __int128)a + b) % q); }
+    u64 sub(u64 a, u64 b) const { return a >= b ? a - b : (u64)((unsigned __int128)a + q - b); }
+    u64 neg(u64 a) const { return a ? q - a : 0; }
+    u64 mul(u64 a, u64 b) const { return (u64)(((unsigned __int128)a * b) % q); }
+    u64 from_i64(long long v) const { return v >= 0 ? (u64)v % q : q - ((u64)(-v) % q); }
+    long long centered(u64 a) const { return a > (q >> 1) ? (long long)(a - q) : (long long)a; }
+    u64 pow(u64 b, u64 e) const {
+        u64 r = 1;
+        while (e) {
+            if (e & 1) r = mul(r, b);
+            b = mul(b, b);
+            e >>= 1;
+        }
+        return r;
+    }
+};
+
 struct Stream {
     u64 key;
-    Stream(u64 seed, u64 id) : key(mix64(seed ^ (id * 0xD6E8FEB86659FD93ULL))) {}
+    Fq f;
+    Stream(u64 seed, u64 id, const Fq &fq) : key(mix64(seed ^ (id * 0xD6E8FEB86659FD93ULL))), f(fq) {}
     u64 raw(u64 idx) const { return mix64(key + (idx + 1) * 0x9E3779B97F4A7C15ULL); }
     u64 bit(u64 idx) const { return raw(idx) & 1; }
     u64 uniform(u64 idx) const {
         u64 u = raw(idx);
-        return u >= gl::P ? u - gl::P : u;
+        return f.bits == 64 ? (u >= f.q ? u - f.q : u) : u % f.q;
     }
     u64 gauss(u64 idx, double sigma) const {  // Box-Muller, rounded to an element of Z_q
         const double u1 = (double)((raw(2 * idx) >> 11) + 1) * (1.0 / 9007199254740992.0);
         const double u2 = (double)(raw(2 * idx + 1) >> 11) * (1.0 / 9007199254740992.0);
         const double g = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586476925286766559 * u2);
-        const long long e = std::llround(g * sigma * 18446744073709551616.0);
-        return e >= 0 ? (u64)e % gl::P : gl::P - ((u64)(-e) % gl::P);
+        const long long e = std::llround(g * sigma * (f.bits == 64 ? 18446744073709551616.0 : (double)f.q));
+        return f.from_i64(e);
     }
 };
 enum : u64 { S_SK_SMALL = 1, S_SK_BIG, S_BSK_MASK, S_BSK_NOISE, S_KSK_MASK, S_KSK_NOISE, S_ENC_MASK, S_ENC_NOISE };
 
 thread_local std::string g_create_error;
-
-u64 pow_mod(u64 b, u64 e) {
-    u64 r = 1;
-    while (e) {
-        if (e & 1) r = gl::mul(r, b);
-        b = gl::mul(b, b);
-        e >>= 1;
-    }
-    return r;
-}
 
 template <class F>
 void parallel_for(size_t n, F f) {
@@ -76,13 +91,15 @@ void parallel_for(size_t n, F f) {
 
 struct bmi_ctx {
     bmi_params P{};
+    Fq f;
     int device = 0;
     uint32_t N = 0, big_n = 0, rows = 0, ks_stride = 0;
     hipStream_t stream = nullptr;  // the context's own stream (host-buffer entry points)
     bool have_keys = false;
     u64 seed = 0, enc_counter = 0;
     std::vector<u64> sk_small, sk_big, bsk_std, ksk;
-    u64 *d_bsk = nullptr, *d_ksk = nullptr, *d_ks_bias = nullptr, *d_tw = nullptr, *d_luts = nullptr;
+    void *d_bsk = nullptr, *d_tw = nullptr, *d_luts = nullptr;  // u64 words (Goldilocks) or f64 words (49-bit field)
+    u64 *d_ksk = nullptr, *d_ks_bias = nullptr;
     uint32_t n_luts = 0, lut_cap = 0;
     std::vector<std::vector<u64>> luts_host;
     // growable device scratch
@@ -92,10 +109,11 @@ struct bmi_ctx {
     uint32_t *d_io_ids = nullptr;
     size_t io_cap = 0;
     int variant = 0;
-    uint32_t lat_threshold = 768;  // 3 rounds of 256 one-workgroup PBS still beat one 66 ms round of the one-wave-per-PBS kernel
+    uint32_t lat_threshold = 768;  // 3 rounds of 256 one-workgroup PBS still beat one round of the wave-pair kernel
     void *d_ks_partial = nullptr;
     size_t ks_partial_bytes = 0;
     mutable std::string err;
+    bool f64() const { return f.bits == 49; }
 };
 
 namespace {
@@ -134,27 +152,35 @@ int ensure_io(bmi_ctx *c, size_t count) {
 }
 
 // out += X^t * a  (negacyclic), coefficient-wise in Z_q
-void add_shifted(u64 *out, const u64 *a, uint32_t t, uint32_t N) {
-    for (uint32_t j = 0; j + t < N; j++) out[j + t] = gl::add(out[j + t], a[j]);
-    for (uint32_t j = N - t; j < N; j++) out[j + t - N] = gl::sub(out[j + t - N], a[j]);
+void add_shifted(const Fq &f, u64 *out, const u64 *a, uint32_t t, uint32_t N) {
+    for (uint32_t j = 0; j + t < N; j++) out[j + t] = f.add(out[j + t], a[j]);
+    for (uint32_t j = N - t; j < N; j++) out[j + t - N] = f.sub(out[j + t - N], a[j]);
 }
 
-std::vector<u64> build_twiddles() {
+// Twiddle tables of the wave NTT as canonical integers mod q: W1[k1][l] = psi^(l (2 k1 + 1)),
+// W1I = psi^-(..) / N, W2[v][t] = (psi^32)^(t v), W2I its inverse (layout shared by both fields).
+std::vector<u64> build_twiddles(const Fq &f, u64 psi, u64 psi_inv, u64 n_inv) {
     using namespace nttw;
     std::vector<u64> tw(TW_WORDS);
     for (int k1 = 0; k1 < 16; k1++)
         for (int l = 0; l < 64; l++) {
             const u64 e = (u64)l * (2 * k1 + 1);
-            tw[TW_W1 + k1 * 64 + l] = pow_mod(PSI, e);
-            tw[TW_W1I + k1 * 64 + l] = gl::mul(pow_mod(PSI_INV, e), N_INV);
+            tw[TW_W1 + k1 * 64 + l] = f.pow(psi, e);
+            tw[TW_W1I + k1 * 64 + l] = f.mul(f.pow(psi_inv, e), n_inv);
         }
-    const u64 inv8 = pow_mod(8, gl::P - 2);
+    const u64 w64 = f.pow(psi, 32), w64i = f.pow(psi_inv, 32);
     for (int v = 0; v < 16; v++)
         for (int t = 0; t < 4; t++) {
-            tw[TW_W2 + v * 4 + t] = pow_mod(8, (u64)t * v);
-            tw[TW_W2I + v * 4 + t] = pow_mod(inv8, (u64)t * v);
+            tw[TW_W2 + v * 4 + t] = f.pow(w64, (u64)t * v);
+            tw[TW_W2I + v * 4 + t] = f.pow(w64i, (u64)t * v);
         }
     return tw;
+}
+
+std::vector<double> to_centred_doubles(const std::vector<u64> &v) {
+    std::vector<double> d(v.size());
+    for (size_t i = 0; i < v.size(); i++) d[i] = f49::to_f(v[i]);
+    return d;
 }
 
 bool params_supported(const bmi_params &P, std::string &why) {
@@ -162,7 +188,9 @@ bool params_supported(const bmi_params &P, std::string &why) {
     if (P.k != 1) { why = "only k = 1 has a HIP kernel in this build"; return false; }
     if (P.bs_levels != 3 || P.bs_base_log != 15) { why = "only (l, Bg) = (3, 2^15) has a HIP kernel in this build"; return false; }
     if (P.n == 0 || P.n > 639) { why = "n must be in [1, 639]"; return false; }
-    if (P.ks_levels * P.ks_base_log > 63 || P.ks_base_log > 7 || P.ks_levels == 0) { why = "unsupported keyswitch decomposition"; return false; }
+    if (P.q_bits != 0 && P.q_bits != 64 && P.q_bits != 49) { why = "q_bits must be 64 (2^64-2^32+1) or 49 (2^49-720895)"; return false; }
+    const uint32_t qb = P.q_bits == 49 ? 49 : 64;
+    if (P.ks_levels * P.ks_base_log >= qb || P.ks_base_log > 7 || P.ks_levels == 0) { why = "unsupported keyswitch decomposition"; return false; }
     return true;
 }
 
@@ -170,11 +198,14 @@ bool params_supported(const bmi_params &P, std::string &why) {
 
 extern "C" {
 
-int bmi_default_params(bmi_params *out) {
-    if (!out) return -1;
-    *out = bmi_params{630, 10, 1, 3, 15, 8, 4, 0, std::ldexp(1.0, -25), std::ldexp(1.0, -44)};
+int bmi_default_params_for(uint32_t q_bits, bmi_params *out) {
+    if (!out || (q_bits != 64 && q_bits != 49)) return -1;
+    // same shape for both fields; the 49-bit modulus keeps the absolute bootstrap-key noise above the integer grid
+    *out = bmi_params{630, 10, 1, 3, 15, 8, 4, q_bits, std::ldexp(1.0, -25), std::ldexp(1.0, q_bits == 49 ? -40 : -44)};
     return 0;
 }
+
+int bmi_default_params(bmi_params *out) { return bmi_default_params_for(BMI_DEFAULT_Q_BITS, out); }
 
 const char *bmi_last_error(const bmi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -190,6 +221,8 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
     if (device < 0 || device >= ndev) return fail(nullptr, -1, "bad device index");
     bmi_ctx *c = new bmi_ctx();
     c->P = *params;
+    if (c->P.q_bits == 0) c->P.q_bits = 64;
+    if (c->P.q_bits == 49) c->f = Fq{f49::Q, 49};
     c->device = device;
     c->N = 1u << params->log_N;
     c->big_n = params->k * c->N;
@@ -202,12 +235,18 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
     };
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice failed");
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
-    std::vector<u64> tw = build_twiddles();
-    if (hipMalloc(&c->d_tw, tw.size() * sizeof(u64)) != hipSuccess) return bail("hipMalloc(twiddles) failed");
-    if (hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess)
-        return bail("hipMemcpy(twiddles) failed");
+    {
+        const bool f64 = c->f64();
+        const std::vector<u64> tw = f64 ? build_twiddles(c->f, nttf::PSI_U, nttf::PSI_INV_U, nttf::N_INV_U)
+                                        : build_twiddles(c->f, nttw::PSI, nttw::PSI_INV, nttw::N_INV);
+        const std::vector<double> twd = f64 ? to_centred_doubles(tw) : std::vector<double>();
+        const void *src = f64 ? (const void *)twd.data() : (const void *)tw.data();
+        if (hipMalloc(&c->d_tw, tw.size() * 8) != hipSuccess) return bail("hipMalloc(twiddles) failed");
+        if (hipMemcpy(c->d_tw, src, tw.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+            return bail("hipMemcpy(twiddles) failed");
+    }
     c->lut_cap = 1024;
-    if (hipMalloc(&c->d_luts, (size_t)c->lut_cap * c->N * sizeof(u64)) != hipSuccess) return bail("hipMalloc(luts) failed");
+    if (hipMalloc(&c->d_luts, (size_t)c->lut_cap * c->N * 8) != hipSuccess) return bail("hipMalloc(luts) failed");
     *out = c;
     return 0;
 }
@@ -215,7 +254,7 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
 void bmi_ctx_destroy(bmi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (void *p : {(void *)c->d_bsk, (void *)c->d_ksk, (void *)c->d_ks_bias, (void *)c->d_tw, (void *)c->d_luts, (void *)c->d_small,
+    for (void *p : {c->d_bsk, (void *)c->d_ksk, (void *)c->d_ks_bias, c->d_tw, c->d_luts, (void *)c->d_small,
                     (void *)c->d_io_a, (void *)c->d_io_b, (void *)c->d_io_ids, c->d_ks_partial})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -238,14 +277,15 @@ int bmi_keygen(bmi_ctx *c, uint64_t seed) {
     c->sk_small.assign(n, 0);
     c->sk_big.assign((size_t)k * N, 0);
     {
-        Stream s1(seed, S_SK_SMALL), s2(seed, S_SK_BIG);
+        Stream s1(seed, S_SK_SMALL, c->f), s2(seed, S_SK_BIG, c->f);
         for (uint32_t i = 0; i < n; i++) c->sk_small[i] = s1.bit(i);
         for (uint32_t i = 0; i < k * N; i++) c->sk_big[i] = s2.bit(i);
     }
     // --- bootstrap key: GGSW(s_i) rows, standard domain.  B = sum_j A_j * S_j + E by shifted adds (S binary).
     c->bsk_std.assign((size_t)n * rows * (k + 1) * N, 0);
     {
-        Stream sm(seed, S_BSK_MASK), se(seed, S_BSK_NOISE);
+        Stream sm(seed, S_BSK_MASK, c->f), se(seed, S_BSK_NOISE, c->f);
+        const Fq f = c->f;
         const u64 *skb = c->sk_big.data();
         const u64 *sks = c->sk_small.data();
         u64 *bsk = c->bsk_std.data();
@@ -260,15 +300,16 @@ int bmi_keygen(bmi_ctx *c, uint64_t seed) {
                 u64 *A = row + (size_t)j * N;
                 for (uint32_t x = 0; x < N; x++) A[x] = sm.uniform(((u64)ir * (k + 1) + j) * N + x);
                 for (uint32_t t = 0; t < N; t++)
-                    if (skb[(size_t)j * N + t]) add_shifted(B, A, t, N);
+                    if (skb[(size_t)j * N + t]) add_shifted(f, B, A, t, N);
             }
-            if (sks[i]) row[(size_t)comp * N] = gl::add(row[(size_t)comp * N], (u64)1 << (64 - bl * (lev + 1)));
+            if (sks[i]) row[(size_t)comp * N] = f.add(row[(size_t)comp * N], (u64)1 << (f.bits - bl * (lev + 1)));
         });
     }
     // --- keyswitch key
     c->ksk.assign((size_t)k * N * lk * (n + 1), 0);
     {
-        Stream sm(seed, S_KSK_MASK), se(seed, S_KSK_NOISE);
+        Stream sm(seed, S_KSK_MASK, c->f), se(seed, S_KSK_NOISE, c->f);
+        const Fq f = c->f;
         const u64 *skb = c->sk_big.data();
         const u64 *sks = c->sk_small.data();
         u64 *ksk = c->ksk.data();
@@ -280,19 +321,20 @@ int bmi_keygen(bmi_ctx *c, uint64_t seed) {
             u64 b = se.gauss(jr, sigma);
             for (uint32_t x = 0; x < n; x++) {
                 row[x] = sm.uniform((u64)jr * (n + 1) + x);
-                if (sks[x]) b = gl::add(b, row[x]);
+                if (sks[x]) b = f.add(b, row[x]);
             }
-            if (skb[j]) b = gl::add(b, (u64)1 << (64 - bl * (lev + 1)));
+            if (skb[j]) b = f.add(b, (u64)1 << (f.bits - bl * (lev + 1)));
             row[n] = b;
         });
     }
     // --- upload: bootstrap key -> NTT domain on the GPU; keyswitch key with padded rows
     const size_t bsk_words = c->bsk_std.size();
-    if (!c->d_bsk) HIP_OK(c, hipMalloc(&c->d_bsk, bsk_words * sizeof(u64)));
+    if (!c->d_bsk) HIP_OK(c, hipMalloc(&c->d_bsk, bsk_words * 8));
     u64 *d_tmp = nullptr;
     HIP_OK(c, hipMalloc(&d_tmp, bsk_words * sizeof(u64)));
     HIP_OK(c, hipMemcpy(d_tmp, c->bsk_std.data(), bsk_words * sizeof(u64), hipMemcpyHostToDevice));
-    int rc = bmi::launch_bsk_to_ntt(d_tmp, c->d_bsk, c->d_tw, (uint32_t)(bsk_words / N), c->stream);
+    int rc = c->f64() ? bmi49::launch_bsk_to_ntt(d_tmp, (double *)c->d_bsk, (const double *)c->d_tw, (uint32_t)(bsk_words / N), c->stream)
+                      : bmi::launch_bsk_to_ntt(d_tmp, (u64 *)c->d_bsk, (const u64 *)c->d_tw, (uint32_t)(bsk_words / N), c->stream);
     if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_ntt launch failed"); }
     HIP_OK(c, hipStreamSynchronize(c->stream));
     HIP_OK(c, hipFree(d_tmp));
@@ -307,9 +349,9 @@ int bmi_keygen(bmi_ctx *c, uint64_t seed) {
         const u64 half = (u64)1 << (P.ks_base_log - 1);
         for (size_t r = 0; r < ksk_rows; r++) {
             const u64 *row = c->ksk.data() + r * (n + 1);
-            for (uint32_t x = 0; x <= n; x++) bias[x] = gl::add(bias[x], row[x]);
+            for (uint32_t x = 0; x <= n; x++) bias[x] = c->f.add(bias[x], row[x]);
         }
-        for (uint32_t x = 0; x <= n; x++) bias[x] = gl::mul(bias[x], half);
+        for (uint32_t x = 0; x <= n; x++) bias[x] = c->f.mul(bias[x], half);
         if (!c->d_ks_bias) HIP_OK(c, hipMalloc(&c->d_ks_bias, c->ks_stride * sizeof(u64)));
         HIP_OK(c, hipMemcpy(c->d_ks_bias, bias.data(), c->ks_stride * sizeof(u64), hipMemcpyHostToDevice));
     }
@@ -337,19 +379,20 @@ int bmi_key_bytes(const bmi_ctx *c, uint64_t *bsk_bytes, uint64_t *ksk_bytes) {
 int bmi_encrypt(bmi_ctx *c, const int64_t *msgs, uint32_t count, uint32_t delta_log, uint64_t *ct_out) {
     if (!c || !msgs || !ct_out) return -1;
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
-    if (delta_log > 62) return fail(c, -1, "delta_log out of range");
-    Stream sm(c->seed, S_ENC_MASK), se(c->seed, S_ENC_NOISE);
+    if (delta_log >= c->f.bits - 1) return fail(c, -1, "delta_log out of range");
+    Stream sm(c->seed, S_ENC_MASK, c->f), se(c->seed, S_ENC_NOISE, c->f);
+    const Fq f = c->f;
     const uint32_t dim = c->big_n;
     const u64 first = c->enc_counter;
     const u64 *key = c->sk_big.data();
     const double sigma = c->P.glwe_noise;
     parallel_for(count, [=](size_t i) {
         u64 *ct = ct_out + i * (dim + 1);
-        const u64 torus = gl::mul(gl::from_i64(msgs[i]), (u64)1 << delta_log);
-        u64 b = gl::add(torus, se.gauss(first + i, sigma));
+        const u64 torus = f.mul(f.from_i64(msgs[i]), (u64)1 << delta_log);
+        u64 b = f.add(torus, se.gauss(first + i, sigma));
         for (uint32_t x = 0; x < dim; x++) {
             ct[x] = sm.uniform((first + i) * (u64)(dim + 1) + x);
-            if (key[x]) b = gl::add(b, ct[x]);
+            if (key[x]) b = f.add(b, ct[x]);
         }
         ct[dim] = b;
     });
@@ -366,7 +409,7 @@ int bmi_phase(const bmi_ctx *c, const uint64_t *ct_in, uint32_t count, uint64_t 
         const u64 *ct = ct_in + (size_t)i * (dim + 1);
         u64 p = ct[dim];
         for (uint32_t x = 0; x < dim; x++)
-            if (key[x]) p = gl::sub(p, ct[x]);
+            if (key[x]) p = c->f.sub(p, ct[x]);
         phase[i] = p;
     }
     return 0;
@@ -374,12 +417,12 @@ int bmi_phase(const bmi_ctx *c, const uint64_t *ct_in, uint32_t count, uint64_t 
 
 int bmi_decrypt(const bmi_ctx *c, const uint64_t *ct_in, uint32_t count, uint32_t delta_log, int64_t *msgs) {
     if (!c || !ct_in || !msgs) return -1;
-    if (delta_log == 0 || delta_log > 62) return fail(c, -1, "delta_log out of range");
+    if (delta_log == 0 || delta_log >= c->f.bits - 1) return fail(c, -1, "delta_log out of range");
     std::vector<u64> ph(count);
     int rc = bmi_phase(c, ct_in, count, ph.data());
     if (rc) return rc;
     for (uint32_t i = 0; i < count; i++) {
-        const i64 v = gl::centered(ph[i]);
+        const i64 v = c->f.centered(ph[i]);
         msgs[i] = (v >> delta_log) + ((v >> (delta_log - 1)) & 1);
     }
     return 0;
@@ -389,7 +432,7 @@ int bmi_lut_register(bmi_ctx *c, const int64_t *table, uint32_t msg_bits, uint32
     if (!c || !table || !lut_id) return -1;
     const uint32_t N = c->N;
     if (msg_bits == 0 || (1u << msg_bits) * 2 > N) return fail(c, -1, "msg_bits out of range for N");
-    if (out_delta_log > 62) return fail(c, -1, "out_delta_log out of range");
+    if (out_delta_log >= c->f.bits - 1) return fail(c, -1, "out_delta_log out of range");
     if (c->n_luts == c->lut_cap) return fail(c, -1, "LUT table full");
     // Signed messages on the whole negacyclic circle: box width w = N / 2^p, boxes centred on m*w.
     const uint32_t M = 1u << msg_bits, Mh = M >> 1, w = N >> msg_bits, half = w >> 1;
@@ -401,11 +444,15 @@ int bmi_lut_register(bmi_ctx *c, const int64_t *table, uint32_t msg_bits, uint32
         if (box < Mh) { f = table[box + Mh]; negate = false; }        // m = box >= 0
         else if (box < M) { f = table[box - Mh]; negate = true; }      // m = box - M < 0, reached as -X^(j-N)
         else { f = table[Mh]; negate = true; }                         // m = 0 from below
-        const u64 v = gl::mul(gl::from_i64(f), (u64)1 << out_delta_log);
-        tv[j] = negate ? gl::neg(v) : v;
+        const u64 v = c->f.mul(c->f.from_i64(f), (u64)1 << out_delta_log);
+        tv[j] = negate ? c->f.neg(v) : v;
     }
     HIP_OK(c, hipSetDevice(c->device));
-    HIP_OK(c, hipMemcpy(c->d_luts + (size_t)c->n_luts * N, tv.data(), N * sizeof(u64), hipMemcpyHostToDevice));
+    {
+        const std::vector<double> tvd = c->f64() ? to_centred_doubles(tv) : std::vector<double>();
+        const void *src = c->f64() ? (const void *)tvd.data() : (const void *)tv.data();
+        HIP_OK(c, hipMemcpy((char *)c->d_luts + (size_t)c->n_luts * N * 8, src, N * 8, hipMemcpyHostToDevice));
+    }
     c->luts_host.push_back(std::move(tv));
     *lut_id = c->n_luts++;
     return 0;
@@ -448,8 +495,9 @@ int bmi_keyswitch_batch(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64
         HIP_OK(c, hipMalloc(&c->d_ks_partial, cap));
         c->ks_partial_bytes = cap;
     }
-    int rc = bmi::launch_keyswitch(d_in, c->d_ksk, c->d_ks_bias, d_small, slices > 1 ? c->d_ks_partial : nullptr, slices, count, c->P.n,
-                                   c->big_n, c->P.ks_levels, c->P.ks_base_log, c->ks_stride, (hipStream_t)stream);
+    int rc = (c->f64() ? bmi49::launch_keyswitch : bmi::launch_keyswitch)(
+        d_in, c->d_ksk, c->d_ks_bias, d_small, slices > 1 ? c->d_ks_partial : nullptr, slices, count, c->P.n, c->big_n,
+        c->P.ks_levels, c->P.ks_base_log, c->ks_stride, (hipStream_t)stream);
     return rc ? fail(c, -2, std::string("keyswitch launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
 }
 
@@ -461,10 +509,16 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     // variant 0 = auto: the latency kernel (one workgroup per ciphertext) while the batch cannot fill the chip
     // with one-wave-per-ciphertext work, the throughput kernel beyond that.
     const bool latency = c->variant == 2 || (c->variant == 0 && count <= c->lat_threshold);
-    int rc = latency ? bmi::launch_blind_rotate_lat(d_small, d_lut_ids, c->d_luts, c->d_bsk, c->d_tw, d_out, count, c->P.n,
-                                                    (hipStream_t)stream)
-                     : bmi::launch_blind_rotate_tp(d_small, d_lut_ids, c->d_luts, c->d_bsk, c->d_tw, d_out, count, c->P.n,
-                                                   (hipStream_t)stream);
+    int rc;
+    if (c->f64()) {
+        const double *luts = (const double *)c->d_luts, *bsk = (const double *)c->d_bsk, *tw = (const double *)c->d_tw;
+        rc = latency ? bmi49::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
+                     : bmi49::launch_blind_rotate_tp(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream);
+    } else {
+        const u64 *luts = (const u64 *)c->d_luts, *bsk = (const u64 *)c->d_bsk, *tw = (const u64 *)c->d_tw;
+        rc = latency ? bmi::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
+                     : bmi::launch_blind_rotate_tp(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream);
+    }
     return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
 }
 
@@ -483,8 +537,9 @@ int bmi_lincomb_batch(bmi_ctx *c, const uint64_t *d_store, const uint32_t *d_row
                       const int64_t *d_coef, const uint64_t *d_const_body, uint32_t count, uint64_t *d_out,
                       void *stream) {
     if (!c || (count && (!d_store || !d_row_ptr || !d_const_body || !d_out))) return -1;
-    int rc = bmi::launch_lincomb(d_store, d_row_ptr, d_idx, (const i64 *)d_coef, d_const_body, d_out, count, c->big_n + 1,
-                                 (hipStream_t)stream);
+    int rc = (c->f64() ? bmi49::launch_lincomb : bmi::launch_lincomb)(d_store, d_row_ptr, d_idx, (const i64 *)d_coef,
+                                                                      d_const_body, d_out, count, c->big_n + 1,
+                                                                      (hipStream_t)stream);
     return rc ? fail(c, -2, std::string("lincomb launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
 }
 
@@ -563,7 +618,8 @@ int bmi_negacyclic_mul_host(bmi_ctx *c, const uint64_t *a, const uint64_t *b, ui
     HIP_OK(c, hipMalloc(&dc, bytes));
     HIP_OK(c, hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
     HIP_OK(c, hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
-    int rc = bmi::launch_negacyclic_mul(da, db, dc, c->d_tw, count, c->stream);
+    int rc = c->f64() ? bmi49::launch_negacyclic_mul(da, db, dc, (const double *)c->d_tw, count, c->stream)
+                      : bmi::launch_negacyclic_mul(da, db, dc, (const u64 *)c->d_tw, count, c->stream);
     if (rc) return fail(c, -2, "negacyclic_mul launch failed");
     HIP_OK(c, hipStreamSynchronize(c->stream));
     HIP_OK(c, hipMemcpy(out, dc, bytes, hipMemcpyDeviceToHost));

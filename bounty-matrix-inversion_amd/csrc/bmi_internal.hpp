@@ -5,6 +5,10 @@
 
 #include "goldilocks.hpp"
 
+#ifndef BMI_DEFAULT_Q_BITS
+#define BMI_DEFAULT_Q_BITS 64  // modulus of bmi_default_params(): 64 (Goldilocks) or 49 (f64 kernels)
+#endif
+
 #ifndef BMI_TP_CTS
 #define BMI_TP_CTS 2  // ciphertexts (= wavefront pairs) per workgroup in the throughput blind rotation
 #endif
@@ -27,3 +31,20 @@ int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out
 int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *idx, const i64 *coef,
                    const u64 *const_body, u64 *out, uint32_t count, uint32_t width, hipStream_t s);
 }  // namespace bmi
+
+// The same launchers for the 49-bit field (bmi_kernels_f64.hip): NTT-domain key, twiddles and test polynomials are f64.
+namespace bmi49 {
+using gl::i64;
+using gl::u64;
+int launch_bsk_to_ntt(const u64 *std_polys, double *ntt_polys, const double *g_tw, uint32_t n_polys, hipStream_t s);
+int launch_negacyclic_mul(const u64 *a, const u64 *b, u64 *c, const double *g_tw, uint32_t count, hipStream_t s);
+int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
+                           const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s);
+int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
+                            const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s);
+int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
+                     uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,
+                     hipStream_t s);
+int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *idx, const i64 *coef,
+                   const u64 *const_body, u64 *out, uint32_t count, uint32_t width, hipStream_t s);
+}  // namespace bmi49

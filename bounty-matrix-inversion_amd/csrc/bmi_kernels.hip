@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bmi_internal.hpp"
+#include "ks_lincomb.hpp"
 #include "ntt_wave.hpp"
 
 using gl::u64;
@@ -296,52 +297,13 @@ __global__ void __launch_bounds__(LAT_THREADS)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Keyswitch: out = (0,...,0,b) - sum_j sum_lev dec_lev(a_j) * KSK[j][lev].  One workgroup handles KS_TILE
-// ciphertexts; thread t owns output columns t, t+256, t+512.  The signed digits d in [-B/2, B/2] are staged in
-// LDS as d + B/2 (unsigned), so the inner multiply-accumulate is unsigned: acc(96 bit) += d' * K is two
-// v_mad_u64_u32 and one add; the bias sum_rows (B/2) * K is a per-key constant (ks_bias, computed at keygen)
-// and is added back at the end:  -sum d K = bias - sum d' K.
-constexpr int KS_TILE = 8;
-constexpr int KS_THREADS = 256;
-constexpr int KS_COLS = 3;  // ceil(631 / 256)
-
-struct acc96 {
-    u64 lo;       // bits 0..63
-    uint32_t hi;  // bits 64..95
-};
-
-__device__ __forceinline__ void mac96(acc96 &a, uint32_t d, u64 k) {
-    // a += d * k, d < 2^8: (t1:t0) = d*k0 + a0 ; (u1:u0) = d*k1 + (a2:a1) + t1
-    const u64 t = (u64)d * gl::lo32(k) + gl::lo32(a.lo);
-    const u64 u = (u64)d * gl::hi32(k) + gl::mk64(gl::hi32(a.lo), a.hi) + gl::hi32(t);
-    a.lo = gl::mk64(gl::lo32(t), gl::lo32(u));
-    a.hi = gl::hi32(u);
-}
-
-// SPLIT = false: one workgroup walks all rows and writes the finished small ciphertexts (throughput form).
-// SPLIT = true : blockIdx.y selects a slice of the coefficients; the workgroup writes its 96-bit partial sums
-//                and k_keyswitch_reduce finishes (latency form for small batches: the row walk is the latency).
-template <bool SPLIT>
-__global__ void __launch_bounds__(KS_THREADS)
-    k_keyswitch(const u64 *__restrict__ in, const u64 *__restrict__ ksk, const u64 *__restrict__ ks_bias,
-                u64 *__restrict__ out, unsigned __int128 *__restrict__ partial, uint32_t count, uint32_t n,
-                uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride, uint32_t coefs_per_slice) {
-    extern __shared__ unsigned char digits[];  // [KS_TILE][slice coefficients * levels], value d + B/2
-    const uint32_t first = blockIdx.x * KS_TILE;
-    const uint32_t tile = min((uint32_t)KS_TILE, count - first);
-    const uint32_t j0 = SPLIT ? blockIdx.y * coefs_per_slice : 0;
-    const uint32_t nj = SPLIT ? min(coefs_per_slice, big_n - j0) : big_n;
-    const uint32_t rows = nj * levels;
-    const uint32_t shift = 64 - levels * base_log;
-    const i64 B = (i64)1 << base_log, half = B >> 1;
-    for (uint32_t idx = threadIdx.x; idx < KS_TILE * nj; idx += KS_THREADS) {
-        const uint32_t b = idx / nj, j = idx % nj;
-        unsigned char *d = digits + (size_t)b * rows + (size_t)j * levels;
-        if (b >= tile) {  // unused slots of a ragged last tile: digit value 0 -> stored bias only (result discarded)
-            for (uint32_t lev = 0; lev < levels; lev++) d[lev] = (unsigned char)half;
-            continue;
-        }
-        const i64 c = gl::centered(in[(size_t)(first + b) * (big_n + 1) + j0 + j]);
+// Keyswitch and lincomb live in ks_lincomb.hpp (shared with the 49-bit field); the Goldilocks policy:
+struct FieldG {
+    static __device__ __forceinline__ void digits(u64 a, uint32_t levels, uint32_t base_log, unsigned char *d) {
+        // centred lift, round half up to the top levels*base_log bits, signed digits in [-B/2, B/2), top absorbs the carry
+        const uint32_t shift = 64 - levels * base_log;
+        const i64 B = (i64)1 << base_log, half = B >> 1;
+        const i64 c = gl::centered(a);
         i64 r = (c >> shift) + ((c >> (shift - 1)) & 1);
         for (int lev = (int)levels - 1; lev >= 1; lev--) {
             i64 v = r & (B - 1);
@@ -351,85 +313,13 @@ __global__ void __launch_bounds__(KS_THREADS)
         }
         d[0] = (unsigned char)(r + half);
     }
-    __syncthreads();
-
-    acc96 acc[KS_TILE][KS_COLS];
-#pragma unroll
-    for (int b = 0; b < KS_TILE; b++)
-#pragma unroll
-        for (int cc = 0; cc < KS_COLS; cc++) acc[b][cc] = acc96{0, 0};
-    bool col_ok[KS_COLS];
-#pragma unroll
-    for (int cc = 0; cc < KS_COLS; cc++) col_ok[cc] = threadIdx.x + cc * KS_THREADS <= n;
-
-    const u64 *kbase = ksk + (size_t)j0 * levels * ks_stride;
-#pragma unroll 2
-    for (uint32_t r = 0; r < rows; r++) {
-        const u64 *krow = kbase + (size_t)r * ks_stride;
-        u64 kv[KS_COLS];
-#pragma unroll
-        for (int cc = 0; cc < KS_COLS; cc++) kv[cc] = col_ok[cc] ? krow[threadIdx.x + cc * KS_THREADS] : 0;
-#pragma unroll
-        for (int b = 0; b < KS_TILE; b++) {
-            const uint32_t d = digits[(size_t)b * rows + r];
-#pragma unroll
-            for (int cc = 0; cc < KS_COLS; cc++) mac96(acc[b][cc], d, kv[cc]);
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < KS_TILE; b++) {
-        if (b >= (int)tile) break;
-#pragma unroll
-        for (int cc = 0; cc < KS_COLS; cc++) {
-            const uint32_t col = threadIdx.x + cc * KS_THREADS;
-            if (col > n) continue;
-            if constexpr (SPLIT) {
-                partial[((size_t)blockIdx.y * count + first + b) * ks_stride + col] =
-                    ((unsigned __int128)acc[b][cc].hi << 64) | acc[b][cc].lo;
-            } else {
-                u64 v = gl::sub(ks_bias[col], gl::reduce96(acc[b][cc].hi, acc[b][cc].lo));
-                if (col == n) v = gl::add(v, in[(size_t)(first + b) * (big_n + 1) + big_n]);
-                out[(size_t)(first + b) * (n + 1) + col] = v;
-            }
-        }
-    }
-}
-
-__global__ void __launch_bounds__(256)
-    k_keyswitch_reduce(const u64 *__restrict__ in, const unsigned __int128 *__restrict__ partial,
-                       const u64 *__restrict__ ks_bias, u64 *__restrict__ out, uint32_t count, uint32_t n,
-                       uint32_t big_n, uint32_t ks_stride, uint32_t slices) {
-    const uint32_t ct = blockIdx.x;
-    for (uint32_t col = threadIdx.x; col <= n; col += blockDim.x) {
-        unsigned __int128 a = 0;  // <= 64 slices of < 2^81
-        for (uint32_t s = 0; s < slices; s++) a += partial[((size_t)s * count + ct) * ks_stride + col];
-        u64 v = gl::sub(ks_bias[col], gl::reduce128((u64)(a >> 64), (u64)a));
-        if (col == n) v = gl::add(v, in[(size_t)ct * (big_n + 1) + big_n]);
-        out[(size_t)ct * (n + 1) + col] = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-    k_lincomb(const u64 *__restrict__ store, const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ idx,
-              const i64 *__restrict__ coef, const u64 *__restrict__ const_body, u64 *__restrict__ out, uint32_t width) {
-    const uint32_t row = blockIdx.x;
-    const uint32_t e0 = row_ptr[row], e1 = row_ptr[row + 1];
-    for (uint32_t x = threadIdx.x; x < width; x += blockDim.x) {
-        u64 acc = 0;
-        for (uint32_t e = e0; e < e1; e++) {
-            const i64 cf = coef[e];
-            const u64 s = store[(size_t)idx[e] * width + x];
-            u64 term;
-            if (cf == 1) term = s;
-            else if (cf == -1) term = gl::neg(s);
-            else term = gl::mul(gl::from_i64(cf), s);
-            acc = gl::add(acc, term);
-        }
-        if (x == width - 1) acc = gl::add(acc, const_body[row]);
-        out[(size_t)row * width + x] = acc;
-    }
-}
+    static __device__ __forceinline__ u64 add(u64 a, u64 b) { return gl::add(a, b); }
+    static __device__ __forceinline__ u64 sub(u64 a, u64 b) { return gl::sub(a, b); }
+    static __device__ __forceinline__ u64 neg(u64 a) { return gl::neg(a); }
+    static __device__ __forceinline__ u64 mul_small(i64 cf, u64 v) { return gl::mul(gl::from_i64(cf), v); }
+    static __device__ __forceinline__ u64 reduce96(uint32_t hi, u64 lo) { return gl::reduce96(hi, lo); }
+    static __device__ __forceinline__ u64 reduce128(u64 hi, u64 lo) { return gl::reduce128(hi, lo); }
+};
 
 }  // namespace
 
@@ -484,32 +374,13 @@ int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const
 int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
                      uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,
                      hipStream_t s) {
-    if (count == 0) return 0;
-    const dim3 tiles((count + KS_TILE - 1) / KS_TILE);
-    if (slices <= 1 || partial == nullptr) {
-        const size_t lds = (size_t)KS_TILE * big_n * levels;
-        hipLaunchKernelGGL(k_keyswitch<false>, tiles, dim3(KS_THREADS), lds, s, in, ksk, ks_bias, out,
-                           (unsigned __int128 *)nullptr, count, n, big_n, levels, base_log, ks_stride, big_n);
-        BMI_LAUNCH_CHECK();
-        return 0;
-    }
-    const uint32_t per = (big_n + slices - 1) / slices;
-    const size_t lds = (size_t)KS_TILE * per * levels;
-    hipLaunchKernelGGL(k_keyswitch<true>, dim3(tiles.x, slices), dim3(KS_THREADS), lds, s, in, ksk, ks_bias, out,
-                       (unsigned __int128 *)partial, count, n, big_n, levels, base_log, ks_stride, per);
-    BMI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_keyswitch_reduce, dim3(count), dim3(256), 0, s, in, (const unsigned __int128 *)partial, ks_bias,
-                       out, count, n, big_n, ks_stride, slices);
-    BMI_LAUNCH_CHECK();
-    return 0;
+    return ksl::launch_keyswitch<FieldG>(in, ksk, ks_bias, out, partial, slices, count, n, big_n, levels, base_log,
+                                         ks_stride, s);
 }
 
 int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *idx, const i64 *coef,
                    const u64 *const_body, u64 *out, uint32_t count, uint32_t width, hipStream_t s) {
-    if (count == 0) return 0;
-    hipLaunchKernelGGL(k_lincomb, dim3(count), dim3(256), 0, s, store, row_ptr, idx, coef, const_body, out, width);
-    BMI_LAUNCH_CHECK();
-    return 0;
+    return ksl::launch_lincomb<FieldG>(store, row_ptr, idx, coef, const_body, out, count, width, s);
 }
 
 }  // namespace bmi

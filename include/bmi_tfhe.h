@@ -18,9 +18,11 @@
  *   - every function returns 0 on success, <0 on error; bmi_last_error() gives the text.
  *   - plain pointers and sizes only.  Pointers named d_* are DEVICE pointers (HIP), all
  *     others are host pointers.  `stream` is a hipStream_t passed as void* (NULL = default stream).
- *   - ciphertext modulus q = 2^64 - 2^32 + 1; words are canonical (< q).
+ *   - ciphertext modulus q (bmi_params.q_bits): 2^64 - 2^32 + 1 or 2^49 - 720895; words are canonical (< q) 64-bit
+ *     integers at this boundary for both.
  *   - a "big" LWE ciphertext has k*N+1 words (mask, then body); a "small" one n+1 words.
- *   - messages are signed integers m encoded as m * 2^delta_log (mod q).
+ *   - messages are signed integers m encoded as m * 2^delta_log (mod q); a p-bit signed message space uses
+ *     delta_log = q_bits - 1 - p (59 resp. 44 for p = 4).
  *   - a context is single-caller (no internal locking); work on a stream is asynchronous
  *     until bmi_sync() or a call that returns data to the host.
  */
@@ -43,13 +45,16 @@ typedef struct {
     uint32_t bs_base_log; /* bootstrap decomposition base log (15) */
     uint32_t ks_levels;   /* keyswitch levels (8) */
     uint32_t ks_base_log; /* keyswitch base log (4) */
-    uint32_t reserved;
+    uint32_t q_bits;      /* ciphertext modulus: 64 -> q = 2^64 - 2^32 + 1 (Goldilocks, integer kernels);
+                             49 -> q = 2^49 - 720895 (exact integers carried in f64: ~2x faster kernels); 0 = 64 */
     double lwe_noise;     /* std-dev / q of keyswitch-key encryptions */
     double glwe_noise;    /* std-dev / q of bootstrap-key rows and fresh big-key encryptions */
 } bmi_params;
 
-/* The north-star parameter set of BASELINE.json (n=630, N=1024, k=1, l=3). */
+/* The north-star parameter set of BASELINE.json (n=630, N=1024, k=1, l=3) with the build's default modulus. */
 int bmi_default_params(bmi_params *out);
+/* ... and with an explicit choice of the ciphertext modulus (q_bits = 64 or 49). */
+int bmi_default_params_for(uint32_t q_bits, bmi_params *out);
 
 /* replaces fhe.Compiler(...).compile(...) (main.py:53-66): fixes the crypto parameters, binds a GPU. */
 int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out);
@@ -76,7 +81,7 @@ int bmi_phase(const bmi_ctx *ctx, const uint64_t *ct_in, uint32_t count, uint64_
 /* replaces a table look-up definition (fhe.univariate, base_p_arrays.py:365, and every non-linear
  * Tracer operator).  table[m + 2^(msg_bits-1)] = f(m) for signed m in [-2^(msg_bits-1), 2^(msg_bits-1));
  * the looked-up value is returned encoded as f(m) * 2^out_delta_log.  The input ciphertext of a PBS
- * using this LUT must encode m * 2^(63-msg_bits).  Returns the id used by the batch calls. */
+ * using this LUT must encode m * 2^(q_bits-1-msg_bits).  Returns the id used by the batch calls. */
 int bmi_lut_register(bmi_ctx *ctx, const int64_t *table, uint32_t msg_bits, uint32_t out_delta_log, uint32_t *lut_id);
 /* the N-coefficient test polynomial built for a LUT (host copy; test hook) */
 int bmi_lut_get(const bmi_ctx *ctx, uint32_t lut_id, uint64_t *test_vector);

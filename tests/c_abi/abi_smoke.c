@@ -33,20 +33,21 @@ int main(void) {
     const uint32_t big = P.k * (1u << P.log_N) + 1;
     int64_t msgs[5] = {-8, -1, 0, 3, 7};
     uint64_t *ct = (uint64_t *)malloc(5 * big * 8), *out = (uint64_t *)malloc(5 * big * 8);
-    CHECK(bmi_encrypt(ctx, msgs, 5, 59, ct) < 0, "encrypt before keygen fails");
+    const uint32_t DL = (P.q_bits == 49 ? 49 : 64) - 1 - 4; /* scaling exponent of a 4-bit signed message space */
+    CHECK(bmi_encrypt(ctx, msgs, 5, DL, ct) < 0, "encrypt before keygen fails");
     CHECK(strstr(bmi_last_error(ctx), "keygen") != NULL, "error text mentions keygen");
     CHECK(bmi_keygen(ctx, 0x5EED) == 0, "keygen");
 
     int64_t table[16];
     for (int m = -8; m < 8; m++) table[m + 8] = (m * m) % 16 - 8;
     uint32_t lut = 0, ids[5];
-    CHECK(bmi_lut_register(ctx, table, 9, 59, &lut) < 0, "msg_bits too large rejected");
-    CHECK(bmi_lut_register(ctx, table, 4, 59, &lut) == 0, "lut registered");
+    CHECK(bmi_lut_register(ctx, table, 9, DL, &lut) < 0, "msg_bits too large rejected");
+    CHECK(bmi_lut_register(ctx, table, 4, DL, &lut) == 0, "lut registered");
     for (int i = 0; i < 5; i++) ids[i] = lut;
-    CHECK(bmi_encrypt(ctx, msgs, 5, 59, ct) == 0, "encrypt");
+    CHECK(bmi_encrypt(ctx, msgs, 5, DL, ct) == 0, "encrypt");
     CHECK(bmi_pbs_batch_host(ctx, ct, ids, 5, out) == 0, "pbs batch");
     int64_t dec[5];
-    CHECK(bmi_decrypt(ctx, out, 5, 59, dec) == 0, "decrypt");
+    CHECK(bmi_decrypt(ctx, out, 5, DL, dec) == 0, "decrypt");
     for (int i = 0; i < 5; i++) CHECK(dec[i] == table[msgs[i] + 8], "LUT value");
     CHECK(bmi_pbs_batch_host(ctx, ct, ids, 0, out) == 0, "empty batch is a no-op");
     uint64_t bsk_b = 0, ksk_b = 0;

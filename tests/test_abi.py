@@ -29,13 +29,14 @@ def test_library_exports_every_declared_symbol():
 
 def test_default_params_are_the_north_star_set():
     from bmi_amd import tfhe
-    P = tfhe.default_params()
-    assert (P.n, P.N, P.k, P.bs_levels) == (630, 1024, 1, 3)
-    # same numbers as the oracle's default set
     from oracle import tfhe_oracle as to
-    O = to.default_params()
-    for f, _ in tfhe.Params._fields_:
-        assert getattr(P, f) == getattr(O, f), f
+    for qb in (64, 49):
+        P = tfhe.default_params(q_bits=qb)
+        assert (P.n, P.N, P.k, P.bs_levels, P.q_bits) == (630, 1024, 1, 3, qb)
+        O = to.default_params(q_bits=qb)  # same numbers as the oracle's default set
+        for f, _ in tfhe.Params._fields_:
+            assert getattr(P, f) == getattr(O, f), f
+    assert tfhe.default_params().q_bits in (64, 49)
 
 
 def test_no_gpu_means_loud_failure():

@@ -16,10 +16,10 @@ def load(name):
         return json.load(f)
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=[64, 49], ids=["goldilocks64", "p49_f64"])
+def eng(request):
     from bmi_amd import tfhe
-    e = tfhe.Engine()
+    e = tfhe.Engine(tfhe.default_params(q_bits=request.param))
     e.keygen(0x5EED)
     yield e
     e.close()
@@ -27,7 +27,8 @@ def eng():
 
 def test_encrypted_qfloat_ops_on_gpu(eng):
     """a + b, a * b, a > b on encrypted QFloats (pattern of tests/test_qfloat_fhe.py:186-246, exact digits)."""
-    from bmi_amd.circuit import Circuit, DELTA_LOG
+    from bmi_amd.circuit import Circuit
+    DELTA_LOG = eng.delta_log()
     from bmi_amd.executor import Executor
     from bmi_amd.qfloat import QFloat
     c = load("qfloat_ops.json")["pairs"]
@@ -91,6 +92,8 @@ def test_encrypted_3x3_inverse_matches_reference_golden(eng):
 
 
 def test_encrypted_4x4_inverse_matches_reference_golden(eng):
+    if eng.q_bits == 64:
+        pytest.skip("config 4 is run once, on the faster field (the 64-bit field covers configs 2 and 3)")
     """BASELINE config 4 (4x4, len 40, ints 16) on ONE MI355X: 323 k PBS, depth 1,858.  (BASELINE shards this
     config's PBS over 8 GPUs; the inverse's levels are narrower than one GPU's latency-kernel capacity, so a
     single GPU is the faster placement - DESIGN.md §6.)"""

@@ -6,19 +6,22 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-Q = 0xFFFFFFFF00000001
 SEED = 0x5EED
 
 
-def rand_q(rng, shape):
-    v = rng.integers(0, 2**63, shape, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, shape, dtype=np.uint64)
-    return np.where(v >= np.uint64(Q), v - np.uint64(Q), v)
+def rand_q(rng, shape, Q):
+    """uniform canonical words of Z_q (top values included)"""
+    if Q >> 63:
+        v = rng.integers(0, 2**63, shape, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, shape, dtype=np.uint64)
+        return np.where(v >= np.uint64(Q), v - np.uint64(Q), v)
+    return rng.integers(0, Q, shape, dtype=np.uint64)
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=[64, 49], ids=["goldilocks64", "p49_f64"])
+def eng(request):
+    """both ciphertext fields: q = 2^64 - 2^32 + 1 (integer kernels) and q = 2^49 - 720895 (f64 kernels)"""
     from bmi_amd import tfhe
-    e = tfhe.Engine()
+    e = tfhe.Engine(tfhe.default_params(q_bits=request.param))
     e.keygen(SEED)
     yield e
     e.close()
@@ -28,15 +31,24 @@ def eng():
 def ora(eng):
     from oracle import tfhe_oracle as to
     sk_small, sk_big, bsk, ksk = eng.export_keys()
-    P = to.default_params()
-    ctx = to.Ctx(P, bsk, ksk)
+    P = to.default_params(q_bits=eng.q_bits)
+    assert P.glwe_noise == eng.P.glwe_noise and P.lwe_noise == eng.P.lwe_noise
+    ctx = to.Ctx(P, bsk, ksk)   # selects the oracle's field
     return to, P, ctx, sk_small, sk_big, bsk, ksk
+
+
+@pytest.fixture(autouse=True)
+def _select_oracle_field(eng):
+    from oracle import tfhe_oracle as to
+    to.set_field(eng.q_bits)
+    yield
 
 
 def test_negacyclic_product_matches_oracle(eng, ora):
     to = ora[0]
     rng = np.random.default_rng(1)
-    a, b = rand_q(rng, (9, 1024)), rand_q(rng, (9, 1024))
+    Q = eng.modulus
+    a, b = rand_q(rng, (9, 1024), Q), rand_q(rng, (9, 1024), Q)
     # edge rows: zeros, ones, X^(N-1) * X = -1, max values
     a[0] = 0
     a[1] = 1
@@ -62,27 +74,28 @@ def test_keygen_matches_oracle_keygen(eng, ora):
 def test_encrypt_decrypt_roundtrip_and_oracle_phase(eng, ora):
     to, P, _, _, sk_big, _, _ = ora
     msgs = np.arange(-8, 8)
-    ct = eng.encrypt(msgs, 59)
-    assert list(eng.decrypt(ct, 59)) == list(msgs)
+    ct = eng.encrypt(msgs, eng.delta_log())
+    assert list(eng.decrypt(ct, eng.delta_log())) == list(msgs)
     assert np.array_equal(eng.phase(ct), to.lwe_phase(sk_big, ct))
-    assert list(to.decode(to.lwe_phase(sk_big, ct), 59)) == list(msgs)
+    assert list(to.decode(to.lwe_phase(sk_big, ct), eng.delta_log())) == list(msgs)
 
 
 def test_lut_test_vector_matches_oracle(eng, ora):
     to = ora[0]
     rng = np.random.default_rng(3)
-    for p in (1, 2, 3, 4, 6):
+    for p in (1, 2, 3, 4, 6):  # 6 bits: only the test-polynomial construction is compared
         table = rng.integers(-(1 << (p - 1)), 1 << (p - 1), 1 << p)
-        lid = eng.lut_register(table, p, 63 - p)
-        assert np.array_equal(eng.lut_get(lid), to.make_test_vector(10, p, table, 63 - p))
+        lid = eng.lut_register(table, p, eng.q_bits - 1 - p)
+        assert np.array_equal(eng.lut_get(lid), to.make_test_vector(10, p, table, eng.q_bits - 1 - p))
 
 
 def test_keyswitch_bit_exact(eng, ora):
     to, P, ctx, sk_small, _, _, _ = ora
     rng = np.random.default_rng(4)
     msgs = rng.integers(-8, 8, 19)  # not a multiple of the kernel tile: exercises the ragged tail
-    ct = eng.encrypt(msgs, 59)
-    ct[3, :1024] = rand_q(rng, 1024)        # arbitrary masks are valid inputs too
+    ct = eng.encrypt(msgs, eng.delta_log())
+    Q = eng.modulus
+    ct[3, :1024] = rand_q(rng, 1024, Q)     # arbitrary masks are valid inputs too
     ct[4, :1024] = Q - 1                    # extreme words
     ct[5, :1024] = Q // 2
     ct[6, :1024] = Q // 2 + 1
@@ -91,23 +104,23 @@ def test_keyswitch_bit_exact(eng, ora):
     want = ctx.keyswitch(ct)
     assert np.array_equal(got, want)
     ok = [0, 1, 2] + list(range(8, 19))
-    assert list(to.decode(to.lwe_phase(sk_small, got[ok]), 59)) == list(msgs[ok])
+    assert list(to.decode(to.lwe_phase(sk_small, got[ok]), eng.delta_log())) == list(msgs[ok])
 
 
 def test_blind_rotate_bit_exact(eng, ora):
     to, P, ctx, _, sk_big, _, _ = ora
     rng = np.random.default_rng(5)
     tables = [np.arange(-8, 8), rng.integers(-8, 8, 16)]
-    ids = [eng.lut_register(t, 4, 59) for t in tables]
+    ids = [eng.lut_register(t, 4, eng.delta_log()) for t in tables]
     tvs = np.stack([eng.lut_get(i) for i in ids])
     msgs = rng.integers(-8, 8, 6)
-    small = ctx.keyswitch(eng.encrypt(msgs, 59))
-    small = np.concatenate([small, rand_q(rng, (1, 631)), np.zeros((1, 631), np.uint64)])  # random + all-zero ciphertexts
+    small = ctx.keyswitch(eng.encrypt(msgs, eng.delta_log()))
+    small = np.concatenate([small, rand_q(rng, (1, 631), eng.modulus), np.zeros((1, 631), np.uint64)])  # random + all-zero ciphertexts
     sel = np.array([0, 1, 0, 1, 0, 1, 1, 0], np.uint32)
     got = eng.blind_rotate_host(small, np.array(ids, np.uint32)[sel])
     want = ctx.blind_rotate(small, tvs, sel)
     assert np.array_equal(got, want)
-    dec = to.decode(to.lwe_phase(sk_big, got[:6]), 59)
+    dec = to.decode(to.lwe_phase(sk_big, got[:6]), eng.delta_log())
     assert list(dec) == [int(tables[s][m + 8]) for s, m in zip(sel[:6], msgs)]
 
 
@@ -116,20 +129,20 @@ def test_pbs_bit_exact_and_evaluates_every_entry(eng, ora):
     rng = np.random.default_rng(6)
     table = rng.integers(-8, 8, 16)
     sq = np.array([(m * m) // 4 % 8 for m in range(-8, 8)])
-    ids = [eng.lut_register(table, 4, 59), eng.lut_register(sq, 4, 59)]
+    ids = [eng.lut_register(table, 4, eng.delta_log()), eng.lut_register(sq, 4, eng.delta_log())]
     tvs = np.stack([eng.lut_get(i) for i in ids])
     msgs = np.concatenate([np.arange(-8, 8), np.arange(-8, 8)])
     sel = np.array([0] * 16 + [1] * 16, np.uint32)
-    ct = eng.encrypt(msgs, 59)
+    ct = eng.encrypt(msgs, eng.delta_log())
     got = eng.pbs_host(ct, np.array(ids, np.uint32)[sel])
     want = ctx.pbs(ct, tvs, sel)
     assert np.array_equal(got, want)
-    dec = eng.decrypt(got, 59)
+    dec = eng.decrypt(got, eng.delta_log())
     assert list(dec[:16]) == list(table) and list(dec[16:]) == list(sq)
     # a second bootstrap of the outputs (noise stays bounded; still bit-exact)
     got2 = eng.pbs_host(got, np.array([ids[1]] * 32, np.uint32))
     assert np.array_equal(got2, ctx.pbs(got, tvs, np.ones(32, np.uint32)))
-    assert list(eng.decrypt(got2, 59)) == [int(sq[m + 8]) for m in dec]
+    assert list(eng.decrypt(got2, eng.delta_log())) == [int(sq[m + 8]) for m in dec]
 
 
 def test_small_message_space_luts(eng):
@@ -138,21 +151,21 @@ def test_small_message_space_luts(eng):
         M = 1 << p
         msgs = np.arange(-M // 2, M // 2)
         table = (msgs * 3 + 1) % M - M // 2
-        lid = eng.lut_register(table, p, 59)
-        ct = eng.encrypt(msgs, 63 - p)
+        lid = eng.lut_register(table, p, eng.delta_log())
+        ct = eng.encrypt(msgs, eng.q_bits - 1 - p)
         out = eng.pbs_host(ct, np.full(M, lid, np.uint32))
-        assert list(eng.decrypt(out, 59)) == list(table)
+        assert list(eng.decrypt(out, eng.delta_log())) == list(table)
 
 
 def test_lincomb_device_matches_oracle(eng, ora):
     import torch
     to, P, _, _, sk_big, _, _ = ora
     msgs = np.array([1, -2, 3, 0, 2])
-    ct = eng.encrypt(msgs, 59)
+    ct = eng.encrypt(msgs, eng.delta_log())
     row_ptr = np.array([0, 2, 5, 5, 8], np.uint32)
     idx = np.array([0, 1, 2, 3, 0, 4, 4, 1], np.uint32)
     coef = np.array([2, -1, 1, 1, -1, 3, -7, 1], np.int64)
-    consts = to.encode([1, 0, -4, 0], 59)
+    consts = to.encode([1, 0, -4, 0], eng.delta_log())
     want = to.lincomb(P.big, ct, row_ptr, idx, coef, consts)
     dev = torch.device("cuda:0")
     d = lambda a, dt: torch.from_numpy(a.view(dt) if a.dtype != dt else a).to(dev)
@@ -167,7 +180,7 @@ def test_lincomb_device_matches_oracle(eng, ora):
     torch.cuda.synchronize()
     got = d_out.cpu().numpy().view(np.uint64)
     assert np.array_equal(got, want)
-    assert list(eng.decrypt(got, 59)) == [5, 2, -4, -10]
+    assert list(eng.decrypt(got, eng.delta_log())) == [5, 2, -4, -10]
 
 
 def test_pbs_device_pointers_and_noise_budget(eng, ora):
@@ -177,8 +190,8 @@ def test_pbs_device_pointers_and_noise_budget(eng, ora):
     rng = np.random.default_rng(8)
     B = 300  # spans several workgroups, ragged last group
     msgs = rng.integers(-8, 8, B)
-    ident = eng.lut_register(np.arange(-8, 8), 4, 59)
-    ct = eng.encrypt(msgs, 59)
+    ident = eng.lut_register(np.arange(-8, 8), 4, eng.delta_log())
+    ct = eng.encrypt(msgs, eng.delta_log())
     dev = torch.device("cuda:0")
     d_in = torch.from_numpy(ct.view(np.int64)).to(dev)
     d_ids = torch.full((B,), ident, dtype=torch.int32, device=dev)
@@ -187,11 +200,12 @@ def test_pbs_device_pointers_and_noise_budget(eng, ora):
     eng.pbs(d_in, d_ids, B, d_out, s)
     torch.cuda.synchronize()
     out = d_out.cpu().numpy().view(np.uint64)
-    assert list(eng.decrypt(out, 59)) == list(msgs)
+    assert list(eng.decrypt(out, eng.delta_log())) == list(msgs)
     # spot-check bit-exactness on a sample (oracle is ~30 ms per PBS per core)
     pick = rng.choice(B, 12, replace=False)
     tv = eng.lut_get(ident)[None, :]
     assert np.array_equal(out[pick], ctx.pbs(ct[pick], tv, np.zeros(12, np.uint32)))
     ph = eng.phase(out)
-    err = np.array([((int(x) - (int(m) << 59)) + Q // 2) % Q - Q // 2 for x, m in zip(ph, msgs)], dtype=np.float64)
-    assert np.max(np.abs(err)) < 2.0 ** 50  # half a box is 2^58
+    Q, dl = eng.modulus, eng.delta_log()
+    err = np.array([((int(x) - (int(m) << dl)) + Q // 2) % Q - Q // 2 for x, m in zip(ph, msgs)], dtype=np.float64)
+    assert np.max(np.abs(err)) < 2.0 ** (dl - 9)  # half a box is 2^(dl-1)

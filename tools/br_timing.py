@@ -10,16 +10,18 @@ from oracle import tfhe_oracle as to
 def main():
     batches = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,64,4096").split(",")]
     variants = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1").split(",")]
-    eng = tfhe.Engine(); eng.keygen(0x5EED)
+    qb = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    eng = tfhe.Engine(tfhe.default_params(q_bits=qb)); eng.keygen(0x5EED)
+    DL = eng.delta_log()
     sk_small, sk_big, bsk, ksk = eng.export_keys()
-    octx = to.Ctx(to.default_params(), bsk, ksk)
-    lid = eng.lut_register(np.random.default_rng(9).integers(-8, 8, 16), 4, 59)
+    octx = to.Ctx(to.default_params(q_bits=eng.q_bits), bsk, ksk)
+    lid = eng.lut_register(np.random.default_rng(9).integers(-8, 8, 16), 4, DL)
     tv = eng.lut_get(lid)[None, :]
     dev = torch.device("cuda:0")
     s = torch.cuda.current_stream().cuda_stream
     for B in batches:
         msgs = np.random.default_rng(B).integers(-8, 8, B)
-        ct = eng.encrypt(msgs, 59)
+        ct = eng.encrypt(msgs, DL)
         small = eng.keyswitch_host(ct)
         d_small = torch.from_numpy(small.view(np.int64)).to(dev)
         d_ids = torch.full((B,), lid, dtype=torch.int32, device=dev)
@@ -42,6 +44,6 @@ def main():
             for _ in range(reps): eng.keyswitch(d_in, B, d_ks, s)
             e1.record(); torch.cuda.synchronize()
             ks = e0.elapsed_time(e1) / reps
-            print(json.dumps({"B": B, "variant": v, "br_ms": round(ms, 3), "ks_ms": round(ks, 3), "pbs_per_s": round(B / ((ms + ks) * 1e-3), 1), "bit_exact": bool(ok)}), flush=True)
+            print(json.dumps({"B": B, "variant": v, "br_ms": round(ms, 3), "ks_ms": round(ks, 3), "pbs_per_s": round(B / ((ms + ks) * 1e-3), 1), "bit_exact": bool(ok), "q_bits": eng.q_bits}), flush=True)
 
 main()
