@@ -6,7 +6,7 @@
 #include "goldilocks.hpp"
 
 #ifndef BMI_DEFAULT_Q_BITS
-#define BMI_DEFAULT_Q_BITS 64  // modulus of bmi_default_params(): 64 (Goldilocks) or 49 (f64 kernels)
+#define BMI_DEFAULT_Q_BITS 49  // modulus of bmi_default_params(): 64 (Goldilocks) or 49 (f64 kernels)
 #endif
 
 #ifndef BMI_TP_CTS

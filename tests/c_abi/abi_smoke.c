@@ -41,7 +41,7 @@ int main(void) {
     int64_t table[16];
     for (int m = -8; m < 8; m++) table[m + 8] = (m * m) % 16 - 8;
     uint32_t lut = 0, ids[5];
-    CHECK(bmi_lut_register(ctx, table, 9, DL, &lut) < 0, "msg_bits too large rejected");
+    CHECK(bmi_lut_register(ctx, table, 11, DL, &lut) < 0, "msg_bits too large for N rejected");
     CHECK(bmi_lut_register(ctx, table, 4, DL, &lut) == 0, "lut registered");
     for (int i = 0; i < 5; i++) ids[i] = lut;
     CHECK(bmi_encrypt(ctx, msgs, 5, DL, ct) == 0, "encrypt");
