@@ -9,6 +9,11 @@
 #define BMI_DEFAULT_Q_BITS 49  // modulus of bmi_default_params(): 64 (Goldilocks) or 49 (f64 kernels)
 #endif
 
+#ifndef BMI_TP49_CTS
+#define BMI_TP49_CTS 2              // ciphertexts per workgroup, f64 throughput kernel (3 with a 168-VGPR budget spills: measured slower)
+#define BMI_TP49_WAVES_PER_SIMD 2
+#endif
+
 #ifndef BMI_TP_CTS
 #define BMI_TP_CTS 2  // ciphertexts (= wavefront pairs) per workgroup in the throughput blind rotation
 #endif

@@ -70,7 +70,7 @@ __device__ __forceinline__ double digit_of(double r, int lev) {
 }
 
 template <int CTS>
-__global__ void __launch_bounds__(128 * CTS, 2)
+__global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
     k_blind_rotate_tp49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
                         const double *__restrict__ luts, const double *__restrict__ bsk, const double *__restrict__ g_tw,
                         u64 *__restrict__ out, uint32_t count, uint32_t n) {
@@ -121,15 +121,19 @@ __global__ void __launch_bounds__(128 * CTS, 2)
             forward(x, lane, lds, tile);
             wave_sync();
             static_for<0, 16>([&](auto V) { tile[eval_offset(lane, V)] = x[V]; });
-            __syncthreads();
+            // bootstrap-key rows of this level are requested BEFORE the barrier: their L2 latency overlaps the wait
             const double *row_own = bsk_i + ((size_t)(c * 3 + lev) * 2 + c) * N;
             const double *row_par = bsk_i + ((size_t)((c ^ 1) * 3 + lev) * 2 + c) * N;
+            double2 bo[8], bp[8];
             static_for<0, 8>([&](auto VP) {
-                const double2 bo = reinterpret_cast<const double2 *>(row_own)[VP * 64 + lane];
-                const double2 bp = reinterpret_cast<const double2 *>(row_par)[VP * 64 + lane];
+                bo[VP] = reinterpret_cast<const double2 *>(row_own)[VP * 64 + lane];
+                bp[VP] = reinterpret_cast<const double2 *>(row_par)[VP * 64 + lane];
+            });
+            __syncthreads();
+            static_for<0, 8>([&](auto VP) {
                 const double2 xp = reinterpret_cast<const double2 *>(ptile)[VP * 64 + lane];
-                const double s0 = f49::mul(x[2 * VP], bo.x) + f49::mul(xp.x, bp.x);      // lazy: <= 1.6p per level
-                const double s1 = f49::mul(x[2 * VP + 1], bo.y) + f49::mul(xp.y, bp.y);
+                const double s0 = f49::mul(x[2 * VP], bo[VP].x) + f49::mul(xp.x, bp[VP].x);      // lazy: <= 1.6p per level
+                const double s1 = f49::mul(x[2 * VP + 1], bo[VP].y) + f49::mul(xp.y, bp[VP].y);
                 if constexpr (lev == 0) {
                     accn[2 * VP] = s0;
                     accn[2 * VP + 1] = s1;
@@ -295,7 +299,7 @@ int launch_negacyclic_mul(const u64 *a, const u64 *b, u64 *c, const double *g_tw
 int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
                            const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
     if (count == 0) return 0;
-    constexpr int CTS = BMI_TP_CTS;
+    constexpr int CTS = BMI_TP49_CTS;
     hipLaunchKernelGGL((k_blind_rotate_tp49<CTS>), dim3((count + CTS - 1) / CTS), dim3(128 * CTS), 0, s, small_cts, lut_ids,
                        luts, bsk, g_tw, out, count, n);
     BMI49_LAUNCH_CHECK();
