@@ -467,7 +467,7 @@ int bmi_lut_get(const bmi_ctx *c, uint32_t lut_id, uint64_t *test_vector) {
 
 int bmi_set_kernel_variant(bmi_ctx *c, int variant) {
     if (!c) return -1;
-    if (variant < 0 || variant > 2) return fail(c, -1, "variant must be 0, 1 or 2");
+    if (variant < 0 || variant > 3) return fail(c, -1, "variant must be 0..3");
     c->variant = variant;
     return 0;
 }
@@ -482,7 +482,7 @@ int bmi_keyswitch_batch(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64
     // has ~1024 workgroups; large batches fill the chip with one slice.
     const uint32_t tiles = (count + 7) / 8;
     uint32_t slices = 1;
-    if (c->variant != 1)
+    if (c->variant == 0 || c->variant == 2)
         while (slices < 64 && tiles * slices * 2 <= 1024) slices *= 2;
     const size_t need = (size_t)slices * count * c->ks_stride * 16;
     if (slices > 1 && need > c->ks_partial_bytes) {
@@ -513,6 +513,7 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     if (c->f64()) {
         const double *luts = (const double *)c->d_luts, *bsk = (const double *)c->d_bsk, *tw = (const double *)c->d_tw;
         rc = latency ? bmi49::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
+             : c->variant == 3 ? bmi49::launch_blind_rotate_tpx(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
                      : bmi49::launch_blind_rotate_tp(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream);
     } else {
         const u64 *luts = (const u64 *)c->d_luts, *bsk = (const u64 *)c->d_bsk, *tw = (const u64 *)c->d_tw;

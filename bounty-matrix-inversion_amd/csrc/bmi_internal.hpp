@@ -14,6 +14,14 @@
 #define BMI_TP49_WAVES_PER_SIMD 2
 #endif
 
+#ifndef BMI_TPX49_PF
+#define BMI_TPX49_PF 12  // exchange-once kernel: where the two GGSW rows of a level are requested (see the kernel)
+#endif
+
+#ifndef BMI_TPX49_SYNC
+#define BMI_TPX49_SYNC 0  // pair synchronisation of the exchange-once kernel: 0 = LDS counters (pairs only), 1 = workgroup barrier
+#endif
+
 #ifndef BMI_TP_CTS
 #define BMI_TP_CTS 2  // ciphertexts (= wavefront pairs) per workgroup in the throughput blind rotation
 #endif
@@ -45,6 +53,8 @@ int launch_bsk_to_ntt(const u64 *std_polys, double *ntt_polys, const double *g_t
 int launch_negacyclic_mul(const u64 *a, const u64 *b, u64 *c, const double *g_tw, uint32_t count, hipStream_t s);
 int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
                            const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s);
+int launch_blind_rotate_tpx(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
+                            const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s);
 int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
                             const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s);
 int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,

@@ -69,6 +69,36 @@ __device__ __forceinline__ double digit_of(double r, int lev) {
     return r2;
 }
 
+// Phase timing (debug build only: make prof): wall-clock cycles per phase of one wavefront, see tools/phase_prof.py
+#ifdef BMI_PHASE_PROF
+__device__ unsigned long long g_phase[64];
+#define PH_DECL() unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = clock64()
+#define PH_MARK(k)                               \
+    do {                                         \
+        const unsigned long long t_ = clock64(); \
+        ph_[k] += t_ - tl_;                      \
+        tl_ = t_;                                \
+    } while (0)
+#define PH_FLUSH()                                                           \
+    do {                                                                     \
+        if (blockIdx.x == gridDim.x / 2 && lane == 0)                        \
+            for (int k_ = 0; k_ < 8; k_++) g_phase[wave * 8 + k_] = ph_[k_]; \
+    } while (0)
+#else
+#define PH_DECL()
+#define PH_MARK(k)
+#define PH_FLUSH()
+#endif
+
+// Peels the least significant remaining digit off r (round-half-even): returns it and leaves rint(r / 2^15) in r.
+// Walking the levels 2, 1, 0 this way keeps ONE array live (digit_of() from r would keep r, r1 and r2).
+__device__ __forceinline__ double peel_digit(double &r) {
+    const double rn = __builtin_rint(r * 0x1p-15);
+    const double d = __builtin_fma(-32768.0, rn, r);
+    r = rn;
+    return d;
+}
+
 template <int CTS>
 __global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
     k_blind_rotate_tp49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
@@ -100,9 +130,11 @@ __global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
         });
     }
 
+    PH_DECL();
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t a_t = at[i];
         const double *bsk_i = bsk + (size_t)i * 12 * N;
+        PH_MARK(7);
         wave_sync();
         static_for<0, 16>([&](auto J) { tile[lane + 64 * J] = acc[J]; });
         wave_sync();
@@ -114,11 +146,13 @@ __global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
             r[J] = __builtin_rint(f49::red(v - acc[J]) * 0x1p-4);
         });
         double accn[16];
+        PH_MARK(0);
         static_for<0, 3>([&](auto LEV) {
-            constexpr int lev = LEV;
+            constexpr int lev = 2 - LEV;  // least significant digit first
             double x[16];
-            static_for<0, 16>([&](auto J) { x[J] = digit_of(r[J], lev); });
+            static_for<0, 16>([&](auto J) { x[J] = lev == 0 ? r[J] : peel_digit(r[J]); });
             forward(x, lane, lds, tile);
+            PH_MARK(1);
             wave_sync();
             static_for<0, 16>([&](auto V) { tile[eval_offset(lane, V)] = x[V]; });
             // bootstrap-key rows of this level are requested BEFORE the barrier: their L2 latency overlaps the wait
@@ -130,11 +164,12 @@ __global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
                 bp[VP] = reinterpret_cast<const double2 *>(row_par)[VP * 64 + lane];
             });
             __syncthreads();
+            PH_MARK(2);
             static_for<0, 8>([&](auto VP) {
                 const double2 xp = reinterpret_cast<const double2 *>(ptile)[VP * 64 + lane];
                 const double s0 = f49::mul(x[2 * VP], bo[VP].x) + f49::mul(xp.x, bp[VP].x);      // lazy: <= 1.6p per level
                 const double s1 = f49::mul(x[2 * VP + 1], bo[VP].y) + f49::mul(xp.y, bp[VP].y);
-                if constexpr (lev == 0) {
+                if constexpr (lev == 2) {
                     accn[2 * VP] = s0;
                     accn[2 * VP + 1] = s1;
                 } else {
@@ -142,12 +177,16 @@ __global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
                     accn[2 * VP + 1] += s1;
                 }
             });
+            PH_MARK(3);
             __syncthreads();
+            PH_MARK(4);
         });
         static_for<0, 16>([&](auto V) { accn[V] = f49::red(accn[V]); });
         inverse(accn, lane, lds, tile);
         static_for<0, 16>([&](auto J) { acc[J] = f49::red(acc[J] + accn[J]); });
+        PH_MARK(5);
     }
+    PH_FLUSH();
 
     if (!live) return;
     u64 *o = out + (size_t)ct * (N + 1);
@@ -159,6 +198,192 @@ __global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
         });
     } else if (lane == 0) {
         o[N] = f49::to_u(acc[0]);
+    }
+}
+
+
+// THROUGHPUT, second form: one exchange per CMUX instead of three.
+// Wavefront c of a pair owns INPUT polynomial c of the CMUX: it decomposes rot(acc_c) - acc_c, transforms the three
+// digit polynomials and multiplies each with BOTH output columns of its three GGSW rows, so it ends the levels with
+// a partial sum for its own component and one for the partner's.  The partner's partial goes through the tile once,
+// guarded by a pair of LDS counters (publish / consumed) that only the two wavefronts of the pair poll: there is no
+// workgroup barrier in the loop, so the four pairs of a workgroup drift freely and the workgroup can be as large as
+// the CU (8 wavefronts share one copy of the twiddle tables, which leaves LDS room for the accumulators: the
+// accumulator lives in LDS between iterations, not in registers).
+constexpr int TPX_CTS = 4;
+constexpr int TPX_AT_WORDS = 160;
+constexpr int TPX_LDS_WORDS = TW_WORDS + 2 * TPX_CTS * (SCRATCH_WORDS + N) + TPX_CTS * TPX_AT_WORDS + 4 * TPX_CTS;
+
+__device__ __forceinline__ void pair_post(uint32_t *flag, uint32_t v) {
+    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// The poll loop is one opaque asm block: as C++ control flow it splits the loop body into several blocks and the
+// register allocator then spills ~180 dwords per lane (measured); all lanes read the same LDS word.
+__device__ __forceinline__ void pair_wait(uint32_t *flag, uint32_t v) {
+#if BMI_TPX49_SYNC == 1
+    (void)flag;
+    (void)v;
+    __syncthreads();
+#else
+    const uint32_t addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)flag;
+    uint32_t tmp;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %0, %1\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u32 vcc, %2, %0\n\t"
+        "s_cbranch_vccnz 2f\n\t"
+        "s_sleep 1\n\t"
+        "s_branch 1b\n"
+        "2:"
+        : "=&v"(tmp)
+        : "v"(addr), "s"(v)
+        : "vcc", "memory");
+#endif
+}
+
+// keeps memory operations and the machine scheduler from moving work across this point (register pressure control)
+__device__ __forceinline__ void pin() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int PF>
+__global__ void __launch_bounds__(128 * TPX_CTS)
+    k_blind_rotate_tpx49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
+                         const double *__restrict__ luts, const double *__restrict__ bsk,
+                         const double *__restrict__ g_tw, u64 *__restrict__ out, uint32_t count, uint32_t n) {
+    constexpr int CTS = TPX_CTS;
+    extern __shared__ double lds[];
+    double *tiles = lds + TW_WORDS;
+    double *accs = tiles + 2 * CTS * SCRATCH_WORDS;
+    double *at_base = accs + 2 * CTS * N;
+    uint32_t *flags = reinterpret_cast<uint32_t *>(at_base + CTS * TPX_AT_WORDS);  // [2 CTS] published, [2 CTS] consumed
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ctl = wave >> 1, c = wave & 1;
+    if (threadIdx.x < 4 * CTS) flags[threadIdx.x] = 0;
+    stage_twiddles(lds, g_tw);
+    const uint32_t ct_raw = blockIdx.x * CTS + ctl;
+    const bool live = ct_raw < count;
+    const uint32_t ct = live ? ct_raw : count - 1;
+    double *tile = tiles + wave * SCRATCH_WORDS;
+    const double *ptile = tiles + (wave ^ 1) * SCRATCH_WORDS;
+    double *accl = accs + wave * N;
+    uint16_t *at = reinterpret_cast<uint16_t *>(at_base + ctl * TPX_AT_WORDS);
+    uint32_t *f_pub = flags + wave, *f_pub_partner = flags + (wave ^ 1);
+    uint32_t *f_ack = flags + 2 * CTS + wave, *f_ack_partner = flags + 2 * CTS + (wave ^ 1);
+    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
+    for (uint32_t i = lane + 64 * c; i <= n; i += 128) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 1);
+    __syncthreads();
+    {
+        const double *tv = luts + (size_t)lut_ids[ct] * N;
+        const uint32_t bt = at[n];
+        static_for<0, 16>([&](auto J) {
+            const uint32_t e = (lane + 64 * J + bt) & (2 * N - 1);
+            const double v = tv[e & (N - 1)];
+            accl[lane + 64 * J] = c ? ((e & N) ? -v : v) : 0.0;
+        });
+    }
+
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t a_t = at[i];
+        const double *bsk_c = bsk + ((size_t)i * 12 + c * 6) * N;  // this wavefront's three GGSW rows (two columns each)
+        wave_sync();
+        double r[16];
+        {
+            double vr[16], vs[16];  // all 32 reads in flight before the first use
+            static_for<0, 16>([&](auto J) {
+                vr[J] = accl[(lane + 64 * J + 2 * N - a_t) & (N - 1)];
+                vs[J] = accl[lane + 64 * J];
+            });
+            sched_fence();
+            static_for<0, 16>([&](auto J) {
+                const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
+                const double v = (e & N) ? -vr[J] : vr[J];
+                r[J] = __builtin_rint(f49::red(v - vs[J]) * 0x1p-4);
+            });
+        }
+        double am[16], ao[16];  // partial sums: own component, partner's component
+        static_for<0, 3>([&](auto LEV) {
+            constexpr int lev = 2 - LEV;  // least significant digit first
+            const double2 *row_m = reinterpret_cast<const double2 *>(bsk_c + (size_t)(lev * 2 + c) * N);
+            const double2 *row_o = reinterpret_cast<const double2 *>(bsk_c + (size_t)(lev * 2 + (c ^ 1)) * N);
+            double2 bm[8], bo[8];
+            // PF = 10 * (where the own-column row is requested) + (where the partner-column row is requested):
+            // 0 before the transform, 1 before its second DFT16, 2 before its quad transpose, 3 after it
+            constexpr int PM = PF / 10, PO = PF % 10;
+            auto load_m = [&]() { static_for<0, 8>([&](auto VP) { bm[VP] = row_m[VP * 64 + lane]; }); };
+            auto load_o = [&]() { static_for<0, 8>([&](auto VP) { bo[VP] = row_o[VP * 64 + lane]; }); };
+            pin();
+            if constexpr (PM == 0) load_m();
+            if constexpr (PO == 0) load_o();
+            double x[16];
+            static_for<0, 16>([&](auto J) { x[J] = lev == 0 ? r[J] : peel_digit(r[J]); });
+            forward(
+                x, lane, lds, tile,
+                [&]() {
+                    if constexpr (PM == 1) load_m();
+                    if constexpr (PO == 1) load_o();
+                },
+                [&]() {
+                    if constexpr (PM == 2) load_m();
+                    if constexpr (PO == 2) load_o();
+                });
+            pin();
+            if constexpr (PM == 3) load_m();
+            if constexpr (PO == 3) load_o();
+            static_for<0, 8>([&](auto VP) {
+                const double m0 = f49::mul(x[2 * VP], bm[VP].x), m1 = f49::mul(x[2 * VP + 1], bm[VP].y);
+                if constexpr (lev == 2) {
+                    am[2 * VP] = m0;
+                    am[2 * VP + 1] = m1;
+                } else {
+                    am[2 * VP] += m0;
+                    am[2 * VP + 1] += m1;
+                }
+            });
+            static_for<0, 8>([&](auto VP) {
+                const double o0 = f49::mul(x[2 * VP], bo[VP].x), o1 = f49::mul(x[2 * VP + 1], bo[VP].y);
+                if constexpr (lev == 2) {
+                    ao[2 * VP] = o0;
+                    ao[2 * VP + 1] = o1;
+                } else {
+                    ao[2 * VP] += o0;
+                    ao[2 * VP + 1] += o1;
+                }
+            });
+            pin();
+        });
+        // exchange: the partner's partial goes through this wavefront's tile (free since the last forward transform)
+        wave_sync();
+        static_for<0, 8>([&](auto VP) {
+            reinterpret_cast<double2 *>(tile)[VP * 64 + lane] = double2{ao[2 * VP], ao[2 * VP + 1]};
+        });
+        pair_post(f_pub, i + 1);
+        pair_wait(f_pub_partner, i + 1);
+        static_for<0, 8>([&](auto VP) {
+            const double2 p = reinterpret_cast<const double2 *>(ptile)[VP * 64 + lane];
+            am[2 * VP] = f49::red(am[2 * VP] + p.x);          // <= 2 * 3 * 0.9p before the reduction
+            am[2 * VP + 1] = f49::red(am[2 * VP + 1] + p.y);
+        });
+        pair_post(f_ack, i + 1);          // release: the reads above have landed
+        pair_wait(f_ack_partner, i + 1);  // the partner has read this tile: the inverse transform may overwrite it
+        inverse(am, lane, lds, tile);
+        static_for<0, 16>([&](auto J) { accl[lane + 64 * J] = f49::red(accl[lane + 64 * J] + am[J]); });
+    }
+
+    if (!live) return;
+    wave_sync();
+    u64 *o = out + (size_t)ct * (N + 1);
+    if (c == 0) {
+        static_for<0, 16>([&](auto J) {
+            const uint32_t m = lane + 64 * J;
+            const double v = accl[m];
+            if (m == 0) o[0] = f49::to_u(v);
+            else o[N - m] = f49::to_u(-v);
+        });
+    } else if (lane == 0) {
+        o[N] = f49::to_u(accl[0]);
     }
 }
 
@@ -276,6 +501,12 @@ struct Field49 {
 
 }  // namespace
 
+#ifdef BMI_PHASE_PROF
+extern "C" int bmi_debug_phase_prof(unsigned long long *out64) {
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 64);
+}
+#endif
+
 namespace bmi49 {
 
 #define BMI49_LAUNCH_CHECK()                    \
@@ -302,6 +533,25 @@ int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const 
     constexpr int CTS = BMI_TP49_CTS;
     hipLaunchKernelGGL((k_blind_rotate_tp49<CTS>), dim3((count + CTS - 1) / CTS), dim3(128 * CTS), 0, s, small_cts, lut_ids,
                        luts, bsk, g_tw, out, count, n);
+    BMI49_LAUNCH_CHECK();
+    return 0;
+}
+
+
+int launch_blind_rotate_tpx(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
+                            const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+    if (count == 0) return 0;
+    static bool attr_set = false;
+    const size_t lds = (size_t)TPX_LDS_WORDS * sizeof(double);
+    auto kern = k_blind_rotate_tpx49<BMI_TPX49_PF>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((count + TPX_CTS - 1) / TPX_CTS), dim3(128 * TPX_CTS), lds, s, small_cts, lut_ids, luts,
+                       bsk, g_tw, out, count, n);
     BMI49_LAUNCH_CHECK();
     return 0;
 }

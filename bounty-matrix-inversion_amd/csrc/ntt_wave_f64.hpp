@@ -106,20 +106,46 @@ __device__ __forceinline__ void dft4(double (&x)[16]) {
     x[B + 3] = o0 - o1;
 }
 
+// The scheduler may not move anything across this point.  Used to keep batches of LDS twiddle reads ahead of the
+// arithmetic that hides their latency: left alone, the compiler issues each read right before its use and waits
+// for it (lgkmcnt(0) after every ds_read: ~30 exposed LDS latencies per transform, seen in the ISA).
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+
 // Forward transform.  x[j] = a[lane + 64 j] (|.| <= 0.8p) on entry; evaluation layout (|.| <= 3.2p) on exit.
-__device__ __forceinline__ void forward(double (&x)[16], int lane, const double *tw, double *scratch) {
+// mid() runs before the second DFT16, late() before the quad transpose: callers issue global loads there whose
+// latency the rest of the transform hides.
+template <class Mid = NoHook, class Late = NoHook>
+__device__ __forceinline__ void forward(double (&x)[16], int lane, const double *tw, double *scratch, Mid mid = Mid(),
+                                        Late late = Late()) {
+    double wa[8], wb[8];
+    static_for<0, 8>([&](auto K) { wa[K] = tw[TW_W1 + K * 64 + lane]; });
+    sched_fence();
     static_for<1, 16>([&](auto J) { x[J] = f49::mul(x[J], psi_pow<false, 64 * J>()); });  // psi^(64 j)
     dft16<false>(x);
-    static_for<0, 16>([&](auto K) { x[K] = f49::mul(x[K], tw[TW_W1 + K * 64 + lane]); });
+    static_for<0, 8>([&](auto K) { wb[K] = tw[TW_W1 + (K + 8) * 64 + lane]; });
+    sched_fence();
+    static_for<0, 8>([&](auto K) { x[K] = f49::mul(x[K], wa[K]); });
+    static_for<0, 8>([&](auto K) { x[K + 8] = f49::mul(x[K + 8], wb[K]); });
     wave_sync();
     static_for<0, 16>([&](auto K) { scratch[K * ROW + lane] = x[K]; });
     wave_sync();
     const int k1 = lane >> 2, t = lane & 3;
     double *row = scratch + k1 * ROW;
     static_for<0, 16>([&](auto U) { x[U] = row[t + 4 * U]; });
+    static_for<1, 8>([&](auto V) { wa[V] = tw[TW_W2 + V * 4 + t]; });
+    mid();
+    sched_fence();
     dft16<false>(x);
+    static_for<0, 8>([&](auto V) { wb[V] = tw[TW_W2 + (V + 8) * 4 + t]; });
+    sched_fence();
     x[0] = f49::red(x[0]);
-    static_for<1, 16>([&](auto V) { x[V] = f49::mul(x[V], tw[TW_W2 + V * 4 + t]); });
+    static_for<1, 8>([&](auto V) { x[V] = f49::mul(x[V], wa[V]); });
+    static_for<0, 8>([&](auto V) { x[V + 8] = f49::mul(x[V + 8], wb[V]); });
+    late();
     const int sw0 = t & 3, sw1 = (t + 1) & 3, sw2 = (t + 2) & 3, sw3 = (t + 3) & 3;
     wave_sync();
     static_for<0, 16>([&](auto V) {
@@ -144,6 +170,10 @@ __device__ __forceinline__ void inverse(double (&x)[16], int lane, const double 
     const int k1 = lane >> 2, t = lane & 3;
     double *row = scratch + k1 * ROW;
     const int sw0 = t & 3, sw1 = (t + 1) & 3, sw2 = (t + 2) & 3, sw3 = (t + 3) & 3;
+    double wa[8], wb[8];
+    static_for<1, 8>([&](auto V) { wa[V] = tw[TW_W2I + V * 4 + t]; });
+    static_for<0, 8>([&](auto V) { wb[V] = tw[TW_W2I + (V + 8) * 4 + t]; });
+    sched_fence();
     dft4<true, 0>(x);
     dft4<true, 4>(x);
     dft4<true, 8>(x);
@@ -161,12 +191,19 @@ __device__ __forceinline__ void inverse(double (&x)[16], int lane, const double 
         x[V] = row[16 * t + (v & 12) + sw];
     });
     x[0] = f49::red(x[0]);
-    static_for<1, 16>([&](auto V) { x[V] = f49::mul(x[V], tw[TW_W2I + V * 4 + t]); });
+    static_for<1, 8>([&](auto V) { x[V] = f49::mul(x[V], wa[V]); });
+    static_for<0, 8>([&](auto V) { x[V + 8] = f49::mul(x[V + 8], wb[V]); });
     dft16<true>(x);
     wave_sync();
     static_for<0, 16>([&](auto U) { row[t + 4 * U] = x[U]; });
     wave_sync();
-    static_for<0, 16>([&](auto K) { x[K] = f49::mul(scratch[K * ROW + lane], tw[TW_W1I + K * 64 + lane]); });
+    double y[16];
+    static_for<0, 16>([&](auto K) { y[K] = scratch[K * ROW + lane]; });
+    static_for<0, 8>([&](auto K) { wa[K] = tw[TW_W1I + K * 64 + lane]; });
+    static_for<0, 8>([&](auto K) { wb[K] = tw[TW_W1I + (K + 8) * 64 + lane]; });
+    sched_fence();
+    static_for<0, 8>([&](auto K) { x[K] = f49::mul(y[K], wa[K]); });
+    static_for<0, 8>([&](auto K) { x[K + 8] = f49::mul(y[K + 8], wb[K]); });
     dft16<true>(x);
     static_for<1, 16>([&](auto J) { x[J] = f49::mul(x[J], psi_pow<true, 64 * J>()); });
 }

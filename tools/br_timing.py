@@ -6,6 +6,8 @@ sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "bounty-matrix-i
 import numpy as np, torch
 from bmi_amd import tfhe
 from oracle import tfhe_oracle as to
+if os.environ.get('BMI_TFHE_LIB'):  # A/B builds of the kernel library (tools only)
+    tfhe.LIB_PATH = os.environ['BMI_TFHE_LIB']
 
 def main():
     batches = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,64,4096").split(",")]

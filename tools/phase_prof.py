@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Per-phase wall-clock cycles of one workgroup of k_blind_rotate_tp49 (debug build: make -C csrc prof)."""
+import os, sys, json, ctypes as C
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "bounty-matrix-inversion_amd"))
+import numpy as np, torch
+from bmi_amd import tfhe
+tfhe.LIB_PATH = tfhe.LIB_PATH.replace("libbmi_tfhe.so", "libbmi_tfhe_prof.so")
+
+NAMES = ["rotate+decompose", "forward NTT x3", "publish+key loads+barrier", "MAC x3", "barrier 2", "inverse+update", "-", "loop head"]
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    eng = tfhe.Engine(tfhe.default_params(q_bits=49)); eng.keygen(0x5EED)
+    DL = eng.delta_log()
+    lid = eng.lut_register(np.arange(-8, 8), 4, DL)
+    ct = eng.encrypt(np.random.default_rng(1).integers(-8, 8, B), DL)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    d_in = torch.from_numpy(ct.view(np.int64)).to(dev)
+    d_small = torch.empty((B, 631), dtype=torch.int64, device=dev)
+    d_ids = torch.full((B,), lid, dtype=torch.int32, device=dev)
+    d_out = torch.empty((B, 1025), dtype=torch.int64, device=dev)
+    eng.set_kernel_variant(1)
+    eng.keyswitch(d_in, B, d_small, s)
+    for _ in range(2):
+        eng.blind_rotate(d_small, d_ids, B, d_out, s)
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 64)()
+    rc = tfhe.load_library().bmi_debug_phase_prof(buf)
+    assert rc == 0, rc
+    a = np.array(buf[:], dtype=np.float64).reshape(8, 8)
+    for w in range(4):
+        tot = a[w].sum()
+        print(json.dumps({"wave": w, "total_cycles": tot, "per_cmux": round(tot / 630, 1),
+                          "phases_pct": {n: round(100 * v / tot, 1) for n, v in zip(NAMES, a[w]) if n != "-"}}))
+
+main()
