@@ -65,6 +65,7 @@ _SIGS = {
     "bmi_sync": [C.c_void_p, C.c_void_p],
     "bmi_reserve": [C.c_void_p, C.c_uint32],
     "bmi_set_kernel_variant": [C.c_void_p, C.c_int],
+    "bmi_set_keyswitch_variant": [C.c_void_p, C.c_int],
     "bmi_key_bytes": [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
 }
 
@@ -229,7 +230,12 @@ class Engine:
         return tv
 
     def set_kernel_variant(self, v):
+        """blind rotation: 0 auto, 1 pair kernel exchanging per level, 2 latency kernel, 3 pair kernel exchanging per CMUX"""
         self._ck(self.lib.bmi_set_kernel_variant(self.h, int(v)), "bmi_set_kernel_variant")
+
+    def set_keyswitch_variant(self, v):
+        """keyswitch: 0 auto (int8 matrix-core product), 1 scalar kernel"""
+        self._ck(self.lib.bmi_set_keyswitch_variant(self.h, int(v)), "bmi_set_keyswitch_variant")
 
     # ---- hot path, host buffers (numpy in / numpy out)
     def pbs_host(self, cts, lut_ids):

@@ -112,6 +112,13 @@ struct bmi_ctx {
     uint32_t lat_threshold = 768;  // 3 rounds of 256 one-workgroup PBS still beat one round of the wave-pair kernel
     void *d_ks_partial = nullptr;
     size_t ks_partial_bytes = 0;
+    // keyswitch on the matrix cores: limb-wise key (per keygen), digit matrix and int32 sums (growable scratch)
+    int ks_variant = 0;  // 0 = auto (matrix cores when the shape allows), 1 = scalar kernel
+    bool ks_mfma_ok = false;
+    signed char *d_ks_limbs = nullptr, *d_ks_digits = nullptr;
+    int *d_ks_sums = nullptr;
+    size_t ks_digits_bytes = 0, ks_sums_bytes = 0;
+    uint32_t ks_limbs() const { return f64() ? bmi49::KS_LIMBS : bmi::KS_LIMBS; }
     mutable std::string err;
     bool f64() const { return f.bits == 49; }
 };
@@ -255,7 +262,8 @@ void bmi_ctx_destroy(bmi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (void *p : {c->d_bsk, (void *)c->d_ksk, (void *)c->d_ks_bias, c->d_tw, c->d_luts, (void *)c->d_small,
-                    (void *)c->d_io_a, (void *)c->d_io_b, (void *)c->d_io_ids, c->d_ks_partial})
+                    (void *)c->d_io_a, (void *)c->d_io_b, (void *)c->d_io_ids, c->d_ks_partial,
+                    (void *)c->d_ks_limbs, (void *)c->d_ks_digits, (void *)c->d_ks_sums})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -354,6 +362,19 @@ int bmi_keygen(bmi_ctx *c, uint64_t seed) {
         for (uint32_t x = 0; x <= n; x++) bias[x] = c->f.mul(bias[x], half);
         if (!c->d_ks_bias) HIP_OK(c, hipMalloc(&c->d_ks_bias, c->ks_stride * sizeof(u64)));
         HIP_OK(c, hipMemcpy(c->d_ks_bias, bias.data(), c->ks_stride * sizeof(u64), hipMemcpyHostToDevice));
+    }
+    // limb-wise copy of the keyswitch key for the matrix-core keyswitch (int8 operands, int32 sums: the digits must
+    // fit int8 and a column sum of rows * (B/2) * 128 must stay below 2^31)
+    c->ks_mfma_ok = ksk_rows % 32 == 0 && P.ks_levels <= 8 && P.ks_base_log <= 7 &&
+                    (ksk_rows << (P.ks_base_log - 1)) < ((size_t)1 << 24);
+    if (c->ks_mfma_ok) {
+        const uint32_t cbs = (n + 1 + 31) / 32;
+        const size_t bytes = (size_t)cbs * (ksk_rows / 32) * c->ks_limbs() * 1024;
+        if (!c->d_ks_limbs) HIP_OK(c, hipMalloc(&c->d_ks_limbs, bytes));
+        rc = (c->f64() ? bmi49::launch_ksk_to_limbs : bmi::launch_ksk_to_limbs)(c->d_ksk, c->d_ks_limbs, (uint32_t)ksk_rows, n,
+                                                                                c->ks_stride, c->stream);
+        if (rc) return fail(c, -2, "ksk_to_limbs launch failed");
+        HIP_OK(c, hipStreamSynchronize(c->stream));
     }
     c->have_keys = true;
     return 0;
@@ -465,6 +486,13 @@ int bmi_lut_get(const bmi_ctx *c, uint32_t lut_id, uint64_t *test_vector) {
     return 0;
 }
 
+int bmi_set_keyswitch_variant(bmi_ctx *c, int variant) {
+    if (!c) return -1;
+    if (variant < 0 || variant > 1) return fail(c, -1, "keyswitch variant must be 0 or 1");
+    c->ks_variant = variant;
+    return 0;
+}
+
 int bmi_set_kernel_variant(bmi_ctx *c, int variant) {
     if (!c) return -1;
     if (variant < 0 || variant > 3) return fail(c, -1, "variant must be 0..3");
@@ -473,11 +501,58 @@ int bmi_set_kernel_variant(bmi_ctx *c, int variant) {
 }
 
 // ------------------------------------------------------------------------------- the hot path
+namespace {
+// grows a device scratch buffer (never shrinks); the old one may still be in use by queued work -> synchronise first
+int ensure_bytes(bmi_ctx *c, void **p, size_t *cap, size_t need, size_t floor_bytes) {
+    if (need <= *cap) return 0;
+    if (*p) {
+        HIP_OK(c, hipDeviceSynchronize());
+        HIP_OK(c, hipFree(*p));
+        *p = nullptr;
+        *cap = 0;
+    }
+    const size_t bytes = std::max(need, floor_bytes);
+    HIP_OK(c, hipMalloc(p, bytes));
+    *cap = bytes;
+    return 0;
+}
+
+// K-slices of the matrix-core keyswitch: enough wavefronts (tiles x column blocks x slices) to fill 1024 SIMDs twice
+uint32_t ks_mfma_slices(const bmi_ctx *c, uint32_t count) {
+    const uint32_t tiles = (count + 31) / 32, cbs = (c->P.n + 1 + 31) / 32;
+    const uint32_t ksteps = c->big_n * c->P.ks_levels / 32;
+    uint32_t slices = 1;
+    while (slices < 64 && slices * 2 <= ksteps && ksteps % (slices * 2) == 0 && (size_t)tiles * cbs * slices < 2048) slices *= 2;
+    return slices;
+}
+
+int ensure_ks_mfma(bmi_ctx *c, uint32_t count) {
+    const uint32_t cbs = (c->P.n + 1 + 31) / 32;
+    const size_t dig = (size_t)count * c->big_n * c->P.ks_levels;
+    const size_t sums = (size_t)ks_mfma_slices(c, count) * count * c->ks_limbs() * cbs * 32 * sizeof(int);
+    int rc = ensure_bytes(c, (void **)&c->d_ks_digits, &c->ks_digits_bytes, dig, (size_t)8 << 20);
+    if (rc) return rc;
+    return ensure_bytes(c, (void **)&c->d_ks_sums, &c->ks_sums_bytes, sums, (size_t)32 << 20);
+}
+
+int keyswitch_mfma(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64_t *d_small, hipStream_t stream) {
+    if (count == 0) return 0;
+    int rc = ensure_ks_mfma(c, count);
+    if (rc) return rc;
+    rc = (c->f64() ? bmi49::launch_keyswitch_mfma : bmi::launch_keyswitch_mfma)(
+        d_in, c->d_ks_limbs, c->d_ks_digits, c->d_ks_sums, d_small, ks_mfma_slices(c, count), count, c->P.n, c->big_n,
+        c->P.ks_levels, c->P.ks_base_log, stream);
+    return rc ? fail(c, -2, std::string("keyswitch (matrix cores) launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+}
+}  // namespace
+
 int bmi_keyswitch_batch(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64_t *d_small, void *stream) {
     if (!c || (count && (!d_in || !d_small))) return -1;
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
     HIP_OK(c, hipSetDevice(c->device));
-    // The row walk (k*N*levels rows) of one workgroup is the latency of a small batch, so it is split over
+    // small batches: the K-split scalar kernel has the shorter launch chain (measured: 0.14 ms against 0.34 ms at 3 ciphertexts)
+    if (c->ks_variant == 0 && c->ks_mfma_ok && count >= 64) return keyswitch_mfma(c, d_in, count, d_small, (hipStream_t)stream);
+    // Scalar form.  The row walk (k*N*levels rows) of one workgroup is the latency of a small batch, so it is split over
     // `slices` workgroups per tile of 8 ciphertexts (partial 128-bit sums + a reduce kernel) until the launch
     // has ~1024 workgroups; large batches fill the chip with one slice.
     const uint32_t tiles = (count + 7) / 8;
@@ -507,14 +582,14 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
     HIP_OK(c, hipSetDevice(c->device));
     // variant 0 = auto: the latency kernel (one workgroup per ciphertext) while the batch cannot fill the chip
-    // with one-wave-per-ciphertext work, the throughput kernel beyond that.
+    // with wave-pair work, the throughput kernel beyond that (49-bit field: the exchange-once form).
     const bool latency = c->variant == 2 || (c->variant == 0 && count <= c->lat_threshold);
     int rc;
     if (c->f64()) {
         const double *luts = (const double *)c->d_luts, *bsk = (const double *)c->d_bsk, *tw = (const double *)c->d_tw;
         rc = latency ? bmi49::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
-             : c->variant == 3 ? bmi49::launch_blind_rotate_tpx(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
-                     : bmi49::launch_blind_rotate_tp(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream);
+             : c->variant == 1 ? bmi49::launch_blind_rotate_tp(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
+                     : bmi49::launch_blind_rotate_tpx(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream);
     } else {
         const u64 *luts = (const u64 *)c->d_luts, *bsk = (const u64 *)c->d_bsk, *tw = (const u64 *)c->d_tw;
         rc = latency ? bmi::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
@@ -551,6 +626,15 @@ int bmi_reserve(bmi_ctx *c, uint32_t max_count) {
     if (!c->d_ks_partial) {
         c->ks_partial_bytes = (size_t)96 << 20;  // covers every split configuration (<= 1024 workgroups x 8 ciphertexts)
         HIP_OK(c, hipMalloc(&c->d_ks_partial, c->ks_partial_bytes));
+    }
+    if (c->ks_mfma_ok) {
+        // the sums buffer peaks where the K-split is still active (small batches), not at max_count
+        for (uint32_t cnt = 32; cnt < max_count; cnt *= 2) {
+            int rc = ensure_ks_mfma(c, cnt);
+            if (rc) return rc;
+        }
+        int rc = ensure_ks_mfma(c, max_count);
+        if (rc) return rc;
     }
     return ensure_small(c, max_count);
 }

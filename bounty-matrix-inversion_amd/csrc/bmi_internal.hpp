@@ -41,6 +41,13 @@ int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const
 int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
                      uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,
                      hipStream_t s);
+// Keyswitch on the matrix cores (ks_mfma.hpp): the key as KS_LIMBS balanced base-256 limbs in MFMA operand order,
+// digits = count * big_n * levels bytes, sums = slices * count * KS_LIMBS * ceil((n+1)/32)*32 int32 words.
+constexpr uint32_t KS_LIMBS = 9;
+int launch_ksk_to_limbs(const u64 *ksk, signed char *limbs, uint32_t rows, uint32_t n, uint32_t ks_stride, hipStream_t s);
+int launch_keyswitch_mfma(const u64 *in, const signed char *limbs, signed char *digits, int *sums, u64 *out,
+                          uint32_t slices, uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels,
+                          uint32_t base_log, hipStream_t s);
 int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *idx, const i64 *coef,
                    const u64 *const_body, u64 *out, uint32_t count, uint32_t width, hipStream_t s);
 }  // namespace bmi
@@ -60,6 +67,13 @@ int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const
 int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
                      uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,
                      hipStream_t s);
+// Keyswitch on the matrix cores (ks_mfma.hpp): the key as KS_LIMBS balanced base-256 limbs in MFMA operand order,
+// digits = count * big_n * levels bytes, sums = slices * count * KS_LIMBS * ceil((n+1)/32)*32 int32 words.
+constexpr uint32_t KS_LIMBS = 7;
+int launch_ksk_to_limbs(const u64 *ksk, signed char *limbs, uint32_t rows, uint32_t n, uint32_t ks_stride, hipStream_t s);
+int launch_keyswitch_mfma(const u64 *in, const signed char *limbs, signed char *digits, int *sums, u64 *out,
+                          uint32_t slices, uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels,
+                          uint32_t base_log, hipStream_t s);
 int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *idx, const i64 *coef,
                    const u64 *const_body, u64 *out, uint32_t count, uint32_t width, hipStream_t s);
 }  // namespace bmi49

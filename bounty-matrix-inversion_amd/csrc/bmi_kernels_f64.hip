@@ -11,6 +11,7 @@
 
 #include "bmi_internal.hpp"
 #include "ks_lincomb.hpp"
+#include "ks_mfma.hpp"
 #include "ntt_wave_f64.hpp"
 
 using f49::i64;
@@ -487,6 +488,7 @@ struct Field49 {
         }
         d[0] = (unsigned char)(r + half);
     }
+    static __device__ __forceinline__ i64 centered(u64 a) { return f49::centered(a); }
     static __device__ __forceinline__ u64 add(u64 a, u64 b) { return f49::addq(a, b); }
     static __device__ __forceinline__ u64 sub(u64 a, u64 b) { return f49::subq(a, b); }
     static __device__ __forceinline__ u64 neg(u64 a) { return f49::negq(a); }
@@ -578,6 +580,16 @@ int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out
                      hipStream_t s) {
     return ksl::launch_keyswitch<Field49>(in, ksk, ks_bias, out, partial, slices, count, n, big_n, levels, base_log,
                                           ks_stride, s);
+}
+
+int launch_ksk_to_limbs(const u64 *ksk, signed char *limbs, uint32_t rows, uint32_t n, uint32_t ks_stride, hipStream_t s) {
+    return ksm::launch_ksk_to_limbs<Field49>(ksk, limbs, rows, n, ks_stride, KS_LIMBS, s);
+}
+
+int launch_keyswitch_mfma(const u64 *in, const signed char *limbs, signed char *digits, int *sums, u64 *out,
+                          uint32_t slices, uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels,
+                          uint32_t base_log, hipStream_t s) {
+    return ksm::launch_keyswitch<Field49, KS_LIMBS>(in, limbs, digits, sums, out, slices, count, n, big_n, levels, base_log, s);
 }
 
 int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *idx, const i64 *coef,

@@ -117,9 +117,14 @@ int bmi_reserve(bmi_ctx *ctx, uint32_t max_count);
 
 int bmi_sync(bmi_ctx *ctx, void *stream);
 
-/* Selects the blind-rotation kernel: 0 = auto (by batch size), 1 = throughput (one wavefront per
- * ciphertext), 2 = latency (one workgroup of 8 wavefronts per ciphertext). */
+/* Selects the blind-rotation kernel: 0 = auto (by batch size), 1 = throughput, a pair of wavefronts per
+ * ciphertext exchanging every level, 2 = latency (one workgroup of 8 wavefronts per ciphertext), 3 = throughput,
+ * a pair of wavefronts per ciphertext exchanging once per CMUX (49-bit field; what auto picks for large batches). */
 int bmi_set_kernel_variant(bmi_ctx *ctx, int variant);
+
+/* Selects the keyswitch kernel: 0 = auto (int8 matrix-core product when the parameter set allows it),
+ * 1 = scalar 96-bit multiply-accumulate kernel. */
+int bmi_set_keyswitch_variant(bmi_ctx *ctx, int variant);
 
 /* bytes of device memory held by the keys (bootstrap key NTT-domain, keyswitch key) */
 int bmi_key_bytes(const bmi_ctx *ctx, uint64_t *bsk_bytes, uint64_t *ksk_bytes);

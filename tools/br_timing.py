@@ -46,6 +46,15 @@ def main():
             for _ in range(reps): eng.keyswitch(d_in, B, d_ks, s)
             e1.record(); torch.cuda.synchronize()
             ks = e0.elapsed_time(e1) / reps
-            print(json.dumps({"B": B, "variant": v, "br_ms": round(ms, 3), "ks_ms": round(ks, 3), "pbs_per_s": round(B / ((ms + ks) * 1e-3), 1), "bit_exact": bool(ok), "q_bits": eng.q_bits}), flush=True)
+            ks_ok = np.array_equal(d_ks[:nchk].cpu().numpy().view(np.uint64), octx.keyswitch(ct[:nchk]))
+            eng.set_keyswitch_variant(1)
+            eng.keyswitch(d_in, B, d_ks, s); torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps): eng.keyswitch(d_in, B, d_ks, s)
+            e1.record(); torch.cuda.synchronize()
+            ks_scalar = e0.elapsed_time(e1) / reps
+            ks_ok = ks_ok and np.array_equal(d_ks.cpu().numpy().view(np.uint64), small)
+            eng.set_keyswitch_variant(0)
+            print(json.dumps({"B": B, "variant": v, "br_ms": round(ms, 3), "ks_ms": round(ks, 3), "ks_scalar_ms": round(ks_scalar, 3), "ks_exact": bool(ks_ok), "pbs_per_s": round(B / ((ms + ks) * 1e-3), 1), "bit_exact": bool(ok), "q_bits": eng.q_bits}), flush=True)
 
 main()
