@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
             PH_MARK(2);
             static_for<0, 8>([&](auto VP) {
                 const double2 xp = reinterpret_cast<const double2 *>(ptile)[VP * 64 + lane];
-                const double s0 = f49::mul(x[2 * VP], bo[VP].x) + f49::mul(xp.x, bp[VP].x);      // lazy: <= 1.6p per level
+                const double s0 = f49::mul(x[2 * VP], bo[VP].x) + f49::mul(xp.x, bp[VP].x);      // lazy: <= 2.6p per level
                 const double s1 = f49::mul(x[2 * VP + 1], bo[VP].y) + f49::mul(xp.y, bp[VP].y);
                 if constexpr (lev == 2) {
                     accn[2 * VP] = s0;
@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
         pair_wait(f_pub_partner, i + 1);
         static_for<0, 8>([&](auto VP) {
             const double2 p = reinterpret_cast<const double2 *>(ptile)[VP * 64 + lane];
-            am[2 * VP] = f49::red(am[2 * VP] + p.x);          // <= 2 * 3 * 0.9p before the reduction
+            am[2 * VP] = f49::red(am[2 * VP] + p.x);          // <= 2 * 3 * 1.3p before the reduction
             am[2 * VP + 1] = f49::red(am[2 * VP + 1] + p.y);
         });
         pair_post(f_ack, i + 1);          // release: the reads above have landed
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(LAT_THREADS)
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const int slot = tid + LAT_THREADS * m, idx = slot & (N - 1);
-            double y = 0.0;  // lazy sum of six products (<= 4.8p), one reduction
+            double y = 0.0;  // lazy sum of six products (<= 7.8p), one reduction
 #pragma unroll
             for (int r = 0; r < 6; r++) y += f49::mul(tiles[r * SCRATCH_WORDS + idx], b[m][r]);
             Y[slot] = f49::red(y);

@@ -6,7 +6,8 @@
 // mantissa bits allow sums of up to 16 reduced values before any reduction (lazy butterflies, lazy MAC).
 //
 // Bounds (p = q): red() returns |r| <= p/2 exactly (the centred residue) for |x| < 4p and |r| < 0.51p up to 2^53;
-// mul(a, b) is exact for |a| < 2^52, |b| <= p/2; for |a| <= 3.5p (what the lazy butterflies produce) |r| < 0.8p.
+// mul(a, b) is exact for |a| < 2^53, |b| <= p/2 and returns |r| <= (0.5 + |a| / 8p) p: the quotient estimate is off by
+// at most 3 |a|/32p and the low product word adds |a|/32p (tools/f64_bounds.py tracks these through the transforms).
 #pragma once
 #include <stdint.h>
 

@@ -3,10 +3,11 @@
 // Same data flow as ntt_wave.hpp (one wavefront per polynomial, 16 coefficients per lane, 1024 = 16 x 16 x 4:
 // register DFT16 -> table twiddle -> LDS transpose -> register DFT16 -> table twiddle -> LDS transpose inside
 // quads -> register DFT4), but the roots are generic (no power-of-two shifts in this field) and the
-// butterflies are LAZY: additions are plain v_add_f64 on centred values, reductions happen only where a bound
-// would otherwise exceed the 53-bit mantissa (one mid-DFT16 reduction) or inside the multiplications.
-// Value bounds, with p = q:  inputs of a DFT16 <= 0.8p;  its outputs <= 3.2p;  mul() inputs <= 3.5p -> outputs
-// <= 0.8p;  DFT4 outputs <= 3.2p.  Evaluation layout identical to ntt_wave.hpp (eval_offset).
+// butterflies are LAZY: additions are plain v_add_f64 on centred values, reductions happen inside the
+// multiplications (mul(a, b) is exact for any |a| < 2^53 and returns |r| <= (0.5 + |a|/8p) p) and at two running
+// sums per DFT16 where a bound would otherwise approach the 53-bit mantissa.  tools/f64_bounds.py is the bound
+// model: forward() takes |x| <= 0.8 p and returns |.| <= 6.9 p; inverse() takes |x| <= 0.51 p and returns
+// |.| <= 10.6 p; callers reduce.  Evaluation layout identical to ntt_wave.hpp (eval_offset).
 #pragma once
 #include <type_traits>
 
@@ -56,7 +57,11 @@ constexpr double psi_pow() {
 }
 
 // 16-point DFT over the register array, root psi^128 (INV: its inverse), natural order in and out, lazy.
-template <bool INV>
+// RED = true reduces the two running sums x[0], x[1] after the second stage; nothing else is reduced explicitly
+// (every twiddled difference is reduced by its multiplication).  tools/f64_bounds.py tracks the magnitudes through
+// the whole pipeline: with RED only in the second DFT16 of forward() and in both of inverse() no value exceeds
+// 10.6 p (the exact-integer limit of a double is 2^53 = 16 p).
+template <bool INV, bool RED>
 __device__ __forceinline__ void dft16(double (&x)[16]) {
     static_for<0, 8>([&](auto I) {  // half = 8, twiddle w16^i = psi^(128 i)
         constexpr int i = I;
@@ -65,12 +70,12 @@ __device__ __forceinline__ void dft16(double (&x)[16]) {
         if constexpr (i == 0) x[i + 8] = d;
         else x[i + 8] = f49::mul(d, psi_pow<INV, 128 * i>());
     });
-    static_for<0, 2>([&](auto B) {  // half = 4, twiddle w8^i = psi^(256 i); sums and untwiddled differences reduced
+    static_for<0, 2>([&](auto B) {  // half = 4, twiddle w8^i = psi^(256 i)
         static_for<0, 4>([&](auto I) {
             constexpr int b = B * 8, i = I;
             const double u = x[b + i] + x[b + i + 4], d = x[b + i] - x[b + i + 4];
-            x[b + i] = f49::red(u);
-            if constexpr (i == 0) x[b + i + 4] = f49::red(d);
+            x[b + i] = (RED && b == 0 && i < 2) ? f49::red(u) : u;
+            if constexpr (i == 0) x[b + i + 4] = d;
             else x[b + i + 4] = f49::mul(d, psi_pow<INV, 256 * i>());
         });
     });
@@ -115,7 +120,7 @@ struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
 
-// Forward transform.  x[j] = a[lane + 64 j] (|.| <= 0.8p) on entry; evaluation layout (|.| <= 3.2p) on exit.
+// Forward transform.  x[j] = a[lane + 64 j] (|.| <= 0.8p) on entry; evaluation layout (|.| <= 6.9p) on exit.
 // mid() runs before the second DFT16, late() before the quad transpose: callers issue global loads there whose
 // latency the rest of the transform hides.
 template <class Mid = NoHook, class Late = NoHook>
@@ -125,7 +130,7 @@ __device__ __forceinline__ void forward(double (&x)[16], int lane, const double 
     static_for<0, 8>([&](auto K) { wa[K] = tw[TW_W1 + K * 64 + lane]; });
     sched_fence();
     static_for<1, 16>([&](auto J) { x[J] = f49::mul(x[J], psi_pow<false, 64 * J>()); });  // psi^(64 j)
-    dft16<false>(x);
+    dft16<false, false>(x);
     static_for<0, 8>([&](auto K) { wb[K] = tw[TW_W1 + (K + 8) * 64 + lane]; });
     sched_fence();
     static_for<0, 8>([&](auto K) { x[K] = f49::mul(x[K], wa[K]); });
@@ -139,7 +144,7 @@ __device__ __forceinline__ void forward(double (&x)[16], int lane, const double 
     static_for<1, 8>([&](auto V) { wa[V] = tw[TW_W2 + V * 4 + t]; });
     mid();
     sched_fence();
-    dft16<false>(x);
+    dft16<false, true>(x);
     static_for<0, 8>([&](auto V) { wb[V] = tw[TW_W2 + (V + 8) * 4 + t]; });
     sched_fence();
     x[0] = f49::red(x[0]);
@@ -165,7 +170,7 @@ __device__ __forceinline__ void forward(double (&x)[16], int lane, const double 
     dft4<false, 12>(x);
 }
 
-// Inverse transform (includes 1/N): evaluation layout in (|.| <= 0.51p), x[j] = a[lane + 64 j] out (|.| <= 3.2p).
+// Inverse transform (includes 1/N): evaluation layout in (|.| <= 0.51p), x[j] = a[lane + 64 j] out (|.| <= 10.6p).
 __device__ __forceinline__ void inverse(double (&x)[16], int lane, const double *tw, double *scratch) {
     const int k1 = lane >> 2, t = lane & 3;
     double *row = scratch + k1 * ROW;
@@ -193,7 +198,7 @@ __device__ __forceinline__ void inverse(double (&x)[16], int lane, const double 
     x[0] = f49::red(x[0]);
     static_for<1, 8>([&](auto V) { x[V] = f49::mul(x[V], wa[V]); });
     static_for<0, 8>([&](auto V) { x[V + 8] = f49::mul(x[V + 8], wb[V]); });
-    dft16<true>(x);
+    dft16<true, true>(x);
     wave_sync();
     static_for<0, 16>([&](auto U) { row[t + 4 * U] = x[U]; });
     wave_sync();
@@ -204,7 +209,7 @@ __device__ __forceinline__ void inverse(double (&x)[16], int lane, const double 
     sched_fence();
     static_for<0, 8>([&](auto K) { x[K] = f49::mul(y[K], wa[K]); });
     static_for<0, 8>([&](auto K) { x[K + 8] = f49::mul(y[K + 8], wb[K]); });
-    dft16<true>(x);
+    dft16<true, true>(x);
     static_for<1, 16>([&](auto J) { x[J] = f49::mul(x[J], psi_pow<true, 64 * J>()); });
 }
 
