@@ -155,7 +155,7 @@ def main():
                    "derived_reference_pbs_per_s_64core_cpu": "35-69 (derived, BASELINE.md §1)"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_blind_rotate_tp" if eng.q_bits == 64 else "k_blind_rotate_tp49", "kernel_ms": br_ms,
+                     "kernel": "k_blind_rotate_tp" if eng.q_bits == 64 else "k_blind_rotate_tpx49", "kernel_ms": br_ms,
                      "algorithmic_bytes_per_pbs": BSK_BYTES_PER_PBS,
                      "alu": {"modmul_per_s": MODMUL_PER_PBS * B / (br_ms * 1e-3), "modmul_per_pbs": MODMUL_PER_PBS}},
     }

@@ -109,7 +109,7 @@ struct bmi_ctx {
     uint32_t *d_io_ids = nullptr;
     size_t io_cap = 0;
     int variant = 0;
-    uint32_t lat_threshold = 768;  // 3 rounds of 256 one-workgroup PBS still beat one round of the wave-pair kernel
+    uint32_t lat_threshold = 512;  // 2 rounds of 256 one-workgroup PBS (11.2 ms) tie with one round of the wave-pair kernel (11.3 ms)
     void *d_ks_partial = nullptr;
     size_t ks_partial_bytes = 0;
     // keyswitch on the matrix cores: limb-wise key (per keygen), digit matrix and int32 sums (growable scratch)

@@ -107,6 +107,53 @@ def test_keyswitch_bit_exact(eng, ora):
     assert list(to.decode(to.lwe_phase(sk_small, got[ok]), eng.delta_log())) == list(msgs[ok])
 
 
+def test_keyswitch_matrix_core_path_bit_exact(eng, ora):
+    """Batches >= 64 take the int8 matrix-core keyswitch (ks_mfma.hpp): ragged tile counts, extreme words, and the
+    scalar kernel on the same inputs must all agree with the oracle bit for bit."""
+    to, P, ctx, sk_small, _, _, _ = ora
+    rng = np.random.default_rng(14)
+    Q = eng.modulus
+    for count in (64, 97):   # 97 = 3 full tiles of 32 + 1
+        msgs = rng.integers(-8, 8, count)
+        ct = eng.encrypt(msgs, eng.delta_log())
+        ct[3, :1024] = rand_q(rng, 1024, Q)
+        ct[4, :1024] = Q - 1
+        ct[5, :1024] = Q // 2
+        ct[6, :1024] = Q // 2 + 1
+        ct[7, :] = 0
+        ct[count - 1, :1024] = rand_q(rng, 1024, Q)   # the ragged last row
+        want = ctx.keyswitch(ct)
+        got = eng.keyswitch_host(ct)
+        assert np.array_equal(got, want), count
+        eng.set_keyswitch_variant(1)
+        try:
+            assert np.array_equal(eng.keyswitch_host(ct), want), count
+        finally:
+            eng.set_keyswitch_variant(0)
+        ok = [0, 1, 2] + list(range(8, count - 1))
+        assert list(to.decode(to.lwe_phase(sk_small, got[ok]), eng.delta_log())) == list(msgs[ok])
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3], ids=["pair_per_level", "latency", "pair_per_cmux"])
+def test_blind_rotate_every_kernel_variant(eng, ora, variant):
+    """7 ciphertexts: ragged against the 2 (variant 1) and 4 (variant 3) ciphertexts per workgroup."""
+    to, P, ctx, _, sk_big, _, _ = ora
+    rng = np.random.default_rng(15)
+    tables = [np.arange(-8, 8), rng.integers(-8, 8, 16)]
+    ids = [eng.lut_register(t, 4, eng.delta_log()) for t in tables]
+    tvs = np.stack([eng.lut_get(i) for i in ids])
+    msgs = rng.integers(-8, 8, 6)
+    small = ctx.keyswitch(eng.encrypt(msgs, eng.delta_log()))
+    small = np.concatenate([small, rand_q(rng, (1, 631), eng.modulus)])
+    sel = np.array([0, 1, 0, 1, 0, 1, 1], np.uint32)
+    eng.set_kernel_variant(variant)
+    try:
+        got = eng.blind_rotate_host(small, np.array(ids, np.uint32)[sel])
+    finally:
+        eng.set_kernel_variant(0)
+    assert np.array_equal(got, ctx.blind_rotate(small, tvs, sel))
+
+
 def test_blind_rotate_bit_exact(eng, ora):
     to, P, ctx, _, sk_big, _, _ = ora
     rng = np.random.default_rng(5)
@@ -209,3 +256,39 @@ def test_pbs_device_pointers_and_noise_budget(eng, ora):
     Q, dl = eng.modulus, eng.delta_log()
     err = np.array([((int(x) - (int(m) << dl)) + Q // 2) % Q - Q // 2 for x, m in zip(ph, msgs)], dtype=np.float64)
     assert np.max(np.abs(err)) < 2.0 ** (dl - 9)  # half a box is 2^(dl-1)
+
+
+@pytest.mark.parametrize("q_bits", [64, 49])
+def test_other_parameter_shape_bit_exact(q_bits):
+    """n = 97 (98 output columns: a ragged column block in the matrix-core keyswitch) with a 5 x 6-bit keyswitch
+    decomposition: keyswitch (both kernels), every blind-rotation kernel and the fused PBS against the oracle."""
+    from bmi_amd import tfhe
+    from oracle import tfhe_oracle as to
+    kw = dict(n=97, ks_levels=5, ks_base_log=6)
+    e = tfhe.Engine(tfhe.default_params(q_bits=q_bits, **kw))
+    try:
+        e.keygen(SEED + 1)
+        sk_small, sk_big, bsk, ksk = e.export_keys()
+        P = to.default_params(q_bits=q_bits, **kw)
+        ctx = to.Ctx(P, bsk, ksk)
+        rng = np.random.default_rng(16)
+        dl = e.delta_log()
+        msgs = rng.integers(-8, 8, 70)
+        ct = e.encrypt(msgs, dl)
+        ct[1, :1024] = rand_q(rng, 1024, e.modulus)
+        want_small = ctx.keyswitch(ct)
+        assert np.array_equal(e.keyswitch_host(ct), want_small)
+        e.set_keyswitch_variant(1)
+        assert np.array_equal(e.keyswitch_host(ct), want_small)
+        e.set_keyswitch_variant(0)
+        lid = e.lut_register(rng.integers(-8, 8, 16), 4, dl)
+        tv = e.lut_get(lid)[None, :]
+        ids = np.full(5, lid, np.uint32)
+        want = ctx.blind_rotate(want_small[:5], tv, np.zeros(5, np.uint32))
+        for variant in (0, 1, 2, 3):
+            e.set_kernel_variant(variant)
+            assert np.array_equal(e.blind_rotate_host(want_small[:5], ids), want), variant
+        e.set_kernel_variant(0)
+        assert np.array_equal(e.pbs_host(ct[:5], ids), want)
+    finally:
+        e.close()
