@@ -50,7 +50,11 @@ def main():
                          "default: the library's default")
     ap.add_argument("--no-inverse", action="store_true", help="skip the encrypted-inverse wall-clock leg")
     ap.add_argument("--inverse-sizes", default="2,3", help="matrix sizes of the encrypted-inverse leg (N=1, rank 0); "
-                    "4 adds ~45 s (BASELINE configs 2, 3, 4)")
+                    "4 adds ~20 s (BASELINE configs 2, 3, 4)")
+    ap.add_argument("--inverse-sharded", action="store_true",
+                    help="N > 1 only (opt-in): also run the encrypted-inverse leg with its wide levels split across the "
+                         "ranks (executor.py; one RCCL all-gather per split level)")
+    ap.add_argument("--shard-threshold", type=int, default=1024, help="narrowest level that is split across ranks")
     args = ap.parse_args()
 
     import torch
@@ -188,6 +192,12 @@ def main():
             res["config"]["encrypted_inverse_wall_clock"] = inverse_bench.run(eng, sizes)
         except Exception as e:  # reported, never hidden
             res["config"]["encrypted_inverse_wall_clock"] = {"error": repr(e)}
+
+    if args.inverse_sharded and world > 1:
+        from bmi_amd import inverse_bench
+        sizes = tuple(int(x) for x in args.inverse_sizes.split(",") if x)
+        rep = inverse_bench.run(eng, sizes, shard_threshold=args.shard_threshold)   # collective: every rank calls it
+        res["config"]["encrypted_inverse_wall_clock_sharded"] = rep
 
     if rank == 0:
         print(json.dumps(res))

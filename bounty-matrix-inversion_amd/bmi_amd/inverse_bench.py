@@ -13,14 +13,16 @@ from .main import EncryptedMatrixInversion
 CONFIGS = {2: (20, 8), 3: (30, 12), 4: (40, 16), 8: (48, 16)}
 
 
-def run(engine, sizes=(2, 3)):
+def run(engine, sizes=(2, 3), shard_threshold=1024):
+    """With torch.distributed initialised on several ranks every rank must call this (the wide levels are split
+    across the ranks' GPUs, executor.py); every rank returns the same report."""
     out = {}
     for n in sizes:
         ln, ints = CONFIGS[n]
         np.random.seed(1234 + n)
         M = np.random.randn(n, n) * 100
         t0 = time.time()
-        emi = EncryptedMatrixInversion(n, None, 2, ln, ints, False, False, engine=engine)
+        emi = EncryptedMatrixInversion(n, None, 2, ln, ints, False, False, engine=engine, shard_threshold=shard_threshold)
         emi._executor()
         t_compile = time.time() - t0
         q, s = emi.quantize(M)
@@ -41,6 +43,7 @@ def run(engine, sizes=(2, 3)):
             "len": ln, "ints": ints, "evaluate_s": round(t_eval, 3), "compile_s": round(t_compile, 3),
             "encrypt_s": round(t_enc, 3), "decrypt_s": round(t_dec, 3), "pbs": summ["pbs"], "depth": summ["depth"],
             "ms_per_level": round(t_eval / max(summ["depth"], 1) * 1e3, 3),
+            "ranks": emi._executor().world, "sharded_levels": emi._executor().sharded_levels,
             "matches_plaintext_circuit": bool(np.array_equal(dec, sim)),
             "max_abs_err_vs_numpy": float(np.max(np.abs(emi.dequantize(dec) - np.linalg.inv(M)))),
         }

@@ -36,7 +36,10 @@ class EncryptedMatrixInversion:
     shape: Tuple[int, int]
 
     def __init__(self, n, sampler=None, qfloat_base=2, qfloat_len=32, qfloat_ints=16, true_division=False,
-                 tensorize=False, engine=None, device=0):
+                 tensorize=False, engine=None, device=0, shard_threshold=1024):
+        """The reference's seven arguments (main.py:17-36), then: engine / device (the GPU context to use) and
+        shard_threshold (with torch.distributed initialised on several ranks, levels at least this wide are split
+        across the ranks' GPUs, see executor.py)."""
         self.shape = (n, n)
         self.qfloat_base, self.qfloat_len, self.qfloat_ints = qfloat_base, qfloat_len, qfloat_ints
         self.true_division, self.tensorize = true_division, tensorize
@@ -50,6 +53,7 @@ class EncryptedMatrixInversion:
         self.trace_seconds = time.time() - t0
         self.engine = engine
         self.device = device
+        self.shard_threshold = shard_threshold
         self._exec = None
 
     # ---- key generation / engine -------------------------------------------------------------------
@@ -65,7 +69,7 @@ class EncryptedMatrixInversion:
     def _executor(self):
         if self._exec is None:
             from .executor import Executor
-            self._exec = Executor(self.circuit, self._engine())
+            self._exec = Executor(self.circuit, self._engine(), shard_threshold=self.shard_threshold)
         return self._exec
 
     # ---- the reference's six methods -----------------------------------------------------------------

@@ -26,6 +26,20 @@
 #define BMI_TP_CTS 2  // ciphertexts (= wavefront pairs) per workgroup in the throughput blind rotation
 #endif
 
+// hipFuncSetAttribute acts on the current device only: remember per kernel which devices have been configured
+// (several contexts on several GPUs may live in one process).
+#include <atomic>
+inline int set_max_dynamic_lds(const void *kernel, size_t bytes, std::atomic<uint64_t> &done_devices) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 64 && ((done_devices.load() >> dev) & 1)) return 0;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 64) done_devices.fetch_or((uint64_t)1 << dev);
+    return 0;
+}
+
 namespace bmi {
 using gl::i64;
 using gl::u64;

@@ -359,14 +359,9 @@ int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const 
 int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const u64 *bsk,
                             const u64 *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
     if (count == 0) return 0;
-    static bool attr_set = false;
+    static std::atomic<uint64_t> configured{0};
     const size_t lds = (size_t)LAT_LDS_WORDS * sizeof(u64);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate_lat),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k_blind_rotate_lat), lds, configured)) return rc;
     hipLaunchKernelGGL(k_blind_rotate_lat, dim3(count), dim3(LAT_THREADS), lds, s, small_cts, lut_ids, luts, bsk, g_tw, out,
                        count, n);
     BMI_LAUNCH_CHECK();

@@ -418,10 +418,12 @@ __global__ void __launch_bounds__(LAT_THREADS)
     }
     __syncthreads();
 
+    PH_DECL();
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t a_t = at[i];
         if (a_t == 0) continue;  // uniform over the workgroup
         const double *bsk_i = bsk + (size_t)i * 12 * N;
+        PH_MARK(7);
         double b[4][6];
 #pragma unroll
         for (int m = 0; m < 4; m++) {
@@ -445,7 +447,9 @@ __global__ void __launch_bounds__(LAT_THREADS)
             wave_sync();
             static_for<0, 16>([&](auto V) { tile[eval_offset(lane, V)] = x[V]; });
         }
+        PH_MARK(0);
         __syncthreads();
+        PH_MARK(1);
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const int slot = tid + LAT_THREADS * m, idx = slot & (N - 1);
@@ -454,7 +458,9 @@ __global__ void __launch_bounds__(LAT_THREADS)
             for (int r = 0; r < 6; r++) y += f49::mul(tiles[r * SCRATCH_WORDS + idx], b[m][r]);
             Y[slot] = f49::red(y);
         }
+        PH_MARK(2);
         __syncthreads();
+        PH_MARK(3);
         if (wave < 2) {
             double x[16];
             static_for<0, 16>([&](auto V) { x[V] = Y[wave * N + eval_offset(lane, V)]; });
@@ -463,8 +469,14 @@ __global__ void __launch_bounds__(LAT_THREADS)
             double *a = acc + wave * N;
             static_for<0, 16>([&](auto J) { a[lane + 64 * J] = f49::red(a[lane + 64 * J] + x[J]); });
         }
+        PH_MARK(4);
         __syncthreads();
+        PH_MARK(5);
     }
+#ifdef BMI_PHASE_PROF
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k_ = 0; k_ < 8; k_++) g_phase[wave * 8 + k_] = ph_[k_];
+#endif
     u64 *o = out + (size_t)ct * (N + 1);
     for (int m = tid; m < N; m += LAT_THREADS) {
         if (m == 0) {
@@ -543,15 +555,10 @@ int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const 
 int launch_blind_rotate_tpx(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
                             const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
     if (count == 0) return 0;
-    static bool attr_set = false;
+    static std::atomic<uint64_t> configured{0};
     const size_t lds = (size_t)TPX_LDS_WORDS * sizeof(double);
     auto kern = k_blind_rotate_tpx49<BMI_TPX49_PF>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
     hipLaunchKernelGGL(kern, dim3((count + TPX_CTS - 1) / TPX_CTS), dim3(128 * TPX_CTS), lds, s, small_cts, lut_ids, luts,
                        bsk, g_tw, out, count, n);
     BMI49_LAUNCH_CHECK();
@@ -561,14 +568,9 @@ int launch_blind_rotate_tpx(const u64 *small_cts, const uint32_t *lut_ids, const
 int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
                             const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
     if (count == 0) return 0;
-    static bool attr_set = false;
+    static std::atomic<uint64_t> configured{0};
     const size_t lds = (size_t)LAT_LDS_WORDS * sizeof(double);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_blind_rotate_lat49),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k_blind_rotate_lat49), lds, configured)) return rc;
     hipLaunchKernelGGL(k_blind_rotate_lat49, dim3(count), dim3(LAT_THREADS), lds, s, small_cts, lut_ids, luts, bsk, g_tw,
                        out, count, n);
     BMI49_LAUNCH_CHECK();

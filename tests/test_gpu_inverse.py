@@ -111,3 +111,44 @@ def test_encrypted_4x4_inverse_matches_reference_golden(eng):
     out = emi.decrypt(res)
     assert out.tolist() == c["out"]
     print(f"encrypted 4x4 (len 40, ints 16): {wall:.1f} s, {emi.circuit.summary()}")
+
+
+def _two_rank_worker(rank, world, port, out_dir, tag):
+    """one of two processes sharing cuda:0 (the GPU box has one GPU): gloo stands in for RCCL, which refuses two ranks
+    on one device; the level split, the padded store regions and the gather are the code the N-GPU run uses."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bmi_amd import tfhe
+    from bmi_amd.main import EncryptedMatrixInversion
+    c = next(x for x in load("inverse.json") if x["tag"] == tag)
+    eng = tfhe.Engine()
+    eng.keygen(0x5EED)                                   # same seed on every rank: replicated keys
+    emi = EncryptedMatrixInversion(2, None, 2, c["len"], c["ints"], False, False, engine=eng, shard_threshold=48)
+    M = np.array(c["M"]).reshape(2, 2)
+    q, s = emi.quantize(M)
+    out = emi.decrypt(emi.evaluate(emi.encrypt(q, s)))
+    ex = emi._executor()
+    np.save(os.path.join(out_dir, f"out{rank}.npy"), out)
+    np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array([ex.sharded_levels, len(ex.levels), ex.world]))
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+def test_two_rank_sharded_encrypted_inverse(tmp_path):
+    """SURVEY 8e on the inverse itself: levels >= 48 wide are split over two ranks, narrower ones replicated;
+    both ranks must decrypt the reference's digits."""
+    import socket
+    import torch.multiprocessing as mp
+    tag = "baseline_n2_len20_ints8"
+    c = next(x for x in load("inverse.json") if x["tag"] == tag)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), tag), nprocs=2, join=True)
+    for r in range(2):
+        assert np.load(tmp_path / f"out{r}.npy").tolist() == c["out"], r
+    sharded, total, world = np.load(tmp_path / "meta0.npy")
+    assert world == 2 and 0 < sharded < total

@@ -8,6 +8,7 @@ from bmi_amd import tfhe
 tfhe.LIB_PATH = tfhe.LIB_PATH.replace("libbmi_tfhe.so", "libbmi_tfhe_prof.so")
 
 NAMES = ["rotate+decompose", "forward NTT x3", "publish+key loads+barrier", "MAC x3", "barrier 2", "inverse+update", "-", "loop head"]
+LAT_NAMES = ["key loads issue + decompose + forward (waves 0-5)", "barrier 1 wait", "MAC", "barrier 2 wait", "inverse + update (waves 0-1)", "barrier 3 wait", "-", "loop head"]
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
@@ -21,7 +22,8 @@ def main():
     d_small = torch.empty((B, 631), dtype=torch.int64, device=dev)
     d_ids = torch.full((B,), lid, dtype=torch.int32, device=dev)
     d_out = torch.empty((B, 1025), dtype=torch.int64, device=dev)
-    eng.set_kernel_variant(1)
+    variant = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # 1: pair kernel (4 waves), 2: latency kernel (8 waves)
+    eng.set_kernel_variant(variant)
     eng.keyswitch(d_in, B, d_small, s)
     for _ in range(2):
         eng.blind_rotate(d_small, d_ids, B, d_out, s)
@@ -30,9 +32,9 @@ def main():
     rc = tfhe.load_library().bmi_debug_phase_prof(buf)
     assert rc == 0, rc
     a = np.array(buf[:], dtype=np.float64).reshape(8, 8)
-    for w in range(4):
+    for w in range(8 if variant == 2 else 4):
         tot = a[w].sum()
         print(json.dumps({"wave": w, "total_cycles": tot, "per_cmux": round(tot / 630, 1),
-                          "phases_pct": {n: round(100 * v / tot, 1) for n, v in zip(NAMES, a[w]) if n != "-"}}))
+                          "phases_cycles_per_cmux": {n: round(v / 630, 0) for n, v in zip(LAT_NAMES if variant == 2 else NAMES, a[w]) if n != "-"}}))
 
 main()
