@@ -16,6 +16,7 @@
 #include "bmi_internal.hpp"
 #include "field49.hpp"
 #include "ntt_wave.hpp"
+#include "ntt_half_f64.hpp"
 #include "ntt_wave_f64.hpp"
 
 using gl::i64;
@@ -99,6 +100,7 @@ struct bmi_ctx {
     u64 seed = 0, enc_counter = 0;
     std::vector<u64> sk_small, sk_big, bsk_std, ksk;
     void *d_bsk = nullptr, *d_tw = nullptr, *d_luts = nullptr;  // u64 words (Goldilocks) or f64 words (49-bit field)
+    double *d_tw_half = nullptr, *d_bsk_lat = nullptr;          // 49-bit field: tables and key copy of the split-transform latency kernel
     u64 *d_ksk = nullptr, *d_ks_bias = nullptr;
     uint32_t n_luts = 0, lut_cap = 0;
     std::vector<std::vector<u64>> luts_host;
@@ -190,6 +192,31 @@ std::vector<double> to_centred_doubles(const std::vector<u64> &v) {
     return d;
 }
 
+// Tables of the two-wave half transform (ntt_half_f64.hpp, tools/ntt_half_model.py), canonical integers mod q
+std::vector<u64> build_twiddles_half(const Fq &f, u64 psi, u64 psi_inv) {
+    using namespace ntth;
+    std::vector<u64> tw(HT_WORDS);
+    const u64 inv1024 = f.pow(1024 % f.q, f.q - 2);
+    for (int k1 = 0; k1 < 8; k1++)
+        for (int l = 0; l < 64; l++) {
+            const u64 e = (u64)2 * (2 * k1 + 1) * l;
+            tw[HT_W1 + k1 * 64 + l] = f.pow(psi, e);
+            tw[HT_W1I + k1 * 64 + l] = f.mul(f.pow(psi_inv, e), inv1024);
+        }
+    for (int k2a = 0; k2a < 8; k2a++)
+        for (int l0 = 0; l0 < 8; l0++) {
+            tw[HT_W2 + k2a * 8 + l0] = f.pow(psi, (u64)32 * l0 * k2a);
+            tw[HT_W2I + k2a * 8 + l0] = f.pow(psi_inv, (u64)32 * l0 * k2a);
+        }
+    for (int reg = 0; reg < 8; reg++)
+        for (int lane = 0; lane < 64; lane++) {
+            const u64 e = (u64)2 * kk_of(lane, reg) + 1;
+            tw[HT_T + reg * 64 + lane] = f.pow(psi, e);
+            tw[HT_TI + reg * 64 + lane] = f.pow(psi_inv, e);
+        }
+    return tw;
+}
+
 bool params_supported(const bmi_params &P, std::string &why) {
     if (P.log_N != 10) { why = "only log_N = 10 (N = 1024) has a HIP kernel in this build"; return false; }
     if (P.k != 1) { why = "only k = 1 has a HIP kernel in this build"; return false; }
@@ -252,6 +279,12 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
         if (hipMemcpy(c->d_tw, src, tw.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(twiddles) failed");
     }
+    if (c->f64()) {
+        const std::vector<double> th = to_centred_doubles(build_twiddles_half(c->f, nttf::PSI_U, nttf::PSI_INV_U));
+        if (hipMalloc(&c->d_tw_half, th.size() * 8) != hipSuccess) return bail("hipMalloc(half-transform twiddles) failed");
+        if (hipMemcpy(c->d_tw_half, th.data(), th.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+            return bail("hipMemcpy(half-transform twiddles) failed");
+    }
     c->lut_cap = 1024;
     if (hipMalloc(&c->d_luts, (size_t)c->lut_cap * c->N * 8) != hipSuccess) return bail("hipMalloc(luts) failed");
     *out = c;
@@ -263,7 +296,8 @@ void bmi_ctx_destroy(bmi_ctx *c) {
     (void)hipSetDevice(c->device);
     for (void *p : {c->d_bsk, (void *)c->d_ksk, (void *)c->d_ks_bias, c->d_tw, c->d_luts, (void *)c->d_small,
                     (void *)c->d_io_a, (void *)c->d_io_b, (void *)c->d_io_ids, c->d_ks_partial,
-                    (void *)c->d_ks_limbs, (void *)c->d_ks_digits, (void *)c->d_ks_sums})
+                    (void *)c->d_ks_limbs, (void *)c->d_ks_digits, (void *)c->d_ks_sums, (void *)c->d_tw_half,
+                    (void *)c->d_bsk_lat})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -344,6 +378,14 @@ int bmi_keygen(bmi_ctx *c, uint64_t seed) {
     int rc = c->f64() ? bmi49::launch_bsk_to_ntt(d_tmp, (double *)c->d_bsk, (const double *)c->d_tw, (uint32_t)(bsk_words / N), c->stream)
                       : bmi::launch_bsk_to_ntt(d_tmp, (u64 *)c->d_bsk, (const u64 *)c->d_tw, (uint32_t)(bsk_words / N), c->stream);
     if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_ntt launch failed"); }
+    if (c->f64()) {  // second copy of the key, in the slot order of the split-transform latency kernel
+        if (!c->d_bsk_lat && hipMalloc(&c->d_bsk_lat, bsk_words * 8) != hipSuccess) {
+            (void)hipFree(d_tmp);
+            return fail(c, -2, "hipMalloc(latency-kernel key) failed");
+        }
+        rc = bmi49::launch_bsk_to_lat(d_tmp, c->d_bsk_lat, c->d_tw_half, (uint32_t)(bsk_words / N), c->stream);
+        if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat launch failed"); }
+    }
     HIP_OK(c, hipStreamSynchronize(c->stream));
     HIP_OK(c, hipFree(d_tmp));
     const size_t ksk_rows = (size_t)k * N * lk;
@@ -495,7 +537,7 @@ int bmi_set_keyswitch_variant(bmi_ctx *c, int variant) {
 
 int bmi_set_kernel_variant(bmi_ctx *c, int variant) {
     if (!c) return -1;
-    if (variant < 0 || variant > 3) return fail(c, -1, "variant must be 0..3");
+    if (variant < 0 || variant > 4) return fail(c, -1, "variant must be 0..4");
     c->variant = variant;
     return 0;
 }
@@ -587,7 +629,8 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     int rc;
     if (c->f64()) {
         const double *luts = (const double *)c->d_luts, *bsk = (const double *)c->d_bsk, *tw = (const double *)c->d_tw;
-        rc = latency ? bmi49::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
+        rc = c->variant == 4 ? bmi49::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
+             : latency ? bmi49::launch_blind_rotate_lat2(d_small, d_lut_ids, luts, c->d_bsk_lat, c->d_tw_half, d_out, count, c->P.n, (hipStream_t)stream)
              : c->variant == 1 ? bmi49::launch_blind_rotate_tp(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
                      : bmi49::launch_blind_rotate_tpx(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream);
     } else {

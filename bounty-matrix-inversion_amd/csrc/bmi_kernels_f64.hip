@@ -12,6 +12,7 @@
 #include "bmi_internal.hpp"
 #include "ks_lincomb.hpp"
 #include "ks_mfma.hpp"
+#include "ntt_half_f64.hpp"
 #include "ntt_wave_f64.hpp"
 
 using f49::i64;
@@ -488,6 +489,143 @@ __global__ void __launch_bounds__(LAT_THREADS)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// LATENCY kernel, second form: one workgroup of 16 wavefronts per ciphertext, every transform split over two
+// wavefronts by parity (ntt_half_f64.hpp).  Per CMUX:
+//   A  wavefronts 0..11  = (input polynomial c, level, parity): rotate/decompose 512 coefficients, half transform -> tile
+//   B  all 1,024 threads = (output polynomial o, slot p): form A_lo = E + O', A_hi = E - O' of the six digit transforms
+//      on the fly, multiply with the key (own copy in slot order, k_bsk_to_lat49), write S = Y_lo + Y_hi and Y_lo - Y_hi
+//   C  wavefronts 0..3   = (o, parity): inverse half transform, accumulator update
+// The accumulator is kept de-interleaved in LDS (acc[c][parity][512]) so that every access of a wavefront is contiguous.
+constexpr int L2_THREADS = 1024;
+constexpr int L2_LDS_WORDS = ntth::HT_WORDS + 2 * N + 12 * ntth::HSCRATCH + 2 * N + 160;
+
+__global__ void __launch_bounds__(256) k_bsk_to_lat49(const u64 *__restrict__ std_polys, double *__restrict__ lat_polys,
+                                                      const double *__restrict__ g_tw_h, uint32_t n_polys) {
+    __shared__ double lds[ntth::HT_WORDS + 4 * ntth::HSCRATCH];
+    for (int i = threadIdx.x; i < ntth::HT_WORDS; i += blockDim.x) lds[i] = g_tw_h[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = wave & 1;
+    const uint32_t poly = blockIdx.x * 2 + (wave >> 1);   // two polynomials per workgroup, two wavefronts each
+    double *tile = lds + ntth::HT_WORDS + wave * ntth::HSCRATCH;
+    if (poly < n_polys) {
+        double x[8];
+        static_for<0, 8>([&](auto J) { x[J] = f49::to_f(std_polys[(size_t)poly * N + 2 * (lane + 64 * J) + h]); });
+        if (h) ntth::forward_half<true>(x, lane, lds, tile);
+        else ntth::forward_half<false>(x, lane, lds, tile);
+        wave_sync();
+        static_for<0, 8>([&](auto R) { tile[R * 64 + lane] = x[R]; });
+    }
+    __syncthreads();
+    if (poly < n_polys) {
+        const double *te = lds + ntth::HT_WORDS + (wave & ~1) * ntth::HSCRATCH, *to = te + ntth::HSCRATCH;
+        double *o = lat_polys + (size_t)poly * N;
+        static_for<0, 4>([&](auto Q4) {
+            const int p = (h * 4 + Q4) * 64 + lane;   // the pair's 128 lanes cover the 512 slots in 4 steps
+            const double e = te[p], od = to[p];
+            o[p] = f49::red(e + od);
+            o[ntth::HALF + p] = f49::red(e - od);
+        });
+    }
+}
+
+__global__ void __launch_bounds__(L2_THREADS)
+    k_blind_rotate_lat2_49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
+                           const double *__restrict__ luts, const double *__restrict__ bsk_lat,
+                           const double *__restrict__ g_tw_h, u64 *__restrict__ out, uint32_t count, uint32_t n) {
+    extern __shared__ double lds[];
+    double *acc = lds + ntth::HT_WORDS;              // [2 components][2 parities][512], centred (<= q/2 + 2)
+    double *tiles = acc + 2 * N;                     // [12][HSCRATCH]
+    double *SD = tiles + 12 * ntth::HSCRATCH;        // [2 outputs][sum, difference][512]
+    uint16_t *at = reinterpret_cast<uint16_t *>(SD + 2 * N);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < ntth::HT_WORDS; i += L2_THREADS) lds[i] = g_tw_h[i];
+    const uint32_t ct = blockIdx.x;
+    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
+    for (uint32_t i = tid; i <= n; i += L2_THREADS) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 1);
+    __syncthreads();
+    {
+        const double *tv = luts + (size_t)lut_ids[ct] * N;
+        const uint32_t bt = at[n];
+        const uint32_t nn = tid;  // coefficient index
+        const uint32_t e = (nn + bt) & (2 * N - 1);
+        const double v = tv[e & (N - 1)];
+        acc[(nn & 1) * ntth::HALF + (nn >> 1)] = 0.0;
+        acc[N + (nn & 1) * ntth::HALF + (nn >> 1)] = (e & N) ? -v : v;
+    }
+    __syncthreads();
+    const int mo = tid >> 9, mp = tid & 511;  // phase B: output polynomial, slot
+
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t a_t = at[i];
+        if (a_t == 0) continue;  // uniform over the workgroup
+        const double *bi = bsk_lat + (size_t)i * 12 * N;
+        double b[6][2];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            b[r][0] = bi[(size_t)(r * 2 + mo) * N + mp];
+            b[r][1] = bi[(size_t)(r * 2 + mo) * N + ntth::HALF + mp];
+        }
+        if (wave < 12) {
+            const int c = wave / 6, lev = (wave % 6) >> 1, h = wave & 1;
+            const double *ac = acc + c * N;
+            double x[8];
+            static_for<0, 8>([&](auto J) {
+                const uint32_t m = lane + 64 * J;
+                const uint32_t e = (2 * m + h + 2 * N - a_t) & (2 * N - 1);
+                const uint32_t n2 = e & (N - 1);
+                double v = ac[(n2 & 1) * ntth::HALF + (n2 >> 1)];
+                v = (e & N) ? -v : v;
+                x[J] = digit_of(__builtin_rint(f49::red(v - ac[h * ntth::HALF + m]) * 0x1p-4), lev);
+            });
+            double *tile = tiles + wave * ntth::HSCRATCH;
+            if (h) ntth::forward_half<true>(x, lane, lds, tile);
+            else ntth::forward_half<false>(x, lane, lds, tile);
+            wave_sync();
+            static_for<0, 8>([&](auto R) { tile[R * 64 + lane] = x[R]; });
+        }
+        __syncthreads();
+        {
+            double ylo = 0.0, yhi = 0.0;  // lazy sums of six products (<= 10.2 q)
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const double e = tiles[(2 * r) * ntth::HSCRATCH + mp], od = tiles[(2 * r + 1) * ntth::HSCRATCH + mp];
+                ylo += f49::mul(e + od, b[r][0]);
+                yhi += f49::mul(e - od, b[r][1]);
+            }
+            ylo = f49::red(ylo);
+            yhi = f49::red(yhi);
+            SD[(mo * 2 + 0) * ntth::HALF + mp] = ylo + yhi;
+            SD[(mo * 2 + 1) * ntth::HALF + mp] = ylo - yhi;
+        }
+        __syncthreads();
+        if (wave < 4) {
+            const int o = wave >> 1, h = wave & 1;
+            double x[8];
+            static_for<0, 8>([&](auto R) { x[R] = SD[(o * 2 + h) * ntth::HALF + R * 64 + lane]; });
+            double *tile = tiles + wave * ntth::HSCRATCH;
+            if (h) ntth::inverse_half<true>(x, lane, lds, tile);
+            else ntth::inverse_half<false>(x, lane, lds, tile);
+            double *ao = acc + o * N + h * ntth::HALF;
+            static_for<0, 8>([&](auto J) { ao[lane + 64 * J] = f49::red(ao[lane + 64 * J] + x[J]); });
+        }
+        __syncthreads();
+    }
+    u64 *o = out + (size_t)ct * (N + 1);
+    {
+        const uint32_t nn = tid;
+        const double a0 = acc[(nn & 1) * ntth::HALF + (nn >> 1)];
+        if (nn == 0) {
+            o[0] = f49::to_u(a0);
+            o[N] = f49::to_u(acc[N]);
+        } else {
+            o[N - nn] = f49::to_u(-a0);
+        }
+    }
+}
+
 struct Field49 {
     static __device__ __forceinline__ void digits(u64 a, uint32_t levels, uint32_t base_log, unsigned char *d) {
         // centred lift, every rounding round-half-to-even, digits in [-B/2, B/2]
@@ -561,6 +699,25 @@ int launch_blind_rotate_tpx(const u64 *small_cts, const uint32_t *lut_ids, const
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
     hipLaunchKernelGGL(kern, dim3((count + TPX_CTS - 1) / TPX_CTS), dim3(128 * TPX_CTS), lds, s, small_cts, lut_ids, luts,
                        bsk, g_tw, out, count, n);
+    BMI49_LAUNCH_CHECK();
+    return 0;
+}
+
+
+int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, hipStream_t s) {
+    hipLaunchKernelGGL(k_bsk_to_lat49, dim3((n_polys + 1) / 2), dim3(256), 0, s, std_polys, lat_polys, g_tw_h, n_polys);
+    BMI49_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_blind_rotate_lat2(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk_lat,
+                             const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+    if (count == 0) return 0;
+    static std::atomic<uint64_t> configured{0};
+    const size_t lds = (size_t)L2_LDS_WORDS * sizeof(double);
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k_blind_rotate_lat2_49), lds, configured)) return rc;
+    hipLaunchKernelGGL(k_blind_rotate_lat2_49, dim3(count), dim3(L2_THREADS), lds, s, small_cts, lut_ids, luts, bsk_lat,
+                       g_tw_h, out, count, n);
     BMI49_LAUNCH_CHECK();
     return 0;
 }

@@ -119,7 +119,8 @@ int bmi_sync(bmi_ctx *ctx, void *stream);
 
 /* Selects the blind-rotation kernel: 0 = auto (by batch size), 1 = throughput, a pair of wavefronts per
  * ciphertext exchanging every level, 2 = latency (one workgroup of 8 wavefronts per ciphertext), 3 = throughput,
- * a pair of wavefronts per ciphertext exchanging once per CMUX (49-bit field; what auto picks for large batches). */
+ * a pair of wavefronts per ciphertext exchanging once per CMUX (49-bit field; what auto picks for large batches),
+ * 4 = the one-wavefront-per-transform latency kernel (2 is the two-wavefronts-per-transform one on the 49-bit field). */
 int bmi_set_kernel_variant(bmi_ctx *ctx, int variant);
 
 /* Selects the keyswitch kernel: 0 = auto (int8 matrix-core product when the parameter set allows it),

@@ -134,7 +134,7 @@ def test_keyswitch_matrix_core_path_bit_exact(eng, ora):
         assert list(to.decode(to.lwe_phase(sk_small, got[ok]), eng.delta_log())) == list(msgs[ok])
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3], ids=["pair_per_level", "latency", "pair_per_cmux"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4], ids=["pair_per_level", "latency", "pair_per_cmux", "latency_one_wave_transform"])
 def test_blind_rotate_every_kernel_variant(eng, ora, variant):
     """7 ciphertexts: ragged against the 2 (variant 1) and 4 (variant 3) ciphertexts per workgroup."""
     to, P, ctx, _, sk_big, _, _ = ora
@@ -285,7 +285,7 @@ def test_other_parameter_shape_bit_exact(q_bits):
         tv = e.lut_get(lid)[None, :]
         ids = np.full(5, lid, np.uint32)
         want = ctx.blind_rotate(want_small[:5], tv, np.zeros(5, np.uint32))
-        for variant in (0, 1, 2, 3):
+        for variant in (0, 1, 2, 3, 4):
             e.set_kernel_variant(variant)
             assert np.array_equal(e.blind_rotate_host(want_small[:5], ids), want), variant
         e.set_kernel_variant(0)
