@@ -592,8 +592,7 @@ int bmi_keyswitch_batch(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64
     if (!c || (count && (!d_in || !d_small))) return -1;
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
     HIP_OK(c, hipSetDevice(c->device));
-    // small batches: the K-split scalar kernel has the shorter launch chain (measured: 0.14 ms against 0.34 ms at 3 ciphertexts)
-    if (c->ks_variant == 0 && c->ks_mfma_ok && count >= 64) return keyswitch_mfma(c, d_in, count, d_small, (hipStream_t)stream);
+    if (c->ks_variant == 0 && c->ks_mfma_ok && count >= BMI_KS_MFMA_MIN) return keyswitch_mfma(c, d_in, count, d_small, (hipStream_t)stream);
     // Scalar form.  The row walk (k*N*levels rows) of one workgroup is the latency of a small batch, so it is split over
     // `slices` workgroups per tile of 8 ciphertexts (partial 128-bit sums + a reduce kernel) until the launch
     // has ~1024 workgroups; large batches fill the chip with one slice.

@@ -22,6 +22,10 @@
 #define BMI_TPX49_SYNC 0  // pair synchronisation of the exchange-once kernel: 0 = LDS counters (pairs only), 1 = workgroup barrier
 #endif
 
+#ifndef BMI_KS_MFMA_MIN
+#define BMI_KS_MFMA_MIN 1  // smallest batch that takes the matrix-core keyswitch (0.05 ms against 0.14 ms scalar even at one ciphertext)
+#endif
+
 #ifndef BMI_TP_CTS
 #define BMI_TP_CTS 2  // ciphertexts (= wavefront pairs) per workgroup in the throughput blind rotation
 #endif

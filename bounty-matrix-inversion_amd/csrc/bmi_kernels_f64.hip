@@ -73,7 +73,7 @@ __device__ __forceinline__ double digit_of(double r, int lev) {
 
 // Phase timing (debug build only: make prof): wall-clock cycles per phase of one wavefront, see tools/phase_prof.py
 #ifdef BMI_PHASE_PROF
-__device__ unsigned long long g_phase[64];
+__device__ unsigned long long g_phase[128];
 #define PH_DECL() unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = clock64()
 #define PH_MARK(k)                               \
     do {                                         \
@@ -558,10 +558,12 @@ __global__ void __launch_bounds__(L2_THREADS)
     __syncthreads();
     const int mo = tid >> 9, mp = tid & 511;  // phase B: output polynomial, slot
 
+    PH_DECL();
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t a_t = at[i];
         if (a_t == 0) continue;  // uniform over the workgroup
         const double *bi = bsk_lat + (size_t)i * 12 * N;
+        PH_MARK(7);
         double b[6][2];
 #pragma unroll
         for (int r = 0; r < 6; r++) {
@@ -586,7 +588,9 @@ __global__ void __launch_bounds__(L2_THREADS)
             wave_sync();
             static_for<0, 8>([&](auto R) { tile[R * 64 + lane] = x[R]; });
         }
+        PH_MARK(0);
         __syncthreads();
+        PH_MARK(1);
         {
             double ylo = 0.0, yhi = 0.0;  // lazy sums of six products (<= 10.2 q)
 #pragma unroll
@@ -600,7 +604,9 @@ __global__ void __launch_bounds__(L2_THREADS)
             SD[(mo * 2 + 0) * ntth::HALF + mp] = ylo + yhi;
             SD[(mo * 2 + 1) * ntth::HALF + mp] = ylo - yhi;
         }
+        PH_MARK(2);
         __syncthreads();
+        PH_MARK(3);
         if (wave < 4) {
             const int o = wave >> 1, h = wave & 1;
             double x[8];
@@ -611,8 +617,14 @@ __global__ void __launch_bounds__(L2_THREADS)
             double *ao = acc + o * N + h * ntth::HALF;
             static_for<0, 8>([&](auto J) { ao[lane + 64 * J] = f49::red(ao[lane + 64 * J] + x[J]); });
         }
+        PH_MARK(4);
         __syncthreads();
+        PH_MARK(5);
     }
+#ifdef BMI_PHASE_PROF
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k_ = 0; k_ < 8; k_++) g_phase[wave * 8 + k_] = ph_[k_];
+#endif
     u64 *o = out + (size_t)ct * (N + 1);
     {
         const uint32_t nn = tid;
@@ -655,7 +667,7 @@ struct Field49 {
 
 #ifdef BMI_PHASE_PROF
 extern "C" int bmi_debug_phase_prof(unsigned long long *out64) {
-    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 64);
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 128);
 }
 #endif
 

@@ -118,25 +118,58 @@ __global__ void __launch_bounds__(256)
 }
 
 // ------------------------------------------------------------------------------------------------
+// One workgroup per output row; a thread owns the columns tid, tid + 256, ... and walks the row's terms once, so the
+// loads of one term (LC_COLS per thread) are independent and the term loop is the only serial chain (the first
+// version looped columns outermost: one load in flight per thread, 135 us per level of the encrypted inverse).
+constexpr int LC_COLS = 5;  // 5 x 256 >= k N + 1 = 1025
+
 template <class F>
 __global__ void __launch_bounds__(256)
     k_lincomb(const u64 *__restrict__ store, const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ idx,
               const i64 *__restrict__ coef, const u64 *__restrict__ const_body, u64 *__restrict__ out, uint32_t width) {
     const uint32_t row = blockIdx.x;
     const uint32_t e0 = row_ptr[row], e1 = row_ptr[row + 1];
-    for (uint32_t x = threadIdx.x; x < width; x += blockDim.x) {
-        u64 acc = 0;
+    for (uint32_t x0 = 0; x0 < width; x0 += LC_COLS * 256) {
+        // Coefficients are small integers (weights of packed look-up inputs), so the terms are summed exactly in
+        // signed 128-bit and reduced once per output word; F::mul_small (a 128-bit remainder for the 49-bit field)
+        // is only used for a coefficient too large for that (|cf| >= 2^31: at most 2^32 such terms fit).
+        __int128 acc[LC_COLS];
+        u64 big[LC_COLS];
+#pragma unroll
+        for (int c = 0; c < LC_COLS; c++) {
+            acc[c] = 0;
+            big[c] = 0;
+        }
+#pragma unroll 2
         for (uint32_t e = e0; e < e1; e++) {
             const i64 cf = coef[e];
-            const u64 s = store[(size_t)idx[e] * width + x];
-            u64 term;
-            if (cf == 1) term = s;
-            else if (cf == -1) term = F::neg(s);
-            else term = F::mul_small(cf, s);
-            acc = F::add(acc, term);
+            const u64 *src = store + (size_t)idx[e] * width + x0;
+            u64 v[LC_COLS];
+#pragma unroll
+            for (int c = 0; c < LC_COLS; c++) {
+                const uint32_t x = threadIdx.x + 256 * c;
+                v[c] = x0 + x < width ? src[x] : 0;
+            }
+            if (cf > -((i64)1 << 31) && cf < ((i64)1 << 31)) {
+#pragma unroll
+                for (int c = 0; c < LC_COLS; c++) acc[c] += (__int128)cf * (__int128)v[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < LC_COLS; c++) big[c] = F::add(big[c], F::mul_small(cf, v[c]));
+            }
         }
-        if (x == width - 1) acc = F::add(acc, const_body[row]);
-        out[(size_t)row * width + x] = acc;
+#pragma unroll
+        for (int c = 0; c < LC_COLS; c++) {
+            const uint32_t x = x0 + threadIdx.x + 256 * c;
+            if (x >= width) continue;
+            const bool neg = acc[c] < 0;
+            const unsigned __int128 m = neg ? (unsigned __int128)(-acc[c]) : (unsigned __int128)acc[c];
+            u64 a = F::reduce128((u64)(m >> 64), (u64)m);
+            if (neg) a = F::neg(a);
+            a = F::add(a, big[c]);
+            if (x == width - 1) a = F::add(a, const_body[row]);
+            out[(size_t)row * width + x] = a;
+        }
     }
 }
 

@@ -145,13 +145,18 @@ __global__ void __launch_bounds__(256)
     const uint32_t ct = blockIdx.x;
     const uint32_t cw = cbs * TILE;
     for (uint32_t col = threadIdx.x; col <= n; col += blockDim.x) {
+        i64 sum[L];
+#pragma unroll
+        for (int l = 0; l < L; l++) sum[l] = 0;
+#pragma unroll 4
+        for (uint32_t sl = 0; sl < slices; sl++) {  // L independent loads per slice, four slices in flight
+            const int *base = S + (((size_t)sl * count + ct) * L) * cw + col;
+#pragma unroll
+            for (int l = 0; l < L; l++) sum[l] += base[(size_t)l * cw];
+        }
         __int128 v = 0;
 #pragma unroll
-        for (int l = L - 1; l >= 0; l--) {
-            i64 s = 0;
-            for (uint32_t sl = 0; sl < slices; sl++) s += S[(((size_t)sl * count + ct) * L + l) * cw + col];
-            v = v * 256 + s;
-        }
+        for (int l = L - 1; l >= 0; l--) v = v * 256 + sum[l];
         const bool neg = v < 0;
         const unsigned __int128 m = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
         u64 red = F::reduce128((u64)(m >> 64), (u64)m);

@@ -103,6 +103,11 @@ def test_keyswitch_bit_exact(eng, ora):
     got = eng.keyswitch_host(ct)
     want = ctx.keyswitch(ct)
     assert np.array_equal(got, want)
+    eng.set_keyswitch_variant(1)          # the scalar kernel (K-split form at this batch size)
+    try:
+        assert np.array_equal(eng.keyswitch_host(ct), want)
+    finally:
+        eng.set_keyswitch_variant(0)
     ok = [0, 1, 2] + list(range(8, 19))
     assert list(to.decode(to.lwe_phase(sk_small, got[ok]), eng.delta_log())) == list(msgs[ok])
 

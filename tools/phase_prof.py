@@ -28,13 +28,13 @@ def main():
     for _ in range(2):
         eng.blind_rotate(d_small, d_ids, B, d_out, s)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 64)()
+    buf = (C.c_ulonglong * 128)()
     rc = tfhe.load_library().bmi_debug_phase_prof(buf)
     assert rc == 0, rc
-    a = np.array(buf[:], dtype=np.float64).reshape(8, 8)
-    for w in range(8 if variant == 2 else 4):
+    a = np.array(buf[:], dtype=np.float64).reshape(16, 8)
+    for w in range({1: 4, 2: 16, 3: 4, 4: 8}[variant]):
         tot = a[w].sum()
         print(json.dumps({"wave": w, "total_cycles": tot, "per_cmux": round(tot / 630, 1),
-                          "phases_cycles_per_cmux": {n: round(v / 630, 0) for n, v in zip(LAT_NAMES if variant == 2 else NAMES, a[w]) if n != "-"}}))
+                          "phases_cycles_per_cmux": {n: round(v / 630, 0) for n, v in zip(LAT_NAMES if variant in (2, 4) else NAMES, a[w]) if n != "-"}}))
 
 main()
