@@ -297,3 +297,39 @@ def test_other_parameter_shape_bit_exact(q_bits):
         assert np.array_equal(e.pbs_host(ct[:5], ids), want)
     finally:
         e.close()
+
+
+def test_full_batch_properties(eng, ora):
+    """The bench batch size (8,192 ciphertexts, throughput kernels) through size-independent properties: every
+    output decrypts to LUT[m]; a random sample is bit-exact against the oracle; the keyswitch is additive
+    (KS(c1 + c2) and KS(c1) + KS(c2) decrypt alike although their digits differ); identical inputs at different
+    batch positions give identical outputs (no dependence on the workgroup / wavefront a ciphertext lands in)."""
+    to, P, ctx, sk_small, sk_big, _, _ = ora
+    rng = np.random.default_rng(17)
+    B = 8192
+    dl = eng.delta_log()
+    table = rng.integers(-8, 8, 16)
+    lid = eng.lut_register(table, 4, dl)
+    msgs = rng.integers(-8, 8, B)
+    ct = eng.encrypt(msgs, dl)
+    ct[4097] = ct[5]                      # duplicates far apart in the batch
+    ct[8191] = ct[5]
+    msgs[4097] = msgs[8191] = msgs[5]
+    ids = np.full(B, lid, np.uint32)
+    out = eng.pbs_host(ct, ids)
+    assert np.array_equal(eng.decrypt(out, dl), table[msgs + 8])
+    assert np.array_equal(out[4097], out[5]) and np.array_equal(out[8191], out[5])
+    sample = np.sort(rng.choice(B, 12, replace=False))
+    want = ctx.pbs(ct[sample], eng.lut_get(lid)[None, :], np.zeros(sample.size, np.uint32))
+    assert np.array_equal(out[sample], want)
+    # additivity of the keyswitch on small messages (|m1 + m2| < 8)
+    m1, m2 = rng.integers(-3, 4, 256), rng.integers(-3, 4, 256)
+    c1, c2 = eng.encrypt(m1, dl), eng.encrypt(m2, dl)
+    Q = eng.modulus
+    csum = ((c1.astype(object) + c2.astype(object)) % Q).astype(np.uint64)
+    ks_sum = eng.keyswitch_host(csum)
+    k1, k2 = eng.keyswitch_host(c1), eng.keyswitch_host(c2)
+    sum_ks = ((k1.astype(object) + k2.astype(object)) % Q).astype(np.uint64)
+    d1 = to.decode(to.lwe_phase(sk_small, ks_sum), dl)
+    d2 = to.decode(to.lwe_phase(sk_small, sum_ks), dl)
+    assert list(d1) == list(m1 + m2) and list(d2) == list(m1 + m2)
