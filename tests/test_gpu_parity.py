@@ -333,3 +333,48 @@ def test_full_batch_properties(eng, ora):
     d1 = to.decode(to.lwe_phase(sk_small, ks_sum), dl)
     d2 = to.decode(to.lwe_phase(sk_small, sum_ks), dl)
     assert list(d1) == list(m1 + m2) and list(d2) == list(m1 + m2)
+
+
+def test_context_lifecycle_rekey_growth_and_two_contexts():
+    """One context re-keyed with a second seed (device keys, limb-form keyswitch key and latency-kernel key copy must
+    all follow), scratch growth past bmi_reserve, and two contexts (one per field) alive on the same GPU."""
+    from bmi_amd import tfhe
+    from oracle import tfhe_oracle as to
+    e49 = tfhe.Engine(tfhe.default_params(q_bits=49))
+    e64 = tfhe.Engine(tfhe.default_params(q_bits=64))
+    try:
+        rng = np.random.default_rng(18)
+        table = rng.integers(-8, 8, 16)
+        for seed in (11, 12):
+            e49.keygen(seed)
+            to.set_field(49)
+            _, _, bsk, ksk = e49.export_keys()
+            ctx = to.Ctx(to.default_params(q_bits=49), bsk, ksk)
+            dl = e49.delta_log()
+            lid = e49.lut_register(table, 4, dl)
+            msgs = rng.integers(-8, 8, 6)
+            ct = e49.encrypt(msgs, dl)
+            ids = np.full(6, lid, np.uint32)
+            want = ctx.pbs(ct, e49.lut_get(lid)[None, :], np.zeros(6, np.uint32))
+            assert np.array_equal(e49.pbs_host(ct, ids), want), seed                     # latency kernel + its key copy
+            e49.set_kernel_variant(3)
+            assert np.array_equal(e49.pbs_host(ct, ids), want), seed                     # throughput kernel
+            e49.set_kernel_variant(0)
+            ctx.close()
+        # growth: reserve small, then run a batch 40x larger (scratch buffers reallocate under queued work)
+        e49.reserve(32)
+        big = rng.integers(-8, 8, 1300)
+        out = e49.pbs_host(e49.encrypt(big, dl), np.full(big.size, lid, np.uint32))
+        assert np.array_equal(e49.decrypt(out, dl), table[big + 8])
+        # the other field's context was created before and is still usable after all of the above
+        e64.keygen(13)
+        dl64 = e64.delta_log()
+        l64 = e64.lut_register(table, 4, dl64)
+        m = rng.integers(-8, 8, 70)
+        o64 = e64.pbs_host(e64.encrypt(m, dl64), np.full(m.size, l64, np.uint32))
+        assert np.array_equal(e64.decrypt(o64, dl64), table[m + 8])
+        o49 = e49.pbs_host(e49.encrypt(m, dl), np.full(m.size, lid, np.uint32))
+        assert np.array_equal(e49.decrypt(o49, dl), table[m + 8])
+    finally:
+        e49.close()
+        e64.close()
