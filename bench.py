@@ -154,9 +154,11 @@ def main():
         "metric": "PBS/sec per GPU + encrypted n x n inverse wall-clock (n=2,3,4)", "value": value, "unit": "PBS/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": ("u64 (mod 2^64-2^32+1)" if eng.q_bits == 64 else "exact integers mod 2^49-720895 carried in f64"), "data": "synthetic",
+        "vs_baseline": None, "dtype": ("u64" if eng.q_bits == 64 else "f64"), "data": "synthetic",
         "config": {"workload": f"pbs_batch: B={B} LWE ciphertexts per GPU per step, TFHE n=630 N=1024 k=1 l=3 "
                                f"(Bg=2^15, ks 8x4 bits), q_bits={eng.q_bits}, 4-bit signed messages, 2 LUTs (identity, random)",
+                   "arithmetic": ("integers mod 2^64-2^32+1 in u64 (64-bit integer VALU)" if eng.q_bits == 64 else
+                                  "exact integers mod 2^49-720895 carried in f64 (FMA pairs); keyswitch: int8 matrix cores, int32 sums"),
                    "batch_per_gpu": B, "pbs_per_gpu_per_s": value / world, "verified_decrypt": verified,
                    "derived_reference_pbs_per_s_64core_cpu": "35-69 (derived, BASELINE.md §1)"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
