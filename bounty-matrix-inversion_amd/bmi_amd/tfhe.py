@@ -64,6 +64,7 @@ _SIGS = {
     "bmi_negacyclic_mul_host": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
     "bmi_sync": [C.c_void_p, C.c_void_p],
     "bmi_reserve": [C.c_void_p, C.c_uint32],
+    "bmi_import_keys": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "bmi_set_kernel_variant": [C.c_void_p, C.c_int],
     "bmi_set_keyswitch_variant": [C.c_void_p, C.c_int],
     "bmi_key_bytes": [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
@@ -177,15 +178,60 @@ class Engine:
     def keygen(self, seed=0x5EED):
         self._ck(self.lib.bmi_keygen(self.h, C.c_uint64(seed)), "bmi_keygen")
 
-    def export_keys(self):
+    def export_keys(self, secret=True):
+        """(sk_small, sk_big, bsk, ksk), standard domain; secret=False returns (None, None, bsk, ksk) and also works on
+        an evaluation-only context"""
         P = self.P
         rows = (P.k + 1) * P.bs_levels
-        sk_small = np.zeros(P.n, np.uint64)
-        sk_big = np.zeros(P.k * P.N, np.uint64)
+        sk_small = np.zeros(P.n, np.uint64) if secret else None
+        sk_big = np.zeros(P.k * P.N, np.uint64) if secret else None
         bsk = np.zeros((P.n, rows, P.k + 1, P.N), np.uint64)
         ksk = np.zeros((P.k * P.N, P.ks_levels, P.n + 1), np.uint64)
         self._ck(self.lib.bmi_export_keys(self.h, _ptr(sk_small), _ptr(sk_big), _ptr(bsk), _ptr(ksk)), "bmi_export_keys")
         return sk_small, sk_big, bsk, ksk
+
+    def import_keys(self, sk_small, sk_big, bsk, ksk):
+        """loads a key set (layout of export_keys); sk_small = sk_big = None makes this context evaluation-only"""
+        P = self.P
+        rows = (P.k + 1) * P.bs_levels
+        bsk = np.ascontiguousarray(bsk, dtype=np.uint64)
+        ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
+        if bsk.size != P.n * rows * (P.k + 1) * P.N or ksk.size != P.k * P.N * P.ks_levels * (P.n + 1):
+            raise BmiError("key arrays do not match this context's parameters")
+        if (sk_small is None) != (sk_big is None):
+            raise BmiError("pass both secret keys or neither")
+        if sk_small is not None:
+            sk_small = np.ascontiguousarray(sk_small, dtype=np.uint64)
+            sk_big = np.ascontiguousarray(sk_big, dtype=np.uint64)
+            if sk_small.size != P.n or sk_big.size != P.k * P.N:
+                raise BmiError("secret key arrays do not match this context's parameters")
+        self._ck(self.lib.bmi_import_keys(self.h, _ptr(sk_small), _ptr(sk_big), _ptr(bsk), _ptr(ksk)), "bmi_import_keys")
+
+    _PARAM_FIELDS = ("n", "log_N", "k", "bs_levels", "bs_base_log", "ks_levels", "ks_base_log", "q_bits", "lwe_noise", "glwe_noise")
+
+    def save_keys(self, path, secret=True):
+        """Key file (numpy .npz): the parameter set and the standard-domain keys.  secret=False writes the evaluation
+        keys only - what a server needs (the reference's analogue: Concrete's key cache, qfloat_matrix_inversion.py:997)."""
+        sk_small, sk_big, bsk, ksk = self.export_keys(secret=secret)
+        arrays = {"bsk": bsk, "ksk": ksk, "params": np.array([float(getattr(self.P, f)) for f in self._PARAM_FIELDS])}
+        if secret:
+            arrays.update(sk_small=sk_small, sk_big=sk_big)
+        with open(path, "wb") as f:
+            np.savez(f, **arrays)
+
+    def load_keys(self, path):
+        """loads a key file written by save_keys; the file's parameter set must equal this context's"""
+        with np.load(path) as z:
+            mine = [float(getattr(self.P, f)) for f in self._PARAM_FIELDS]
+            mine[7] = float(self.q_bits)
+            theirs = list(z["params"])
+            if theirs[7] == 0:
+                theirs[7] = 64.0
+            if mine != theirs:
+                raise BmiError(f"key file parameters {theirs} differ from this context's {mine}")
+            has_secret = "sk_small" in z.files
+            self.import_keys(z["sk_small"] if has_secret else None, z["sk_big"] if has_secret else None, z["bsk"], z["ksk"])
+        return has_secret
 
     def key_bytes(self):
         a, b = C.c_uint64(), C.c_uint64()

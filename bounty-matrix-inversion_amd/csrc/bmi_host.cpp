@@ -97,6 +97,7 @@ struct bmi_ctx {
     uint32_t N = 0, big_n = 0, rows = 0, ks_stride = 0;
     hipStream_t stream = nullptr;  // the context's own stream (host-buffer entry points)
     bool have_keys = false;
+    bool have_secret = false;  // false for a context that imported evaluation keys only (no encrypt / decrypt)
     u64 seed = 0, enc_counter = 0;
     std::vector<u64> sk_small, sk_big, bsk_std, ksk;
     void *d_bsk = nullptr, *d_tw = nullptr, *d_luts = nullptr;  // u64 words (Goldilocks) or f64 words (49-bit field)
@@ -309,6 +310,10 @@ int bmi_get_params(const bmi_ctx *c, bmi_params *out) {
     return 0;
 }
 
+namespace {
+int upload_eval_keys(bmi_ctx *c);
+}
+
 int bmi_keygen(bmi_ctx *c, uint64_t seed) {
     if (!c) return -1;
     HIP_OK(c, hipSetDevice(c->device));
@@ -369,6 +374,16 @@ int bmi_keygen(bmi_ctx *c, uint64_t seed) {
             row[n] = b;
         });
     }
+    c->have_secret = true;
+    return upload_eval_keys(c);
+}
+
+namespace {
+// Evaluation keys (host copies in c->bsk_std / c->ksk) -> device: bootstrap key to the NTT domain (both layouts for
+// the 49-bit field), keyswitch key in word form (+ bias vector) and in limb form.
+int upload_eval_keys(bmi_ctx *c) {
+    const bmi_params &P = c->P;
+    const uint32_t n = P.n, N = c->N, k = P.k, lk = P.ks_levels;
     // --- upload: bootstrap key -> NTT domain on the GPU; keyswitch key with padded rows
     const size_t bsk_words = c->bsk_std.size();
     if (!c->d_bsk) HIP_OK(c, hipMalloc(&c->d_bsk, bsk_words * 8));
@@ -421,10 +436,42 @@ int bmi_keygen(bmi_ctx *c, uint64_t seed) {
     c->have_keys = true;
     return 0;
 }
+}  // namespace
+
+int bmi_import_keys(bmi_ctx *c, const uint64_t *sk_small, const uint64_t *sk_big, const uint64_t *bsk, const uint64_t *ksk) {
+    if (!c || !bsk || !ksk) return -1;
+    if ((sk_small == nullptr) != (sk_big == nullptr)) return fail(c, -1, "pass both secret keys or neither");
+    HIP_OK(c, hipSetDevice(c->device));
+    const bmi_params &P = c->P;
+    const size_t bsk_words = (size_t)P.n * c->rows * (P.k + 1) * c->N, ksk_words = (size_t)c->big_n * P.ks_levels * (P.n + 1);
+    for (size_t i = 0; i < bsk_words; i++)
+        if (bsk[i] >= c->f.q) return fail(c, -1, "bootstrap key word not reduced mod q");
+    for (size_t i = 0; i < ksk_words; i++)
+        if (ksk[i] >= c->f.q) return fail(c, -1, "keyswitch key word not reduced mod q");
+    c->have_keys = false;
+    c->bsk_std.assign(bsk, bsk + bsk_words);
+    c->ksk.assign(ksk, ksk + ksk_words);
+    c->have_secret = sk_small != nullptr;
+    if (c->have_secret) {
+        for (uint32_t i = 0; i < P.n; i++)
+            if (sk_small[i] > 1) return fail(c, -1, "secret keys are binary");
+        for (uint32_t i = 0; i < c->big_n; i++)
+            if (sk_big[i] > 1) return fail(c, -1, "secret keys are binary");
+        c->sk_small.assign(sk_small, sk_small + P.n);
+        c->sk_big.assign(sk_big, sk_big + c->big_n);
+    } else {
+        c->sk_small.clear();
+        c->sk_big.clear();
+    }
+    c->seed = 0x1234567ULL;  // encryption randomness stream of an imported key set (bmi_encrypt is still deterministic)
+    c->enc_counter = 0;
+    return upload_eval_keys(c);
+}
 
 int bmi_export_keys(const bmi_ctx *c, uint64_t *sk_small, uint64_t *sk_big, uint64_t *bsk, uint64_t *ksk) {
     if (!c) return -1;
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
+    if ((sk_small || sk_big) && !c->have_secret) return fail(c, -1, "evaluation-only context: it holds no secret key");
     if (sk_small) std::memcpy(sk_small, c->sk_small.data(), c->sk_small.size() * 8);
     if (sk_big) std::memcpy(sk_big, c->sk_big.data(), c->sk_big.size() * 8);
     if (bsk) std::memcpy(bsk, c->bsk_std.data(), c->bsk_std.size() * 8);
@@ -442,6 +489,7 @@ int bmi_key_bytes(const bmi_ctx *c, uint64_t *bsk_bytes, uint64_t *ksk_bytes) {
 int bmi_encrypt(bmi_ctx *c, const int64_t *msgs, uint32_t count, uint32_t delta_log, uint64_t *ct_out) {
     if (!c || !msgs || !ct_out) return -1;
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
+    if (!c->have_secret) return fail(c, -1, "evaluation-only context: it holds no secret key");
     if (delta_log >= c->f.bits - 1) return fail(c, -1, "delta_log out of range");
     Stream sm(c->seed, S_ENC_MASK, c->f), se(c->seed, S_ENC_NOISE, c->f);
     const Fq f = c->f;
@@ -466,6 +514,7 @@ int bmi_encrypt(bmi_ctx *c, const int64_t *msgs, uint32_t count, uint32_t delta_
 int bmi_phase(const bmi_ctx *c, const uint64_t *ct_in, uint32_t count, uint64_t *phase) {
     if (!c || !ct_in || !phase) return -1;
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
+    if (!c->have_secret) return fail(c, -1, "evaluation-only context: it holds no secret key");
     const uint32_t dim = c->big_n;
     const u64 *key = c->sk_big.data();
     for (uint32_t i = 0; i < count; i++) {

@@ -70,6 +70,12 @@ int bmi_keygen(bmi_ctx *ctx, uint64_t seed);
 /* Test hook: copies out the secret keys and the standard-domain evaluation keys.
  * Sizes: sk_small[n], sk_big[k*N], bsk[n*(k+1)*l*(k+1)*N], ksk[k*N*ks_levels*(n+1)]; any may be NULL. */
 int bmi_export_keys(const bmi_ctx *ctx, uint64_t *sk_small, uint64_t *sk_big, uint64_t *bsk, uint64_t *ksk);
+/* Loads a key set generated elsewhere (same sizes and standard-domain layout as bmi_export_keys; words reduced mod q)
+ * and uploads the evaluation keys.  sk_small and sk_big may both be NULL: the context is then evaluation-only (PBS,
+ * keyswitch, linear combinations work; bmi_encrypt / bmi_decrypt / bmi_phase fail) - the server half of the
+ * client/server split the reference reaches through Concrete's key objects (circuit.keys, the ".keys" cache of
+ * qfloat_matrix_inversion.py:997-998). */
+int bmi_import_keys(bmi_ctx *ctx, const uint64_t *sk_small, const uint64_t *sk_big, const uint64_t *bsk, const uint64_t *ksk);
 
 /* replaces circuit.encrypt (main.py:76): big-key LWE encryptions of msgs[i] * 2^delta_log. */
 int bmi_encrypt(bmi_ctx *ctx, const int64_t *msgs, uint32_t count, uint32_t delta_log, uint64_t *ct_out);

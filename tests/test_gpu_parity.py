@@ -378,3 +378,49 @@ def test_context_lifecycle_rekey_growth_and_two_contexts():
     finally:
         e49.close()
         e64.close()
+
+
+def test_key_import_and_evaluation_only_context(tmp_path):
+    """Keys exported from one context and imported into another give identical ciphertexts; a context that imported
+    the evaluation keys only bootstraps but refuses to encrypt / decrypt; the key file round-trips."""
+    from bmi_amd import tfhe
+    a = tfhe.Engine(tfhe.default_params(q_bits=49))
+    b = tfhe.Engine(tfhe.default_params(q_bits=49))
+    c = tfhe.Engine(tfhe.default_params(q_bits=49))
+    try:
+        a.keygen(21)
+        dl = a.delta_log()
+        rng = np.random.default_rng(19)
+        table = rng.integers(-8, 8, 16)
+        msgs = rng.integers(-8, 8, 9)
+        ct = a.encrypt(msgs, dl)
+        la = a.lut_register(table, 4, dl)
+        want = a.pbs_host(ct, np.full(9, la, np.uint32))
+        sk_small, sk_big, bsk, ksk = a.export_keys()
+        b.import_keys(None, None, bsk, ksk)                       # server: evaluation keys only
+        lb = b.lut_register(table, 4, dl)
+        assert np.array_equal(b.pbs_host(ct, np.full(9, lb, np.uint32)), want)
+        for call in (lambda: b.encrypt(msgs, dl), lambda: b.decrypt(want, dl), lambda: b.phase(want), lambda: b.export_keys()):
+            with pytest.raises(tfhe.BmiError):
+                call()
+        assert b.export_keys(secret=False)[0] is None
+        assert list(a.decrypt(want, dl)) == list(table[msgs + 8])  # the client decrypts the server's output
+        a.save_keys(tmp_path / "full.npz")
+        a.save_keys(tmp_path / "eval.npz", secret=False)
+        assert c.load_keys(tmp_path / "full.npz") is True
+        assert list(c.decrypt(c.pbs_host(ct, np.full(9, c.lut_register(table, 4, dl), np.uint32)), dl)) == list(table[msgs + 8])
+        assert c.load_keys(tmp_path / "eval.npz") is False
+        with pytest.raises(tfhe.BmiError):
+            c.decrypt(want, dl)
+        bad = bsk.copy()
+        bad[0, 0, 0, 0] = np.uint64(a.modulus)                     # not reduced
+        with pytest.raises(tfhe.BmiError):
+            c.import_keys(None, None, bad, ksk)
+        e64 = tfhe.Engine(tfhe.default_params(q_bits=64))
+        try:
+            with pytest.raises(tfhe.BmiError):
+                e64.load_keys(tmp_path / "eval.npz")                # other field: parameter mismatch
+        finally:
+            e64.close()
+    finally:
+        a.close(); b.close(); c.close()
