@@ -263,13 +263,16 @@ def test_pbs_device_pointers_and_noise_budget(eng, ora):
     assert np.max(np.abs(err)) < 2.0 ** (dl - 9)  # half a box is 2^(dl-1)
 
 
-@pytest.mark.parametrize("q_bits", [64, 49])
-def test_other_parameter_shape_bit_exact(q_bits):
+@pytest.mark.parametrize("q_bits,kw", [(64, dict(n=97, ks_levels=5, ks_base_log=6)), (49, dict(n=97, ks_levels=5, ks_base_log=6)),
+                                       (49, dict(n=639, ks_levels=4, ks_base_log=7))],
+                         ids=["goldilocks64-n97", "p49-n97", "p49-n639-max"])
+def test_other_parameter_shape_bit_exact(q_bits, kw):
     """n = 97 (98 output columns: a ragged column block in the matrix-core keyswitch) with a 5 x 6-bit keyswitch
-    decomposition: keyswitch (both kernels), every blind-rotation kernel and the fused PBS against the oracle."""
+    decomposition, and the largest supported n = 639 (640 columns exactly) with 4 x 7-bit digits (|d| <= 64, the
+    int8 limit of the matrix-core form): keyswitch (both kernels), every blind-rotation kernel and the fused PBS
+    against the oracle; an empty batch is a no-op on every entry point."""
     from bmi_amd import tfhe
     from oracle import tfhe_oracle as to
-    kw = dict(n=97, ks_levels=5, ks_base_log=6)
     e = tfhe.Engine(tfhe.default_params(q_bits=q_bits, **kw))
     try:
         e.keygen(SEED + 1)
@@ -295,6 +298,10 @@ def test_other_parameter_shape_bit_exact(q_bits):
             assert np.array_equal(e.blind_rotate_host(want_small[:5], ids), want), variant
         e.set_kernel_variant(0)
         assert np.array_equal(e.pbs_host(ct[:5], ids), want)
+        empty = np.zeros((0, e.P.big), np.uint64)
+        assert e.pbs_host(empty, np.zeros(0, np.uint32)).shape == (0, e.P.big)
+        assert e.keyswitch_host(empty).shape == (0, e.P.small)
+        assert e.blind_rotate_host(np.zeros((0, e.P.small), np.uint64), np.zeros(0, np.uint32)).shape == (0, e.P.big)
     finally:
         e.close()
 
