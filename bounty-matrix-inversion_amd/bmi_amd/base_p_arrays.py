@@ -291,48 +291,67 @@ def _add_binary(c, a, b):
     return carry_propagate_nonneg(c, cols, 2)
 
 
+DIVISION_BITS = 2  # quotient bits retired per step of the binary division (2: radix 4, 3: radix 8)
+
+
 def _division_radix4(c, dividend, divisor):
-    """floor(dividend / divisor) in binary, two quotient bits per step: the partial remainder (always < divisor,
-    so it fits m digits) is extended by two dividend digits and compared with D, 2D and 3D in parallel (three
-    borrow look-aheads); sel = number of failed comparisons picks the new remainder with one 4-way mux per
-    digit.  A zero divisor makes every comparison succeed: all quotient bits are 1, as in the reference."""
+    return _division_radix(c, dividend, divisor, DIVISION_BITS)
+
+
+def _division_radix(c, dividend, divisor, kbits):
+    """floor(dividend / divisor) in binary, `kbits` quotient bits per step (radix R = 2^kbits): the partial
+    remainder (always < divisor, so it fits m digits) is extended by kbits dividend digits and compared with
+    D, 2D, ..., (R-1)D in parallel (R - 1 borrow look-aheads); sel = number of failed comparisons picks the new
+    remainder with one R-way mux per digit (sel and a candidate bit pack into one 4-bit look-up for R <= 8).
+    A leading group of n mod kbits digits is retired first with the smaller radix.  A zero divisor makes every
+    comparison succeed: all quotient bits are 1, as in the reference."""
     n, m = len(dividend), len(divisor)
-    w = m + 2
-    D1 = [0, 0] + divisor
-    D2 = [0] + divisor + [0]
-    D3 = _add_binary(c, D1, D2)
+    R = 1 << kbits
+    w = m + kbits
+    shifted = lambda sh: [0] * (kbits - sh) + divisor + [0] * sh   # D * 2^sh as w digits  # noqa: E731
+    mult = {1 << sh: shifted(sh) for sh in range(kbits)}
+    for j in range(3, R):
+        if j not in mult:
+            hi = 1 << (j.bit_length() - 1)
+            mult[j] = _add_binary(c, mult[hi], mult[j - hi])       # j D < 2^w: no carry out
     quo = [0] * n
     rem = [0] * m  # m digits, MSD first
-    k = 0
-    if n % 2:  # odd length: one bit-serial step first (remainder is zero, so this only tests dividend[0] >= D)
-        r1 = rem + [dividend[0]]
-        diff, lt = base_p_subtraction(c, r1, [0] + divisor, 2, True)
-        quo[0] = 1 - lt
-        sel1 = [c.select(lt, r, d) if isinstance(lt, Lin) else (r if lt else d) for r, d in zip(r1, diff)]
-        rem = sel1[1:]
-        k = 1
-    while k < n:
-        r4 = rem + [dividend[k], dividend[k + 1]]  # 4 * rem + 2 * N_k + N_{k+1}, w digits
-        d1, lt1 = base_p_subtraction(c, r4, D1, 2, True)
-        d2, lt2 = base_p_subtraction(c, r4, D2, 2, True)
-        d3, lt3 = base_p_subtraction(c, r4, D3, 2, True)
-        sel = lt1 + lt2 + lt3  # 0: >= 3D, 1: >= 2D, 2: >= D, 3: < D   (lt1 <= lt2 <= lt3)
+
+    def step(rem, digs):
+        r = len(digs)                       # this step's radix is 2^r (r <= kbits)
+        Rr = 1 << r
+        ext = rem + digs                    # 2^r * rem + digits, m + r digits
+        diffs, lts = {}, []
+        for j in range(1, Rr):
+            dj, lt = base_p_subtraction(c, ext, mult[j][kbits - r:], 2, True)   # j D < 2^(m + r): leading zeros dropped
+            diffs[j] = dj
+            lts.append(lt)
+        sel = sum(lts[1:], lts[0])          # failed comparisons: 0 -> quotient digit Rr - 1, ..., Rr - 1 -> 0
         if isinstance(sel, Lin):
-            sel = sel.assume(0, 3)
-            quo[k] = c.lut(sel, lambda s: int(s <= 1))
-            quo[k + 1] = c.lut(sel, lambda s: int(s % 2 == 0))
+            sel = sel.assume(0, Rr - 1)
+            bits = [c.lut(sel, lambda s, b=b: ((Rr - 1 - s) >> b) & 1) for b in range(r - 1, -1, -1)]
             new = []
-            for i in range(2, w):  # the new remainder is < D: only its low m digits can be non-zero
-                cands = (d3[i], d2[i], d1[i], r4[i])
+            for i in range(r, m + r):       # the new remainder is < D: only its low m digits can be non-zero
+                cands = [diffs[j][i] for j in range(Rr - 1, 0, -1)] + [ext[i]]
                 acc = 0
                 for kk, x in enumerate(cands):
                     acc = acc + lut2(c, sel, x, lambda s, v, kk=kk: v if s == kk else 0)
                 new.append(acc.assume(0, 1) if isinstance(acc, Lin) else acc)
-            rem = new
-        else:
-            quo[k], quo[k + 1] = int(sel <= 1), int(sel % 2 == 0)
-            rem = list((d3, d2, d1, r4)[sel][2:])
-        k += 2
+            return bits, new
+        qv = Rr - 1 - sel
+        cands = [diffs[j] for j in range(Rr - 1, 0, -1)] + [ext]
+        return [(qv >> b) & 1 for b in range(r - 1, -1, -1)], list(cands[sel][r:])
+
+    k = 0
+    if n % kbits:
+        lead = n % kbits
+        bits, rem = step(rem, list(dividend[:lead]))
+        quo[:lead] = bits
+        k = lead
+    while k < n:
+        bits, rem = step(rem, list(dividend[k:k + kbits]))
+        quo[k:k + kbits] = bits
+        k += kbits
     return quo
 
 

@@ -17,11 +17,45 @@ from .qfloat_matrix_inversion import (float_matrix_to_qfloat_arrays, qfloat_and_
                                       qfloat_matrix_inverse)
 
 
-def trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base=2, true_division=False, tensorize=False):
+def estimated_evaluate_ms(circuit):
+    """Cost model of one evaluation on one MI355X (measured): a level up to 512 ciphertexts wide runs
+    ceil(width / 256) rounds of the latency kernel (4.4 ms each: one workgroup per ciphertext, 256 CUs), a wider one
+    the throughput kernel (10.8 ms per started 1,024 ciphertexts, 96 PBS per ms once the chip is full)."""
+    ms = 0.0
+    for lv in circuit.levels():
+        w = len(lv)
+        ms += 4.4 * -(-w // 256) if w <= 512 else max(10.8 * -(-w // 1024), w / 96.0)
+    return ms
+
+
+def trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base=2, true_division=False, tensorize=False, division_bits=None):
     """Builds the PBS circuit of qfloat_matrix_inverse (the analogue of fhe.Compiler(...).compile, main.py:53-66).
     Inputs are declared in the order: all n^2 * len digits (row-major), then the n^2 signs.
     Digit intervals: leading digit [0, 2*base - 1] (from_float does not reduce it), others
-    [0, base - 1]; signs [-1, 1]."""
+    [0, base - 1]; signs [-1, 1].
+
+    division_bits: quotient bits per step of the binary divisions (2 or 3, base_p_arrays._division_radix); None
+    traces both for n <= 4 and keeps the circuit the cost model above estimates faster (radix 8 is 19 % shallower
+    but 2.3x wider per step: it wins while the steps of the concurrent divisions still fit one kernel round)."""
+    from . import base_p_arrays as bpa
+    if division_bits is None:
+        cands = (2, 3) if (n <= 4 and qfloat_base == 2) else (2,)
+        best = None
+        for bits in cands:
+            cir = trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize, bits)
+            est = estimated_evaluate_ms(cir) if len(cands) > 1 else 0.0
+            if best is None or est < best[0]:
+                best = (est, cir)
+        return best[1]
+    saved = bpa.DIVISION_BITS
+    bpa.DIVISION_BITS = int(division_bits)
+    try:
+        return _trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize)
+    finally:
+        bpa.DIVISION_BITS = saved
+
+
+def _trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize):
     c = Circuit()
     top = 2 * qfloat_base - 1
     arrays = [[c.input(0, top if j == 0 else qfloat_base - 1) for j in range(qfloat_len)] for _ in range(n * n)]

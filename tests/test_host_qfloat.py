@@ -177,6 +177,32 @@ def test_traced_ops_match_goldens():
         same_traced(run_traced(lambda cc, x, y: QFloat.from_mul(x, y, 18, 1), [c["q1"], c["q2"]])[0], c["out"])
 
 
+@pytest.mark.parametrize("bits", [1, 2, 3])
+def test_traced_division_every_radix(bits):
+    """x / y, y.invert and -1 / y with 1, 2 and 3 quotient bits per step (radix 2, 4, 8, odd and even dividend
+    lengths): every radix must return the reference's restoring-division digits."""
+    from bmi_amd import base_p_arrays as bpa
+    g = load("qfloat_ops.json")
+    saved = bpa.DIVISION_BITS
+    bpa.DIVISION_BITS = bits
+    try:
+        n_checked = 0
+        for c in g["pairs"]:
+            if c["base"] != 2 or "div" not in c:
+                continue
+            a, b = c["q1"], c["q2"]
+            same_traced(run_traced(lambda cc, x, y: x / y, [a, b])[0], c["div"])
+            fi = c["invert_fmt"]
+            same_traced(run_traced(lambda cc, y: y.invert(1, fi["newlen"], fi["newints"]), [b])[0], fi)
+            same_traced(run_traced(lambda cc, y: SignedBinary(-1) / y, [b])[0], c["invert_m1"])
+            n_checked += 1
+            if n_checked >= 6:
+                break
+        assert n_checked >= 4
+    finally:
+        bpa.DIVISION_BITS = saved
+
+
 def test_traced_tidy_on_mixed_sign_digits():
     """Pattern of the reference's test_tidy_np (tests/test_qfloat.py:191-213) on encrypted digits.  The
     reference draws untidy digits in [-4b, 4b), which only its plaintext mode can hold; on ciphertexts a
