@@ -35,11 +35,12 @@ def trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base=2, true_division=False
     [0, base - 1]; signs [-1, 1].
 
     division_bits: quotient bits per step of the binary divisions (2 or 3, base_p_arrays._division_radix); None
-    traces both for n <= 4 and keeps the circuit the cost model above estimates faster (radix 8 is 19 % shallower
-    but 2.3x wider per step: it wins while the steps of the concurrent divisions still fit one kernel round)."""
+    traces both for n <= 3 and keeps the circuit the cost model above estimates faster (radix 8 is 19 % shallower
+    but 2.3x wider per step: it wins while a step still fits one kernel round; at 4x4 (len 40) the estimates differ
+    by 3 %, not worth tracing twice)."""
     from . import base_p_arrays as bpa
     if division_bits is None:
-        cands = (2, 3) if (n <= 4 and qfloat_base == 2) else (2,)
+        cands = (2, 3) if (n <= 3 and qfloat_base == 2) else (2,)
         best = None
         for bits in cands:
             cir = trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize, bits)
