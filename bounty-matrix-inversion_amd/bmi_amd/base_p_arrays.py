@@ -151,6 +151,8 @@ def _prefix_borrows(c, sig, first_bit):
     m = len(sig)
     bits = [None] * m
     bits[0] = first_bit
+    if WIDE_LOOKAHEAD:
+        return _lookahead_bits(c, list(sig), 1, bits)
     S = list(sig)
     d = 1
     while d < m:
@@ -200,6 +202,70 @@ def _window3_borrows(c, deltas):
     return bits
 
 
+WIDE_LOOKAHEAD = True  # use the 5-bit look-ups of Circuit.lut_odd in the look-ahead networks (False: 4-bit forms only)
+
+
+def _comb3(v):
+    """combined signal of THREE look-ahead signals packed as 9 s2 + 3 s1 + s0 (s2 most significant): the most
+    significant non-propagating one.  Odd in v, and f(v - 16) = -f(v) on [-13, 13]: one Circuit.lut_odd look-up."""
+    s2 = (v + 13) // 9 - 1            # balanced ternary digits of v
+    r = v - 9 * s2
+    s1 = (r + 4) // 3 - 1
+    s0 = r - 3 * s1
+    return s2 if s2 else (s1 if s1 else s0)
+
+
+def _wide_borrows(c, deltas):
+    """Borrow look-ahead for digit differences in {-1, 0, 1} with 5-bit look-ups (Circuit.lut_odd): the first
+    level reads sliding windows of FOUR positions (sign(8 d_i + 4 d_{i-1} + 2 d_{i-2} + d_{i-3})), later levels
+    combine THREE signals at a time (spans 4, 12, 36, ...).  A borrow BIT is not an odd function, so bits come from
+    ordinary look-ups: directly from a window of up to three positions, from a two-way combine as soon as two
+    signals reach position 0 together, or by converting a signal that already does.  33 positions: 4 levels
+    (window-3 + doubling: 5); 23 positions: 3 (4).  Returns bits[i] = borrow out of position i."""
+    m = len(deltas)
+    S = [None] * m
+    bits = [None] * m
+    sign = lambda v: (v > 0) - (v < 0)  # noqa: E731
+    for i in range(m):
+        if i <= 2:
+            w = deltas[i] * 4
+            if i >= 1:
+                w = w + deltas[i - 1] * 2
+            if i >= 2:
+                w = w + deltas[i - 2]
+            bits[i] = lut(c, w, lambda v: int(v < 0))     # narrow window reaching position 0: final
+            S[i] = lut(c, w, sign)
+        else:
+            w = deltas[i] * 8 + deltas[i - 1] * 4 + deltas[i - 2] * 2 + deltas[i - 3]
+            S[i] = c.lut_odd(w, sign) if isinstance(w, Lin) else sign(int(w))
+    return _lookahead_bits(c, S, 4, bits)
+
+
+def _lookahead_bits(c, S, span, bits):
+    """Finishes a look-ahead: S[i] is the combined signal of positions max(0, i - span + 1) .. i; fills the missing
+    bits[i] = [combined signal of positions 0..i is 'generate'] with three-way signal combines (lut_odd) and
+    ordinary look-ups for the bits (see _wide_borrows)."""
+    m = len(S)
+    while any(b is None for b in bits):
+        newS = list(S)
+        for i in range(m):
+            if bits[i] is None:
+                if i < span:                               # the signal already reaches position 0: convert
+                    bits[i] = lut(c, S[i], lambda v: int(v == -1))
+                elif i < 2 * span:                         # two signals reach position 0 together
+                    bits[i] = lut2(c, S[i], S[i - span], lambda h, l: int(_comb(h, l) == -1))
+            if i >= span and any(bits[j] is None or j >= 2 * span for j in range(i, min(m, i + 2 * span + 1), span)):
+                # still an operand of a later combine: widen the signal (three-way where three exist)
+                if i >= 2 * span:
+                    packed = S[i] * 9 + S[i - span] * 3 + S[i - 2 * span]
+                    newS[i] = c.lut_odd(packed, _comb3) if isinstance(packed, Lin) else _comb3(int(packed))
+                else:
+                    newS[i] = lut2(c, S[i], S[i - span], _comb)
+        S = newS
+        span *= 3
+    return bits
+
+
 def base_p_subtraction(c, a, b, p, overflow=False):
     """reference base_p_arrays.py:108-139: a - b with borrows, right-aligned, and (overflow=True) the flag a < b
     as defined there for unequal sizes.  Same integers as the reference's sequential borrow chain, computed
@@ -234,7 +300,7 @@ def base_p_subtraction(c, a, b, p, overflow=False):
     elif overflow and extra > 0:
         pseudo = -1 * sum_is_positive(c, b[:extra])     # 0 = propagate, -1 = generate
     if pseudo is None and all(-1 <= lo_of(d) and hi_of(d) <= 1 for d in deltas):
-        bits = _window3_borrows(c, deltas)
+        bits = (_wide_borrows if WIDE_LOOKAHEAD else _window3_borrows)(c, deltas)
     else:
         sig = [lut(c, d, _sign3) for d in deltas]
         if pseudo is not None:
@@ -371,11 +437,24 @@ def is_greater_or_equal(c, a, b):
         return 1 - first
     while len(sig) > 2:
         nxt = []
-        for i in range(0, len(sig) - 1, 2):
-            nxt.append(lut2(c, sig[i + 1], sig[i], _comb))
-        if len(sig) % 2:
-            nxt.append(sig[-1])
+        if WIDE_LOOKAHEAD:   # three signals per look-up (Circuit.lut_odd): depth log3 instead of log2
+            for i in range(0, len(sig), 3):
+                grp = sig[i:i + 3]
+                if len(grp) == 3:
+                    packed = grp[2] * 9 + grp[1] * 3 + grp[0]
+                    nxt.append(c.lut_odd(packed, _comb3) if isinstance(packed, Lin) else _comb3(int(packed)))
+                elif len(grp) == 2:
+                    nxt.append(lut2(c, grp[1], grp[0], _comb))
+                else:
+                    nxt.append(grp[0])
+        else:
+            for i in range(0, len(sig) - 1, 2):
+                nxt.append(lut2(c, sig[i + 1], sig[i], _comb))
+            if len(sig) % 2:
+                nxt.append(sig[-1])
         sig = nxt
+    if len(sig) == 1:   # a three-way level left one signal: convert it
+        return 1 - lut(c, sig[0], lambda v: int(v == -1))
     return 1 - lut2(c, sig[1], sig[0], lambda h, l: int(_comb(h, l) == -1))
 
 
@@ -466,7 +545,7 @@ def carry_propagate_nonneg(c, columns, p):
     if p == 2 and all(0 <= lo_of(x) and hi_of(x) <= 2 for x in lsb_first):
         # carry out of a window <=> the most significant non-'propagate' column generates: with e = 1 - col in
         # {-1: generate, 0: propagate, 1: kill} this is exactly the borrow look-ahead on e (windows of three)
-        bits = _window3_borrows(c, [1 - x for x in lsb_first])
+        bits = (_wide_borrows if WIDE_LOOKAHEAD else _window3_borrows)(c, [1 - x for x in lsb_first])
     else:
         sig = [lut(c, x, lambda v: -1 if v >= p else (0 if v == p - 1 else 1)) for x in lsb_first]
         bits = _prefix_borrows(c, sig, lut(c, lsb_first[0], lambda v: int(v >= p)))

@@ -165,6 +165,7 @@ class Circuit:
         self.claims = []         # (snapshot, lo, hi) interval claims to be verified by simulate()
         self.outputs = []        # snapshots of output Lins
         self.stats = {"pbs": 0, "cse_hits": 0, "const_folds": 0}
+        self.wide_leaves = set()  # outputs of lut_odd(): their PBS input may use the whole torus
 
     # ---- construction ----------------------------------------------------------------------------
     def input(self, lo, hi):
@@ -228,6 +229,73 @@ class Circuit:
             self.leaf_hi.append(ohi)
             self.nodes.append((snap[0], snap[1], li, leaf))
             self._cse[ck] = leaf
+            self.stats["pbs"] += 1
+        else:
+            self.stats["cse_hits"] += 1
+        return Lin(self, {leaf: 1}, 0, olo, ohi)
+
+    def lut_odd(self, x, fn):
+        """Look-up on a FIVE-bit input for functions with f(v - 2^(MSG_BITS+1)) = -f(v) (sign-like functions).
+
+        A MSG_BITS-bit message occupies half of the torus; the negacyclic test polynomial returns -f(v - 16) for an
+        input v in [8, 16) and -f(v + 16) for v in [-16, -8).  For a function with exactly that symmetry the look-up is
+        therefore correct on the whole interval [-15, 15] with the ordinary 16-entry table, the same box width and
+        the same noise margin as any 4-bit look-up.  This packs FOUR binary digit differences (8 d3 + 4 d2 + 2 d1 + d0)
+        or THREE ternary look-ahead signals (9 s2 + 3 s1 + s0) into one PBS.  The symmetry is verified here on every
+        reachable value; `simulate` evaluates with the wrap-around rule."""
+        if not isinstance(x, Lin):
+            return self.const(fn(int(x)))
+        if x.is_const:
+            self.stats["const_folds"] += 1
+            return self.const(fn(x.const))
+        half = 1 << (MSG_BITS - 1)
+        full = 1 << (MSG_BITS + 1)
+        if x.lo < -(full // 2 - 1) or x.hi > full // 2 - 1:
+            raise RangeError(f"wide look-up input interval [{x.lo}, {x.hi}] outside [-{full // 2 - 1}, {full // 2 - 1}]")
+        if -half <= x.lo and x.hi < half:
+            return self.lut(x, fn)  # fits the ordinary message space
+        table = [None] * (2 * half)
+        for v in range(x.lo, x.hi + 1):
+            fv = int(fn(v))
+            if -half <= v < half:
+                m, want = v, fv
+            elif v >= half:
+                m, want = v - full // 2, -fv          # slot of v - 16, which must hold -f(v)
+            else:
+                m, want = v + full // 2, -fv
+            if table[m + half] is None:
+                table[m + half] = want
+            elif table[m + half] != want:
+                raise RangeError(f"lut_odd: f({v}) = {fv} breaks f(v - {full // 2}) = -f(v)")
+        known = [t for t in table if t is not None]
+        vals = [int(fn(v)) for v in range(x.lo, x.hi + 1)]
+        olo, ohi = min(vals), max(vals)
+        if olo == ohi:
+            self.stats["const_folds"] += 1
+            return self.const(olo)
+        last = known[0]
+        for i in range(len(table)):       # unreachable slots repeat a neighbouring reachable value
+            if table[i] is None:
+                table[i] = last
+            else:
+                last = table[i]
+        key = (MSG_BITS, tuple(table))
+        li = self._lut_index.get(key)
+        if li is None:
+            li = len(self.luts)
+            self.luts.append(key)
+            self._lut_index[key] = li
+        snap = self._snapshot(x)
+        ck = (snap, li, "wide")
+        leaf = self._cse.get(ck)
+        if leaf is None:
+            leaf = len(self.leaf_level)
+            self.leaf_level.append(self.level_of(x) + 1)
+            self.leaf_lo.append(olo)
+            self.leaf_hi.append(ohi)
+            self.nodes.append((snap[0], snap[1], li, leaf))
+            self._cse[ck] = leaf
+            self.wide_leaves.add(leaf)
             self.stats["pbs"] += 1
         else:
             self.stats["cse_hits"] += 1
@@ -402,12 +470,18 @@ class Circuit:
             p, table = self.luts[li]
             x = const + sum(cf * val[t] for t, cf in terms)
             scale = 1 << (MSG_BITS - p)
-            if check and not (-half_space <= x < half_space):
+            wide = leaf in self.wide_leaves
+            if check and not ((-2 * half_space < x < 2 * half_space) if wide else (-half_space <= x < half_space)):
                 raise RangeError(f"PBS input {x} outside the message space")
             if check and x % scale:
                 raise RangeError("PBS input not a multiple of its scale")
             m = x // scale
-            out = table[m + (1 << (p - 1))]
+            if wide and m >= half_space:        # the other half of the torus: negacyclic wrap-around
+                out = -table[m - 2 * half_space + (1 << (p - 1))]
+            elif wide and m < -half_space:
+                out = -table[m + 2 * half_space + (1 << (p - 1))]
+            else:
+                out = table[m + (1 << (p - 1))]
             if check and not (self.leaf_lo[leaf] <= out <= self.leaf_hi[leaf]):
                 raise RangeError("look-up output outside its interval")
             val[leaf] = out

@@ -55,6 +55,25 @@ def test_encrypted_qfloat_ops_on_gpu(eng):
     assert out[-1] == c["gt"]
 
 
+def test_wide_odd_lookups_on_gpu(eng):
+    """Circuit.lut_odd on ciphertexts: inputs on the whole torus ([-15, 15] at 4 message bits) through the ordinary
+    16-entry test polynomial; every input of the window-4 signal and of the three-way combine, both fields."""
+    import itertools
+    from bmi_amd import base_p_arrays as bpa
+    from bmi_amd.circuit import Circuit
+    from bmi_amd.executor import Executor
+    sgn = lambda v: (v > 0) - (v < 0)  # noqa: E731
+    circ = Circuit()
+    x = circ.input(-15, 15)
+    y = circ.input(-13, 13)
+    circ.set_outputs([circ.lut_odd(x, sgn), circ.lut_odd(y, bpa._comb3)])
+    ex = Executor(circ, eng)
+    dl = eng.delta_log()
+    for xv, yv in itertools.zip_longest(range(-15, 16), range(-13, 14), fillvalue=0):
+        out = eng.decrypt(ex.run(eng.encrypt([xv, yv], dl)), dl)
+        assert list(out) == circ.simulate([xv, yv]) == [sgn(xv), bpa._comb3(yv)], (xv, yv)
+
+
 @pytest.mark.parametrize("tag", ["survey_2x2", "baseline_n2_len20_ints8"])
 def test_encrypted_2x2_inverse_matches_reference_golden(eng, tag):
     from bmi_amd.main import EncryptedMatrixInversion

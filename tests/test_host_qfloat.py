@@ -203,6 +203,60 @@ def test_traced_division_every_radix(bits):
         bpa.DIVISION_BITS = saved
 
 
+def test_wide_odd_lookup_and_lookahead_networks():
+    """Circuit.lut_odd (5-bit inputs for functions with f(v - 16) = -f(v)) and the look-ahead networks built on it:
+    window-4 signals and the three-way combine on every input; subtraction with borrow-out against integer
+    arithmetic for widths on both sides of every depth step, wide and 4-bit-only forms giving the same digits with
+    the wide one never deeper."""
+    import itertools
+    import random
+    from bmi_amd import base_p_arrays as bpa
+    from bmi_amd.circuit import RangeError
+    sgn = lambda v: (v > 0) - (v < 0)  # noqa: E731
+    c = Circuit()
+    d = [c.input(-1, 1) for _ in range(4)]
+    s3 = [c.input(-1, 1) for _ in range(3)]
+    c.set_outputs([c.lut_odd(d[3] * 8 + d[2] * 4 + d[1] * 2 + d[0], sgn), c.lut_odd(s3[2] * 9 + s3[1] * 3 + s3[0], bpa._comb3)])
+    assert len(c.wide_leaves) == 2
+    for vals in itertools.product((-1, 0, 1), repeat=7):
+        w = 8 * vals[3] + 4 * vals[2] + 2 * vals[1] + vals[0]
+        t = vals[6] if vals[6] else (vals[5] if vals[5] else vals[4])
+        assert c.simulate(list(vals)) == [sgn(w), t]
+    c2 = Circuit()
+    x = c2.input(-15, 15)
+    with pytest.raises(RangeError):
+        c2.lut_odd(x, lambda v: int(v < 0))          # a bit is not an odd function
+    with pytest.raises(RangeError):
+        c2.lut_odd(c2.input(-16, 15) if False else x + x, sgn)   # interval beyond the torus
+    saved = bpa.WIDE_LOOKAHEAD
+    try:
+        for m in (1, 3, 4, 12, 13, 24, 25, 33, 37):
+            depth = {}
+            for wide in (True, False):
+                bpa.WIDE_LOOKAHEAD = wide
+                cc = Circuit()
+                a = [cc.input(0, 1) for _ in range(m)]
+                b = [cc.input(0, 1) for _ in range(m)]
+                out, lt = bpa.base_p_subtraction(cc, a, b, 2, True)
+                ge = bpa.is_greater_or_equal(cc, a, b)
+                cc.set_outputs(out + [lt, ge])
+                depth[wide] = len(cc.asap_levels())
+                rng = random.Random(m)
+                for k in range(40):
+                    av = [rng.randint(0, 1) for _ in range(m)]
+                    bv = list(av) if k % 4 == 0 else [rng.randint(0, 1) for _ in range(m)]
+                    if k % 5 == 1:
+                        bv = list(av)
+                        bv[rng.randrange(m)] ^= 1
+                    A, B = int("".join(map(str, av)), 2), int("".join(map(str, bv)), 2)
+                    want = [int(ch) for ch in bin((A - B) % (1 << m))[2:].zfill(m)] + [int(A < B), int(A >= B)]
+                    assert cc.simulate(av + bv) == want, (m, wide)
+            assert depth[True] <= depth[False]
+        assert depth[True] < depth[False]                # at 37 digits: 4 levels against 5
+    finally:
+        bpa.WIDE_LOOKAHEAD = saved
+
+
 def test_traced_tidy_on_mixed_sign_digits():
     """Pattern of the reference's test_tidy_np (tests/test_qfloat.py:191-213) on encrypted digits.  The
     reference draws untidy digits in [-4b, 4b), which only its plaintext mode can hold; on ciphertexts a
