@@ -95,8 +95,14 @@ class _PlainEngine:
             p, table = self.tables[int(ids[r])]
             x = int(d_in[r, -1])
             m = x >> (4 - p)
+            half = 1 << (p - 1)
             d_out[r] = 0
-            d_out[r, -1] = table[m + (1 << (p - 1))]
+            if m >= half:          # the other half of the torus (Circuit.lut_odd inputs): negacyclic wrap-around
+                d_out[r, -1] = -table[m - 2 * half + half]
+            elif m < -half:
+                d_out[r, -1] = -table[m + 2 * half + half]
+            else:
+                d_out[r, -1] = table[m + half]
 
 
 def _trace_small():
