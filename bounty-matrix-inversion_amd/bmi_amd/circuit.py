@@ -235,7 +235,7 @@ class Circuit:
         return Lin(self, {leaf: 1}, 0, olo, ohi)
 
     def lut_odd(self, x, fn):
-        """Look-up on a FIVE-bit input for functions with f(v - 2^(MSG_BITS+1)) = -f(v) (sign-like functions).
+        """Look-up on a FIVE-bit input for functions with f(v - 2^MSG_BITS) = -f(v) (sign-like functions).
 
         A MSG_BITS-bit message occupies half of the torus; the negacyclic test polynomial returns -f(v - 16) for an
         input v in [8, 16) and -f(v + 16) for v in [-16, -8).  For a function with exactly that symmetry the look-up is
@@ -249,9 +249,9 @@ class Circuit:
             self.stats["const_folds"] += 1
             return self.const(fn(x.const))
         half = 1 << (MSG_BITS - 1)
-        full = 1 << (MSG_BITS + 1)
-        if x.lo < -(full // 2 - 1) or x.hi > full // 2 - 1:
-            raise RangeError(f"wide look-up input interval [{x.lo}, {x.hi}] outside [-{full // 2 - 1}, {full // 2 - 1}]")
+        period = 1 << MSG_BITS      # f(v - period) = -f(v); the torus holds 2 * period boxes
+        if x.lo < -(period - 1) or x.hi > period - 1:
+            raise RangeError(f"wide look-up input interval [{x.lo}, {x.hi}] outside [-{period - 1}, {period - 1}]")
         if -half <= x.lo and x.hi < half:
             return self.lut(x, fn)  # fits the ordinary message space
         table = [None] * (2 * half)
@@ -260,13 +260,13 @@ class Circuit:
             if -half <= v < half:
                 m, want = v, fv
             elif v >= half:
-                m, want = v - full // 2, -fv          # slot of v - 16, which must hold -f(v)
+                m, want = v - period, -fv          # slot of v - 16, which must hold -f(v)
             else:
-                m, want = v + full // 2, -fv
+                m, want = v + period, -fv
             if table[m + half] is None:
                 table[m + half] = want
             elif table[m + half] != want:
-                raise RangeError(f"lut_odd: f({v}) = {fv} breaks f(v - {full // 2}) = -f(v)")
+                raise RangeError(f"lut_odd: f({v}) = {fv} breaks f(v - {period}) = -f(v)")
         known = [t for t in table if t is not None]
         vals = [int(fn(v)) for v in range(x.lo, x.hi + 1)]
         olo, ohi = min(vals), max(vals)
