@@ -91,6 +91,22 @@ def test_encrypted_2x2_inverse_matches_reference_golden(eng, tag):
     assert np.max(np.abs(got - np.linalg.inv(M))) < 0.01
 
 
+@pytest.mark.parametrize("tag", ["uniform_2x2_tensorize", "uniform_3x3_small_truediv", "uniform_3x3_small_tensorize"])
+def test_encrypted_inverse_modes_match_reference_golden(eng, tag):
+    """The reference's other modes on ciphertexts: true_division=True (QFloat / QFloat through the long
+    division instead of invert-and-multiply, qfloat.py:1183-1234) and tensorize=True (the multi_* twins)."""
+    from bmi_amd.main import EncryptedMatrixInversion
+    if eng.q_bits == 64 and tag != "uniform_2x2_tensorize":
+        pytest.skip("the 3x3 mode cases run once, on the faster field")
+    c = next(x for x in load("inverse.json") if x["tag"] == tag)
+    emi = EncryptedMatrixInversion(c["n"], None, 2, c["len"], c["ints"], c["true_division"], c["tensorize"], engine=eng)
+    M = np.array(c["M"]).reshape(c["n"], c["n"])
+    q, s = emi.quantize(M)
+    out = emi.decrypt(emi.evaluate(emi.encrypt(q, s)))
+    assert out.tolist() == c["out"]
+    assert emi.dequantize(out).flatten().tolist() == c["float"]
+
+
 def test_encrypted_3x3_inverse_matches_reference_golden(eng):
     """BASELINE config 3: 3x3, len 30, ints 12, one MI355X; the north star asks for < 60 s."""
     import time
