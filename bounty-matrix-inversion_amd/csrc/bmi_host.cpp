@@ -117,6 +117,7 @@ struct bmi_ctx {
     size_t ks_partial_bytes = 0;
     // keyswitch on the matrix cores: limb-wise key (per keygen), digit matrix and int32 sums (growable scratch)
     int ks_variant = 0;  // 0 = auto (matrix cores when the shape allows), 1 = scalar kernel
+    bool no_big_lds = false;  // set when a > 64 KB LDS kernel could not be configured on this device (auto mode only)
     bool ks_mfma_ok = false;
     signed char *d_ks_limbs = nullptr, *d_ks_digits = nullptr;
     int *d_ks_sums = nullptr;
@@ -677,10 +678,28 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     int rc;
     if (c->f64()) {
         const double *luts = (const double *)c->d_luts, *bsk = (const double *)c->d_bsk, *tw = (const double *)c->d_tw;
-        rc = c->variant == 4 ? bmi49::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
-             : latency ? bmi49::launch_blind_rotate_lat2(d_small, d_lut_ids, luts, c->d_bsk_lat, c->d_tw_half, d_out, count, c->P.n, (hipStream_t)stream)
-             : c->variant == 1 ? bmi49::launch_blind_rotate_tp(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
-                     : bmi49::launch_blind_rotate_tpx(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream);
+        hipStream_t st = (hipStream_t)stream;
+        // auto mode falls back from the kernels that need > 64 KB of LDS per workgroup to their predecessors (still on
+        // the GPU) if the device refuses the configuration; a pinned variant reports the error instead
+        if (c->variant == 4 || (latency && c->no_big_lds)) {
+            rc = bmi49::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, st);
+        } else if (latency) {
+            rc = bmi49::launch_blind_rotate_lat2(d_small, d_lut_ids, luts, c->d_bsk_lat, c->d_tw_half, d_out, count, c->P.n, st);
+            if (rc && c->variant == 0) {
+                (void)hipGetLastError();
+                c->no_big_lds = true;
+                rc = bmi49::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, st);
+            }
+        } else if (c->variant == 1 || c->no_big_lds) {
+            rc = bmi49::launch_blind_rotate_tp(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, st);
+        } else {
+            rc = bmi49::launch_blind_rotate_tpx(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, st);
+            if (rc && c->variant == 0) {
+                (void)hipGetLastError();
+                c->no_big_lds = true;
+                rc = bmi49::launch_blind_rotate_tp(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, st);
+            }
+        }
     } else {
         const u64 *luts = (const u64 *)c->d_luts, *bsk = (const u64 *)c->d_bsk, *tw = (const u64 *)c->d_tw;
         rc = latency ? bmi::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, (hipStream_t)stream)
