@@ -18,6 +18,10 @@
 #define BMI_TPX49_PF 12  // exchange-once kernel: where the two GGSW rows of a level are requested (see the kernel)
 #endif
 
+#ifndef BMI_TPX49_RESYNC
+#define BMI_TPX49_RESYNC 4  // workgroup barrier every so many CMUX iterations (0: never): keeps the four pairs on the same key rows, which they share through L1 (83.5 -> 80.6 ms)
+#endif
+
 #ifndef BMI_TPX49_SYNC
 #define BMI_TPX49_SYNC 0  // pair synchronisation of the exchange-once kernel: 0 = LDS counters (pairs only), 1 = workgroup barrier
 #endif

@@ -288,6 +288,9 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
     }
 
     for (uint32_t i = 0; i < n; i++) {
+#if BMI_TPX49_RESYNC
+        if (i % BMI_TPX49_RESYNC == 0) __syncthreads();  // keeps the four pairs on the same key rows (shared through L1)
+#endif
         const uint32_t a_t = at[i];
         const double *bsk_c = bsk + ((size_t)i * 12 + c * 6) * N;  // this wavefront's three GGSW rows (two columns each)
         wave_sync();
