@@ -15,7 +15,7 @@
 #endif
 
 #ifndef BMI_TPX49_PF
-#define BMI_TPX49_PF 12  // exchange-once kernel: where the two GGSW rows of a level are requested (see the kernel)
+#define BMI_TPX49_PF 13  // exchange-once kernel: where the two GGSW rows of a level are requested (see the kernel)
 #endif
 
 #ifndef BMI_TPX49_RESYNC
