@@ -208,8 +208,9 @@ __global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
 // Wavefront c of a pair owns INPUT polynomial c of the CMUX: it decomposes rot(acc_c) - acc_c, transforms the three
 // digit polynomials and multiplies each with BOTH output columns of its three GGSW rows, so it ends the levels with
 // a partial sum for its own component and one for the partner's.  The partner's partial goes through the tile once,
-// guarded by a pair of LDS counters (publish / consumed) that only the two wavefronts of the pair poll: there is no
-// workgroup barrier in the loop, so the four pairs of a workgroup drift freely and the workgroup can be as large as
+// guarded by a pair of LDS counters (publish / consumed) that only the two wavefronts of the pair poll: the exchange
+// needs no workgroup barrier (one every BMI_TPX49_RESYNC iterations only keeps the pairs on the same key rows, which
+// they share through L1), so the workgroup can be as large as
 // the CU (8 wavefronts share one copy of the twiddle tables, which leaves LDS room for the accumulators: the
 // accumulator lives in LDS between iterations, not in registers).
 constexpr int TPX_CTS = 4;
