@@ -276,7 +276,8 @@ class Engine:
         return tv
 
     def set_kernel_variant(self, v):
-        """blind rotation: 0 auto, 1 pair kernel exchanging per level, 2 latency kernel, 3 pair kernel exchanging per CMUX"""
+        """blind rotation: 0 auto, 1 pair kernel exchanging per level, 2 latency kernel (two wavefronts per transform on
+        the 49-bit field), 3 pair kernel exchanging per CMUX, 4 latency kernel with one wavefront per transform"""
         self._ck(self.lib.bmi_set_kernel_variant(self.h, int(v)), "bmi_set_kernel_variant")
 
     def set_keyswitch_variant(self, v):

@@ -117,8 +117,8 @@ int bmi_blind_rotate_batch_host(bmi_ctx *ctx, const uint64_t *small_in, const ui
 /* negacyclic product of two polynomials through the GPU NTT (test hook for the transform) */
 int bmi_negacyclic_mul_host(bmi_ctx *ctx, const uint64_t *a, const uint64_t *b, uint32_t count, uint64_t *c);
 
-/* Pre-sizes the context's internal scratch (small-key ciphertexts of bmi_pbs_batch) for batches up to
- * max_count, so that no allocation happens on the hot path afterwards. */
+/* Pre-sizes the context's internal scratch (small-key ciphertexts of bmi_pbs_batch, digit matrix and limb sums of the
+ * matrix-core keyswitch) for batches up to max_count, so that no allocation happens on the hot path afterwards. */
 int bmi_reserve(bmi_ctx *ctx, uint32_t max_count);
 
 int bmi_sync(bmi_ctx *ctx, void *stream);
