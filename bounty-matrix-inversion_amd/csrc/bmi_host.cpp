@@ -102,6 +102,8 @@ struct bmi_ctx {
     std::vector<u64> sk_small, sk_big, bsk_std, ksk;
     void *d_bsk = nullptr, *d_tw = nullptr, *d_luts = nullptr;  // u64 words (Goldilocks) or f64 words (49-bit field)
     double *d_tw_half = nullptr, *d_bsk_lat = nullptr;          // 49-bit field: tables and key copy of the split-transform latency kernel
+    double *d_tw_wide = nullptr;                                // N = 2048: T / T^-1 of the even/odd combination (d_bsk_lat then holds the wide key copy)
+    bool wide() const { return N == 2048; }
     u64 *d_ksk = nullptr, *d_ks_bias = nullptr;
     uint32_t n_luts = 0, lut_cap = 0;
     std::vector<std::vector<u64>> luts_host;
@@ -219,8 +221,25 @@ std::vector<u64> build_twiddles_half(const Fq &f, u64 psi, u64 psi_inv) {
     return tw;
 }
 
+// N = 2048: T[reg * 64 + lane] = psi_4096^(2 kk + 1) at the evaluation slot (lane, reg) of the 1024-point wave transform
+// (kk = k1 + 16 (4 vl + g) + 256 s for lane 4 k1 + g, register 4 vl + s), then the inverses.
+std::vector<u64> build_twiddles_wide(const Fq &f) {
+    const u64 psi4096 = f.pow(f49::GEN, (f.q - 1) / 4096), inv = f.pow(psi4096, f.q - 2);
+    std::vector<u64> tw(2048);
+    for (int reg = 0; reg < 16; reg++)
+        for (int lane = 0; lane < 64; lane++) {
+            const u64 kk = (u64)(lane >> 2) + 16 * (4 * (reg >> 2) + (lane & 3)) + 256 * (reg & 3);
+            tw[reg * 64 + lane] = f.pow(psi4096, 2 * kk + 1);
+            tw[1024 + reg * 64 + lane] = f.pow(inv, 2 * kk + 1);
+        }
+    return tw;
+}
+
 bool params_supported(const bmi_params &P, std::string &why) {
-    if (P.log_N != 10) { why = "only log_N = 10 (N = 1024) has a HIP kernel in this build"; return false; }
+    if (P.log_N != 10 && !(P.log_N == 11 && P.q_bits == 49)) {
+        why = "log_N must be 10 (N = 1024), or 11 (N = 2048) on the 49-bit field";
+        return false;
+    }
     if (P.k != 1) { why = "only k = 1 has a HIP kernel in this build"; return false; }
     if (P.bs_levels != 3 || P.bs_base_log != 15) { why = "only (l, Bg) = (3, 2^15) has a HIP kernel in this build"; return false; }
     if (P.n == 0 || P.n > 639) { why = "n must be in [1, 639]"; return false; }
@@ -287,6 +306,12 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
         if (hipMemcpy(c->d_tw_half, th.data(), th.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(half-transform twiddles) failed");
     }
+    if (c->wide()) {
+        const std::vector<double> tw = to_centred_doubles(build_twiddles_wide(c->f));
+        if (hipMalloc(&c->d_tw_wide, tw.size() * 8) != hipSuccess) return bail("hipMalloc(wide twiddles) failed");
+        if (hipMemcpy(c->d_tw_wide, tw.data(), tw.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+            return bail("hipMemcpy(wide twiddles) failed");
+    }
     c->lut_cap = 1024;
     if (hipMalloc(&c->d_luts, (size_t)c->lut_cap * c->N * 8) != hipSuccess) return bail("hipMalloc(luts) failed");
     *out = c;
@@ -299,7 +324,7 @@ void bmi_ctx_destroy(bmi_ctx *c) {
     for (void *p : {c->d_bsk, (void *)c->d_ksk, (void *)c->d_ks_bias, c->d_tw, c->d_luts, (void *)c->d_small,
                     (void *)c->d_io_a, (void *)c->d_io_b, (void *)c->d_io_ids, c->d_ks_partial,
                     (void *)c->d_ks_limbs, (void *)c->d_ks_digits, (void *)c->d_ks_sums, (void *)c->d_tw_half,
-                    (void *)c->d_bsk_lat})
+                    (void *)c->d_bsk_lat, (void *)c->d_tw_wide})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -387,20 +412,30 @@ int upload_eval_keys(bmi_ctx *c) {
     const uint32_t n = P.n, N = c->N, k = P.k, lk = P.ks_levels;
     // --- upload: bootstrap key -> NTT domain on the GPU; keyswitch key with padded rows
     const size_t bsk_words = c->bsk_std.size();
-    if (!c->d_bsk) HIP_OK(c, hipMalloc(&c->d_bsk, bsk_words * 8));
+    if (!c->d_bsk && !c->wide()) HIP_OK(c, hipMalloc(&c->d_bsk, bsk_words * 8));
     u64 *d_tmp = nullptr;
     HIP_OK(c, hipMalloc(&d_tmp, bsk_words * sizeof(u64)));
     HIP_OK(c, hipMemcpy(d_tmp, c->bsk_std.data(), bsk_words * sizeof(u64), hipMemcpyHostToDevice));
-    int rc = c->f64() ? bmi49::launch_bsk_to_ntt(d_tmp, (double *)c->d_bsk, (const double *)c->d_tw, (uint32_t)(bsk_words / N), c->stream)
-                      : bmi::launch_bsk_to_ntt(d_tmp, (u64 *)c->d_bsk, (const u64 *)c->d_tw, (uint32_t)(bsk_words / N), c->stream);
-    if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_ntt launch failed"); }
-    if (c->f64()) {  // second copy of the key, in the slot order of the split-transform latency kernel
+    int rc = 0;
+    if (c->wide()) {  // N = 2048: one key copy, in the slot order of k_blind_rotate_wide49
         if (!c->d_bsk_lat && hipMalloc(&c->d_bsk_lat, bsk_words * 8) != hipSuccess) {
             (void)hipFree(d_tmp);
-            return fail(c, -2, "hipMalloc(latency-kernel key) failed");
+            return fail(c, -2, "hipMalloc(wide key) failed");
         }
-        rc = bmi49::launch_bsk_to_lat(d_tmp, c->d_bsk_lat, c->d_tw_half, (uint32_t)(bsk_words / N), c->stream);
-        if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat launch failed"); }
+        rc = bmi49::launch_bsk_to_wide(d_tmp, c->d_bsk_lat, (const double *)c->d_tw, c->d_tw_wide, (uint32_t)(bsk_words / N), c->stream);
+        if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_wide launch failed"); }
+    } else {
+        rc = c->f64() ? bmi49::launch_bsk_to_ntt(d_tmp, (double *)c->d_bsk, (const double *)c->d_tw, (uint32_t)(bsk_words / N), c->stream)
+                      : bmi::launch_bsk_to_ntt(d_tmp, (u64 *)c->d_bsk, (const u64 *)c->d_tw, (uint32_t)(bsk_words / N), c->stream);
+        if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_ntt launch failed"); }
+        if (c->f64()) {  // second copy of the key, in the slot order of the split-transform latency kernel
+            if (!c->d_bsk_lat && hipMalloc(&c->d_bsk_lat, bsk_words * 8) != hipSuccess) {
+                (void)hipFree(d_tmp);
+                return fail(c, -2, "hipMalloc(latency-kernel key) failed");
+            }
+            rc = bmi49::launch_bsk_to_lat(d_tmp, c->d_bsk_lat, c->d_tw_half, (uint32_t)(bsk_words / N), c->stream);
+            if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat launch failed"); }
+        }
     }
     HIP_OK(c, hipStreamSynchronize(c->stream));
     HIP_OK(c, hipFree(d_tmp));
@@ -679,6 +714,10 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     if (c->f64()) {
         const double *luts = (const double *)c->d_luts, *bsk = (const double *)c->d_bsk, *tw = (const double *)c->d_tw;
         hipStream_t st = (hipStream_t)stream;
+        if (c->wide()) {   // N = 2048: one kernel for every batch size
+            rc = bmi49::launch_blind_rotate_wide(d_small, d_lut_ids, luts, c->d_bsk_lat, tw, c->d_tw_wide, d_out, count, c->P.n, st);
+            return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+        }
         // auto mode falls back from the kernels that need > 64 KB of LDS per workgroup to their predecessors (still on
         // the GPU) if the device refuses the configuration; a pinned variant reports the error instead
         if (c->variant == 4 || (latency && c->no_big_lds)) {
@@ -805,6 +844,7 @@ int bmi_blind_rotate_batch_host(bmi_ctx *c, const uint64_t *small_in, const uint
 
 int bmi_negacyclic_mul_host(bmi_ctx *c, const uint64_t *a, const uint64_t *b, uint32_t count, uint64_t *out) {
     if (!c || !a || !b || !out) return -1;
+    if (c->wide()) return fail(c, -1, "the transform test hook exists for N = 1024 only");
     HIP_OK(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)count * c->N * 8;
     u64 *da = nullptr, *db = nullptr, *dc = nullptr;

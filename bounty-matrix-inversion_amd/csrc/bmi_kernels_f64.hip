@@ -642,6 +642,158 @@ __global__ void __launch_bounds__(L2_THREADS)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Second parameter set, N = 2048 (k = 1, l = 3): a 2048-point negacyclic transform is two 1024-point wave transforms
+// (nttf::forward / inverse on the even and the odd coefficients, root psi_4096^2 = the 2048th root they are built on)
+// combined exactly like the two halves of ntt_half_f64.hpp:  A[kk] = E[kk] + T[kk] O[kk],  A[kk + 1024] = E - T O,
+// T = psi_4096^(2 kk + 1) in the slot order of the wave transform.  One workgroup of 8 wavefronts per ciphertext;
+// per CMUX the six digit polynomials are transformed in two rounds (input polynomial 0, then 1: six half-transform
+// tasks each, so that six LDS tiles suffice), every thread multiply-accumulates four (output, slot) items against
+// the key (own copy in slot order, already scaled by 1/2 for the split), four wavefronts run the inverse halves.
+// Twice the polynomial at the same n doubles the look-up boxes: 4-bit look-ups sit at 12.5 sigma instead of 6.2.
+constexpr int W_N = 2 * N;                 // 2048
+constexpr int W_THREADS = 512;
+constexpr int W_T = TW_WORDS;              // T table [reg][lane] (1024 words), then T^-1 (1024 words)
+constexpr int W_LDS_WORDS = TW_WORDS + 2 * N + 2 * W_N + 6 * SCRATCH_WORDS + 2 * W_N + 264;
+
+__device__ __forceinline__ void wide_forward_task(double (&x)[16], int h, int lane, const double *lds, double *tile) {
+    forward(x, lane, lds, tile);
+    if (h) static_for<0, 16>([&](auto V) { x[V] = f49::mul(x[V], lds[W_T + V * 64 + lane]); });
+    wave_sync();
+    static_for<0, 16>([&](auto V) { tile[V * 64 + lane] = f49::red(x[V]); });
+}
+
+__global__ void __launch_bounds__(128) k_bsk_to_wide49(const u64 *__restrict__ std_polys, double *__restrict__ wide_polys,
+                                                       const double *__restrict__ g_tw, const double *__restrict__ g_tw_wide,
+                                                       uint32_t n_polys) {
+    __shared__ double lds[TW_WORDS + N + 2 * SCRATCH_WORDS];
+    for (int i = threadIdx.x; i < TW_WORDS; i += blockDim.x) lds[i] = g_tw[i];
+    for (int i = threadIdx.x; i < N; i += blockDim.x) lds[W_T + i] = g_tw_wide[i];
+    __syncthreads();
+    const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t poly = blockIdx.x;      // one polynomial (2048 coefficients) per workgroup of two wavefronts
+    double *tile = lds + TW_WORDS + N + h * SCRATCH_WORDS;
+    double x[16];
+    static_for<0, 16>([&](auto J) { x[J] = f49::to_f(std_polys[(size_t)poly * W_N + 2 * (lane + 64 * J) + h]); });
+    wide_forward_task(x, h, lane, lds, tile);
+    __syncthreads();
+    const double *te = lds + TW_WORDS + N, *to = te + SCRATCH_WORDS;
+    constexpr double INV2 = f49::centred_c((f49::Q + 1) / 2);   // 1/2 mod q
+    double *o = wide_polys + (size_t)poly * W_N;
+    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+        o[p] = f49::red(f49::mul(te[p] + to[p], INV2));
+        o[N + p] = f49::red(f49::mul(te[p] - to[p], INV2));
+    }
+}
+
+__global__ void __launch_bounds__(W_THREADS)
+    k_blind_rotate_wide49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
+                          const double *__restrict__ luts, const double *__restrict__ bsk_wide,
+                          const double *__restrict__ g_tw, const double *__restrict__ g_tw_wide, u64 *__restrict__ out,
+                          uint32_t count, uint32_t n) {
+    extern __shared__ double lds[];
+    double *acc = lds + TW_WORDS + 2 * N;            // [2 components][2 parities][1024]
+    double *tiles = acc + 2 * W_N;                   // [6][SCRATCH_WORDS]
+    double *SD = tiles + 6 * SCRATCH_WORDS;          // [2 outputs][sum, difference][1024]
+    uint16_t *at = reinterpret_cast<uint16_t *>(SD + 2 * W_N);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < TW_WORDS; i += W_THREADS) lds[i] = g_tw[i];
+    for (int i = tid; i < 2 * N; i += W_THREADS) lds[W_T + i] = g_tw_wide[i];
+    const uint32_t ct = blockIdx.x;
+    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
+    for (uint32_t i = tid; i <= n; i += W_THREADS) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 2);
+    __syncthreads();
+    {
+        const double *tv = luts + (size_t)lut_ids[ct] * W_N;
+        const uint32_t bt = at[n];
+        for (uint32_t nn = tid; nn < (uint32_t)W_N; nn += W_THREADS) {
+            const uint32_t e = (nn + bt) & (2 * W_N - 1);
+            const double v = tv[e & (W_N - 1)];
+            acc[(nn & 1) * N + (nn >> 1)] = 0.0;
+            acc[W_N + (nn & 1) * N + (nn >> 1)] = (e & W_N) ? -v : v;
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t a_t = at[i];
+        if (a_t == 0) continue;  // uniform over the workgroup
+        const double *bi = bsk_wide + (size_t)i * 12 * W_N;
+        double ylo[4], yhi[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) ylo[q] = yhi[q] = 0.0;
+#pragma unroll 1
+        for (int c = 0; c < 2; c++) {      // input polynomial of this round
+            double b[4][3][2];             // key words of this thread's four (output, slot) items, rows 3 c .. 3 c + 2
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int idx = tid + W_THREADS * q, o = idx >> 10, p = idx & (N - 1);
+#pragma unroll
+                for (int lev = 0; lev < 3; lev++) {
+                    const double *row = bi + (size_t)((c * 3 + lev) * 2 + o) * W_N;
+                    b[q][lev][0] = row[p];
+                    b[q][lev][1] = row[N + p];
+                }
+            }
+            if (wave < 6) {
+                const int lev = wave >> 1, h = wave & 1;
+                const double *ac = acc + c * W_N;
+                double x[16];
+                static_for<0, 16>([&](auto J) {
+                    const uint32_t m = lane + 64 * J;
+                    const uint32_t e = (2 * m + h + 2 * W_N - a_t) & (2 * W_N - 1);
+                    const uint32_t n2 = e & (W_N - 1);
+                    double v = ac[(n2 & 1) * N + (n2 >> 1)];
+                    v = (e & W_N) ? -v : v;
+                    x[J] = digit_of(__builtin_rint(f49::red(v - ac[h * N + m]) * 0x1p-4), lev);
+                });
+                wide_forward_task(x, h, lane, lds, tiles + wave * SCRATCH_WORDS);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int p = (tid + W_THREADS * q) & (N - 1);
+#pragma unroll
+                for (int lev = 0; lev < 3; lev++) {
+                    const double e = tiles[(2 * lev) * SCRATCH_WORDS + p], od = tiles[(2 * lev + 1) * SCRATCH_WORDS + p];
+                    ylo[q] += f49::mul(e + od, b[q][lev][0]);   // e, od reduced (<= q/2): lazy sums of six products
+                    yhi[q] += f49::mul(e - od, b[q][lev][1]);
+                }
+            }
+            __syncthreads();   // the tiles are rewritten by the next round / the inverse transforms
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int idx = tid + W_THREADS * q, o = idx >> 10, p = idx & (N - 1);
+            const double lo = f49::red(ylo[q]), hi = f49::red(yhi[q]);
+            SD[(o * 2 + 0) * N + p] = f49::red(lo + hi);   // inverse() takes |.| <= 0.51 q
+            SD[(o * 2 + 1) * N + p] = lo - hi;             // reduced by the multiplication with T^-1
+        }
+        __syncthreads();
+        if (wave < 4) {
+            const int o = wave >> 1, h = wave & 1;
+            double x[16];
+            static_for<0, 16>([&](auto V) { x[V] = SD[(o * 2 + h) * N + V * 64 + lane]; });
+            if (h) static_for<0, 16>([&](auto V) { x[V] = f49::mul(x[V], lds[W_T + N + V * 64 + lane]); });
+            inverse(x, lane, lds, tiles + wave * SCRATCH_WORDS);
+            double *ao = acc + o * W_N + h * N;
+            static_for<0, 16>([&](auto J) { ao[lane + 64 * J] = f49::red(ao[lane + 64 * J] + x[J]); });
+        }
+        __syncthreads();
+    }
+    u64 *o = out + (size_t)ct * (W_N + 1);
+    for (uint32_t nn = tid; nn < (uint32_t)W_N; nn += W_THREADS) {
+        const double a0 = acc[(nn & 1) * N + (nn >> 1)];
+        if (nn == 0) {
+            o[0] = f49::to_u(a0);
+            o[W_N] = f49::to_u(acc[W_N]);
+        } else {
+            o[W_N - nn] = f49::to_u(-a0);
+        }
+    }
+}
+
 struct Field49 {
     static __device__ __forceinline__ void digits(u64 a, uint32_t levels, uint32_t base_log, unsigned char *d) {
         // centred lift, every rounding round-half-to-even, digits in [-B/2, B/2]
@@ -719,6 +871,27 @@ int launch_blind_rotate_tpx(const u64 *small_cts, const uint32_t *lut_ids, const
     return 0;
 }
 
+
+
+int launch_bsk_to_wide(const u64 *std_polys, double *wide_polys, const double *g_tw, const double *g_tw_wide,
+                       uint32_t n_polys, hipStream_t s) {
+    hipLaunchKernelGGL(k_bsk_to_wide49, dim3(n_polys), dim3(128), 0, s, std_polys, wide_polys, g_tw, g_tw_wide, n_polys);
+    BMI49_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_blind_rotate_wide(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk_wide,
+                             const double *g_tw, const double *g_tw_wide, u64 *out, uint32_t count, uint32_t n,
+                             hipStream_t s) {
+    if (count == 0) return 0;
+    static std::atomic<uint64_t> configured{0};
+    const size_t lds = (size_t)W_LDS_WORDS * sizeof(double);
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k_blind_rotate_wide49), lds, configured)) return rc;
+    hipLaunchKernelGGL(k_blind_rotate_wide49, dim3(count), dim3(W_THREADS), lds, s, small_cts, lut_ids, luts, bsk_wide, g_tw,
+                       g_tw_wide, out, count, n);
+    BMI49_LAUNCH_CHECK();
+    return 0;
+}
 
 int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, hipStream_t s) {
     hipLaunchKernelGGL(k_bsk_to_lat49, dim3((n_polys + 1) / 2), dim3(256), 0, s, std_polys, lat_polys, g_tw_h, n_polys);
