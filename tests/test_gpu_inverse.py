@@ -187,3 +187,23 @@ def test_two_rank_sharded_encrypted_inverse(tmp_path):
         assert np.load(tmp_path / f"out{r}.npy").tolist() == c["out"], r
     sharded, total, world = np.load(tmp_path / "meta0.npy")
     assert world == 2 and 0 < sharded < total
+
+
+def test_encrypted_2x2_inverse_on_the_N2048_parameter_set():
+    """The second parameter set (N = 2048, 49-bit field) under the whole stack: ciphertexts of 2,049 words through the
+    executor, the 16,384-row keyswitch and k_blind_rotate_wide49; decrypted digits equal the reference's."""
+    from bmi_amd import tfhe
+    from bmi_amd.main import EncryptedMatrixInversion
+    c = next(x for x in load("inverse.json") if x["tag"] == "baseline_n2_len20_ints8")
+    e = tfhe.Engine(tfhe.default_params(q_bits=49, log_N=11))
+    try:
+        e.keygen(0x5EED)
+        emi = EncryptedMatrixInversion(2, None, 2, c["len"], c["ints"], False, False, engine=e)
+        M = np.array(c["M"]).reshape(2, 2)
+        q, s = emi.quantize(M)
+        enc = emi.encrypt(q, s)
+        assert enc.shape == (84, 2049)
+        out = emi.decrypt(emi.evaluate(enc))
+        assert out.tolist() == c["out"]
+    finally:
+        e.close()
