@@ -12,15 +12,18 @@ from oracle import tfhe_oracle as to
 def main():
     qb = int(sys.argv[1]) if len(sys.argv) > 1 else 49
     budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
-    eng = tfhe.Engine(tfhe.default_params(q_bits=qb)); eng.keygen(77)
+    log_N = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    eng = tfhe.Engine(tfhe.default_params(q_bits=qb, log_N=log_N)); eng.keygen(77)
     dl = eng.delta_log()
     _, _, bsk, ksk = eng.export_keys()
-    octx = to.Ctx(to.default_params(q_bits=qb), bsk, ksk)
+    octx = to.Ctx(to.default_params(q_bits=qb, log_N=log_N), bsk, ksk)
     rng = np.random.default_rng(2024)
     table = rng.integers(-8, 8, 16)
     lid = eng.lut_register(table, 4, dl)
     tv = eng.lut_get(lid)[None, :]
     sizes = [1, 2, 3, 4, 5, 7, 8, 9, 31, 32, 33, 63, 64, 65, 255, 256, 257, 511, 512, 513, 515, 1023, 1024, 1025, 2047, 4097, 8191, 8192]
+    if log_N != 10:
+        sizes = [s_ for s_ in sizes if s_ <= 1025]
     t0 = time.time(); runs = 0; checked = 0
     while time.time() - t0 < budget:
         for B in sizes:
@@ -28,7 +31,7 @@ def main():
             ct = eng.encrypt(msgs, dl)
             ids = np.full(B, lid, np.uint32)
             ref = None
-            for variant in ((0, 1, 2, 3, 4) if B <= 600 else (0, 1, 3)):
+            for variant in ((0,) if log_N != 10 else (0, 1, 2, 3, 4) if B <= 600 else (0, 1, 3)):
                 eng.set_kernel_variant(variant)
                 out = eng.pbs_host(ct, ids)
                 assert np.array_equal(eng.decrypt(out, dl), table[msgs + 8]), (B, variant)
