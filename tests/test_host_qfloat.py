@@ -257,6 +257,47 @@ def test_wide_odd_lookup_and_lookahead_networks():
         bpa.WIDE_LOOKAHEAD = saved
 
 
+def test_width_aware_level_schedule_properties():
+    """Circuit.levels(): same depth as ASAP, every node after its producers, all nodes scheduled exactly once, and no
+    level wider than the rounds its critical nodes need (random layered circuits + the traced 2x2 inverse)."""
+    import random
+
+    def check(c):
+        asap = c.asap_levels()
+        lv = c.levels()
+        assert len(lv) == len(asap)
+        pos = {}
+        for li, level in enumerate(lv):
+            for i in level:
+                assert i not in pos
+                pos[i] = li
+        assert len(pos) == len(c.nodes)
+        producer = {leaf: i for i, (_, _, _, leaf) in enumerate(c.nodes)}
+        for i, (terms, _, _, _) in enumerate(c.nodes):
+            for t, _ in terms:
+                if t in producer:
+                    assert pos[producer[t]] < pos[i]
+        cost = lambda w: -(-w // 256) if w <= 512 else 2.45 * -(-w // 1024)  # noqa: E731  (rounds, in latency-round units)
+        assert sum(cost(len(x)) for x in lv) <= sum(cost(len(x)) for x in asap) + 1e-9
+        return lv
+
+    rng = random.Random(3)
+    for trial in range(3):
+        c = Circuit()
+        pool = [c.input(0, 1) for _ in range(40)]
+        for depth in range(12):
+            width = rng.choice([30, 200, 300, 600])
+            new = []
+            for _ in range(width):
+                a, b = rng.sample(pool[-400:], 2)
+                new.append(c.lut(a + b, lambda v: int(v == 1)))
+            pool += new
+        c.set_outputs(pool[-5:])
+        check(c)
+    lv = check(trace_inverse(2, 20, 8, 2, False, False))
+    assert max(len(x) for x in lv) <= 512
+
+
 def test_traced_tidy_on_mixed_sign_digits():
     """Pattern of the reference's test_tidy_np (tests/test_qfloat.py:191-213) on encrypted digits.  The
     reference draws untidy digits in [-4b, 4b), which only its plaintext mode can hold; on ciphertexts a
