@@ -104,6 +104,7 @@ struct bmi_ctx {
     double *d_tw_half = nullptr, *d_bsk_lat = nullptr;          // 49-bit field: tables and key copy of the split-transform latency kernel
     double *d_tw_wide = nullptr;                                // N = 2048: T / T^-1 of the even/odd combination (d_bsk_lat then holds the wide key copy)
     bool wide() const { return N == 2048; }
+    bool quad() const { return N == 4096; }   // d_tw_wide then holds T_1..T_3 and their inverses, d_bsk_lat the quad key copy
     u64 *d_ksk = nullptr, *d_ks_bias = nullptr;
     uint32_t n_luts = 0, lut_cap = 0;
     std::vector<std::vector<u64>> luts_host;
@@ -235,9 +236,23 @@ std::vector<u64> build_twiddles_wide(const Fq &f) {
     return tw;
 }
 
+// N = 4096: T_j[reg * 64 + lane] = psi_8192^((2 kk + 1) j) for j = 1, 2, 3, then the three inverse tables
+std::vector<u64> build_twiddles_quad(const Fq &f) {
+    const u64 psi = f.pow(f49::GEN, (f.q - 1) / 8192), inv = f.pow(psi, f.q - 2);
+    std::vector<u64> tw(6 * 1024);
+    for (int j = 1; j <= 3; j++)
+        for (int reg = 0; reg < 16; reg++)
+            for (int lane = 0; lane < 64; lane++) {
+                const u64 kk = (u64)(lane >> 2) + 16 * (4 * (reg >> 2) + (lane & 3)) + 256 * (reg & 3);
+                tw[(j - 1) * 1024 + reg * 64 + lane] = f.pow(psi, (2 * kk + 1) * j);
+                tw[(3 + j - 1) * 1024 + reg * 64 + lane] = f.pow(inv, (2 * kk + 1) * j);
+            }
+    return tw;
+}
+
 bool params_supported(const bmi_params &P, std::string &why) {
-    if (P.log_N != 10 && !(P.log_N == 11 && P.q_bits == 49)) {
-        why = "log_N must be 10 (N = 1024), or 11 (N = 2048) on the 49-bit field";
+    if (P.log_N != 10 && !((P.log_N == 11 || P.log_N == 12) && P.q_bits == 49)) {
+        why = "log_N must be 10 (N = 1024), or 11 / 12 (N = 2048 / 4096) on the 49-bit field";
         return false;
     }
     if (P.k != 1) { why = "only k = 1 has a HIP kernel in this build"; return false; }
@@ -306,8 +321,8 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
         if (hipMemcpy(c->d_tw_half, th.data(), th.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(half-transform twiddles) failed");
     }
-    if (c->wide()) {
-        const std::vector<double> tw = to_centred_doubles(build_twiddles_wide(c->f));
+    if (c->wide() || c->quad()) {
+        const std::vector<double> tw = to_centred_doubles(c->quad() ? build_twiddles_quad(c->f) : build_twiddles_wide(c->f));
         if (hipMalloc(&c->d_tw_wide, tw.size() * 8) != hipSuccess) return bail("hipMalloc(wide twiddles) failed");
         if (hipMemcpy(c->d_tw_wide, tw.data(), tw.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(wide twiddles) failed");
@@ -412,17 +427,17 @@ int upload_eval_keys(bmi_ctx *c) {
     const uint32_t n = P.n, N = c->N, k = P.k, lk = P.ks_levels;
     // --- upload: bootstrap key -> NTT domain on the GPU; keyswitch key with padded rows
     const size_t bsk_words = c->bsk_std.size();
-    if (!c->d_bsk && !c->wide()) HIP_OK(c, hipMalloc(&c->d_bsk, bsk_words * 8));
+    if (!c->d_bsk && !c->wide() && !c->quad()) HIP_OK(c, hipMalloc(&c->d_bsk, bsk_words * 8));
     u64 *d_tmp = nullptr;
     HIP_OK(c, hipMalloc(&d_tmp, bsk_words * sizeof(u64)));
     HIP_OK(c, hipMemcpy(d_tmp, c->bsk_std.data(), bsk_words * sizeof(u64), hipMemcpyHostToDevice));
     int rc = 0;
-    if (c->wide()) {  // N = 2048: one key copy, in the slot order of k_blind_rotate_wide49
+    if (c->wide() || c->quad()) {  // N = 2048 / 4096: one key copy, in the slot order of k_blind_rotate_wide49 / quad49
         if (!c->d_bsk_lat && hipMalloc(&c->d_bsk_lat, bsk_words * 8) != hipSuccess) {
             (void)hipFree(d_tmp);
             return fail(c, -2, "hipMalloc(wide key) failed");
         }
-        rc = bmi49::launch_bsk_to_wide(d_tmp, c->d_bsk_lat, (const double *)c->d_tw, c->d_tw_wide, (uint32_t)(bsk_words / N), c->stream);
+        rc = (c->quad() ? bmi49::launch_bsk_to_quad : bmi49::launch_bsk_to_wide)(d_tmp, c->d_bsk_lat, (const double *)c->d_tw, c->d_tw_wide, (uint32_t)(bsk_words / N), c->stream);
         if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_wide launch failed"); }
     } else {
         rc = c->f64() ? bmi49::launch_bsk_to_ntt(d_tmp, (double *)c->d_bsk, (const double *)c->d_tw, (uint32_t)(bsk_words / N), c->stream)
@@ -714,8 +729,8 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     if (c->f64()) {
         const double *luts = (const double *)c->d_luts, *bsk = (const double *)c->d_bsk, *tw = (const double *)c->d_tw;
         hipStream_t st = (hipStream_t)stream;
-        if (c->wide()) {   // N = 2048: one kernel for every batch size
-            rc = bmi49::launch_blind_rotate_wide(d_small, d_lut_ids, luts, c->d_bsk_lat, tw, c->d_tw_wide, d_out, count, c->P.n, st);
+        if (c->wide() || c->quad()) {   // N = 2048 / 4096: one kernel for every batch size
+            rc = (c->quad() ? bmi49::launch_blind_rotate_quad : bmi49::launch_blind_rotate_wide)(d_small, d_lut_ids, luts, c->d_bsk_lat, tw, c->d_tw_wide, d_out, count, c->P.n, st);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }
         // auto mode falls back from the kernels that need > 64 KB of LDS per workgroup to their predecessors (still on
@@ -844,7 +859,7 @@ int bmi_blind_rotate_batch_host(bmi_ctx *c, const uint64_t *small_in, const uint
 
 int bmi_negacyclic_mul_host(bmi_ctx *c, const uint64_t *a, const uint64_t *b, uint32_t count, uint64_t *out) {
     if (!c || !a || !b || !out) return -1;
-    if (c->wide()) return fail(c, -1, "the transform test hook exists for N = 1024 only");
+    if (c->wide() || c->quad()) return fail(c, -1, "the transform test hook exists for N = 1024 only");
     HIP_OK(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)count * c->N * 8;
     u64 *da = nullptr, *db = nullptr, *dc = nullptr;

@@ -82,6 +82,11 @@ int launch_bsk_to_ntt(const u64 *std_polys, double *ntt_polys, const double *g_t
 int launch_negacyclic_mul(const u64 *a, const u64 *b, u64 *c, const double *g_tw, uint32_t count, hipStream_t s);
 int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
                            const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s);
+// third parameter set N = 4096: key copy in slot order (scaled by 1/4); g_t = T_1, T_2, T_3, then their inverses ([6][1024])
+int launch_bsk_to_quad(const u64 *std_polys, double *quad_polys, const double *g_tw, const double *g_t, uint32_t n_polys,
+                       hipStream_t s);
+int launch_blind_rotate_quad(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk_quad,
+                             const double *g_tw, const double *g_t, u64 *out, uint32_t count, uint32_t n, hipStream_t s);
 // second parameter set N = 2048: key copy in slot order (scaled by 1/2), table T / T^-1 of the even/odd combination
 int launch_bsk_to_wide(const u64 *std_polys, double *wide_polys, const double *g_tw, const double *g_tw_wide,
                        uint32_t n_polys, hipStream_t s);

@@ -794,6 +794,199 @@ __global__ void __launch_bounds__(W_THREADS)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Third parameter set, N = 4096: the same construction one level deeper.  a is split by index mod 4 into four
+// 1024-coefficient parts a_j; with psi = psi_8192 (psi^4 is the 2048th root of the wave transform) and S_j = NTT1024(a_j):
+//     A[kk + 1024 t] = sum_j i^(t j) T_j[kk] S_j[kk],   T_j = psi^((2 kk + 1) j),   i = psi^2048 (i^2 = -1),
+// i.e. a 4-point DFT (one multiplication by i) of the twisted parts, formed where the values are consumed.  Per CMUX
+// three rounds of two GGSW rows (8 part-transform tasks = one per wavefront, 8 LDS tiles); every thread owns four
+// (output, slot) items with four accumulators each; the inverse 4-point DFT is applied by the same threads, the sums go
+// through the tile region to eight inverse part-transform tasks.  The key copy is in slot order, scaled by 1/4.
+constexpr int Q_N = 4 * N;                 // 4096
+constexpr int Q_THREADS = 512;
+constexpr int Q_LDS_WORDS = TW_WORDS + 2 * Q_N + 8 * SCRATCH_WORDS + 264;
+constexpr double I4 = f49::centred_c(f49::powmod_c(f49::GEN, (f49::Q - 1) / 4));          // psi_8192^2048
+constexpr double I4_INV = f49::centred_c(f49::powmod_c(f49::GEN, 3 * ((f49::Q - 1) / 4)));  // -i
+static_assert(f49::mulmod_c(f49::powmod_c(f49::GEN, (f49::Q - 1) / 4), f49::powmod_c(f49::GEN, (f49::Q - 1) / 4)) == f49::Q - 1, "i^2 = -1");
+
+// part transform of part j (0..3): forward, twist by T_j (j >= 1; g_t = tables [3][1024] in (reg, lane) order), store reduced
+__device__ __forceinline__ void quad_forward_task(double (&x)[16], int j, int lane, const double *lds, const double *g_t,
+                                                  double *tile) {
+    double t[16];   // requested before the transform that hides the latency (part 0 reads T_1 and ignores it)
+    const double *tp = g_t + (j ? j - 1 : 0) * N;
+    static_for<0, 16>([&](auto V) { t[V] = tp[V * 64 + lane]; });
+    sched_fence();
+    forward(x, lane, lds, tile);
+    if (j) static_for<0, 16>([&](auto V) { x[V] = f49::mul(x[V], t[V]); });
+    wave_sync();
+    static_for<0, 16>([&](auto V) { tile[V * 64 + lane] = f49::red(x[V]); });
+}
+
+// the four values A_t (t = 0..3) of one slot from the four twisted parts (each <= q/2): |A_t| <= 2.6 q
+__device__ __forceinline__ void dft4_parts(double s0, double s1, double s2, double s3, double (&a)[4]) {
+    const double u = s0 + s2, v = s0 - s2, w = s1 + s3, z = f49::mul(s1 - s3, I4);
+    a[0] = u + w;
+    a[1] = v + z;
+    a[2] = u - w;
+    a[3] = v - z;
+}
+
+__global__ void __launch_bounds__(256) k_bsk_to_quad49(const u64 *__restrict__ std_polys, double *__restrict__ quad_polys,
+                                                       const double *__restrict__ g_tw, const double *__restrict__ g_t,
+                                                       uint32_t n_polys) {
+    __shared__ double lds[TW_WORDS + 4 * SCRATCH_WORDS];
+    for (int i = threadIdx.x; i < TW_WORDS; i += blockDim.x) lds[i] = g_tw[i];
+    __syncthreads();
+    const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t poly = blockIdx.x;      // one polynomial (4096 coefficients) per workgroup of four wavefronts
+    double *tiles = lds + TW_WORDS;
+    double x[16];
+    static_for<0, 16>([&](auto J) { x[J] = f49::to_f(std_polys[(size_t)poly * Q_N + 4 * (lane + 64 * J) + j]); });
+    quad_forward_task(x, j, lane, lds, g_t, tiles + j * SCRATCH_WORDS);
+    __syncthreads();
+    constexpr double INV4 = f49::centred_c(f49::powmod_c(4, f49::Q - 2));
+    double *o = quad_polys + (size_t)poly * Q_N;
+    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+        double a[4];
+        dft4_parts(tiles[p], tiles[SCRATCH_WORDS + p], tiles[2 * SCRATCH_WORDS + p], tiles[3 * SCRATCH_WORDS + p], a);
+#pragma unroll
+        for (int t = 0; t < 4; t++) o[t * N + p] = f49::red(f49::mul(a[t], INV4));
+    }
+}
+
+__global__ void __launch_bounds__(Q_THREADS)
+    k_blind_rotate_quad49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
+                          const double *__restrict__ luts, const double *__restrict__ bsk_quad,
+                          const double *__restrict__ g_tw, const double *__restrict__ g_t, u64 *__restrict__ out,
+                          uint32_t count, uint32_t n) {
+    extern __shared__ double lds[];
+    double *acc = lds + TW_WORDS;                    // [2 components][4 parts][1024]
+    double *tiles = acc + 2 * Q_N;                   // [8][SCRATCH_WORDS]; also takes the 2 x 4 x 1024 sums before the inverses
+    uint16_t *at = reinterpret_cast<uint16_t *>(tiles + 8 * SCRATCH_WORDS);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < TW_WORDS; i += Q_THREADS) lds[i] = g_tw[i];
+    const uint32_t ct = blockIdx.x;
+    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
+    for (uint32_t i = tid; i <= n; i += Q_THREADS) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 3);
+    __syncthreads();
+    {
+        const double *tv = luts + (size_t)lut_ids[ct] * Q_N;
+        const uint32_t bt = at[n];
+        for (uint32_t nn = tid; nn < (uint32_t)Q_N; nn += Q_THREADS) {
+            const uint32_t e = (nn + bt) & (2 * Q_N - 1);
+            const double v = tv[e & (Q_N - 1)];
+            acc[(nn & 3) * N + (nn >> 2)] = 0.0;
+            acc[Q_N + (nn & 3) * N + (nn >> 2)] = (e & Q_N) ? -v : v;
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t a_t = at[i];
+        if (a_t == 0) continue;  // uniform over the workgroup
+        const double *bi = bsk_quad + (size_t)i * 12 * Q_N;
+        double y[4][4];          // [item][t]
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) y[q][t] = 0.0;
+#pragma unroll 1
+        for (int rnd = 0; rnd < 3; rnd++) {     // GGSW rows 2 rnd, 2 rnd + 1
+            {
+                const int row = 2 * rnd + (wave >> 2), c = row / 3, lev = row % 3, j = wave & 3;
+                const double *ac = acc + c * Q_N;
+                double x[16];
+                static_for<0, 16>([&](auto J) {
+                    const uint32_t m = lane + 64 * J;
+                    const uint32_t e = (4 * m + j + 2 * Q_N - a_t) & (2 * Q_N - 1);
+                    const uint32_t n2 = e & (Q_N - 1);
+                    double v = ac[(n2 & 3) * N + (n2 >> 2)];
+                    v = (e & Q_N) ? -v : v;
+                    x[J] = digit_of(__builtin_rint(f49::red(v - ac[j * N + m]) * 0x1p-4), lev);
+                });
+                quad_forward_task(x, j, lane, lds, g_t, tiles + wave * SCRATCH_WORDS);
+            }
+            __syncthreads();
+            {
+                // key words of item q + 1 are requested while item q is multiplied (16 words in flight per thread)
+                auto key_ptr = [&](int q, int rr) {
+                    const int idx = tid + Q_THREADS * q, o = idx >> 10, p = idx & (N - 1);
+                    return bi + (size_t)((2 * rnd + rr) * 2 + o) * Q_N + p;
+                };
+                double bc[2][4], bn[2][4];
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) bc[rr][t] = key_ptr(0, rr)[t * N];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int p = (tid + Q_THREADS * q) & (N - 1);
+                    if (q < 3) {
+#pragma unroll
+                        for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                            for (int t = 0; t < 4; t++) bn[rr][t] = key_ptr(q + 1, rr)[t * N];
+                    }
+                    sched_fence();
+#pragma unroll
+                    for (int rr = 0; rr < 2; rr++) {
+                        const double *tb = tiles + (4 * rr) * SCRATCH_WORDS + p;
+                        double a[4];
+                        dft4_parts(tb[0], tb[SCRATCH_WORDS], tb[2 * SCRATCH_WORDS], tb[3 * SCRATCH_WORDS], a);
+#pragma unroll
+                        for (int t = 0; t < 4; t++) y[q][t] += f49::mul(a[t], bc[rr][t]);   // six products of <= 0.83 q each
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                        for (int t = 0; t < 4; t++) bc[rr][t] = bn[rr][t];
+                }
+            }
+            __syncthreads();   // the tiles are rewritten by the next round
+        }
+        double ti[16];   // this wavefront's T_j^-1 row, requested ahead of the barrier (part 0 ignores it)
+        {
+            const double *tp = g_t + (3 + ((wave & 3) ? (wave & 3) - 1 : 0)) * N;
+            static_for<0, 16>([&](auto V) { ti[V] = tp[V * 64 + lane]; });
+        }
+        // inverse 4-point DFT of the (reduced) sums; the results go through the tile region
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int idx = tid + Q_THREADS * q, o = idx >> 10, p = idx & (N - 1);
+            const double y0 = f49::red(y[q][0]), y1 = f49::red(y[q][1]), y2 = f49::red(y[q][2]), y3 = f49::red(y[q][3]);
+            const double u = y0 + y2, v = y0 - y2, w = y1 + y3, z = f49::mul(y1 - y3, I4_INV);
+            double *sd = tiles + (size_t)(o * 4) * N + p;    // packed [2][4][1024] inside the tile region
+            sd[0] = f49::red(u + w);          // inverse() takes |.| <= 0.57 q
+            sd[N] = f49::red(v + z);
+            sd[2 * N] = f49::red(u - w);
+            sd[3 * N] = f49::red(v - z);
+        }
+        __syncthreads();
+        double x[16];
+        const int o = wave >> 2, j = wave & 3;
+        static_for<0, 16>([&](auto V) { x[V] = tiles[(size_t)(o * 4 + j) * N + V * 64 + lane]; });
+        if (j) static_for<0, 16>([&](auto V) { x[V] = f49::mul(x[V], ti[V]); });
+        __syncthreads();       // every wavefront holds its sums: the tile region is scratch again
+        inverse(x, lane, lds, tiles + wave * SCRATCH_WORDS);
+        {
+            double *ao = acc + o * Q_N + j * N;
+            static_for<0, 16>([&](auto J) { ao[lane + 64 * J] = f49::red(ao[lane + 64 * J] + x[J]); });
+        }
+        __syncthreads();
+    }
+    u64 *o = out + (size_t)ct * (Q_N + 1);
+    for (uint32_t nn = tid; nn < (uint32_t)Q_N; nn += Q_THREADS) {
+        const double a0 = acc[(nn & 3) * N + (nn >> 2)];
+        if (nn == 0) {
+            o[0] = f49::to_u(a0);
+            o[Q_N] = f49::to_u(acc[Q_N]);
+        } else {
+            o[Q_N - nn] = f49::to_u(-a0);
+        }
+    }
+}
+
 struct Field49 {
     static __device__ __forceinline__ void digits(u64 a, uint32_t levels, uint32_t base_log, unsigned char *d) {
         // centred lift, every rounding round-half-to-even, digits in [-B/2, B/2]
@@ -872,6 +1065,26 @@ int launch_blind_rotate_tpx(const u64 *small_cts, const uint32_t *lut_ids, const
 }
 
 
+
+
+int launch_bsk_to_quad(const u64 *std_polys, double *quad_polys, const double *g_tw, const double *g_t, uint32_t n_polys,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_bsk_to_quad49, dim3(n_polys), dim3(256), 0, s, std_polys, quad_polys, g_tw, g_t, n_polys);
+    BMI49_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_blind_rotate_quad(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk_quad,
+                             const double *g_tw, const double *g_t, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+    if (count == 0) return 0;
+    static std::atomic<uint64_t> configured{0};
+    const size_t lds = (size_t)Q_LDS_WORDS * sizeof(double);
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k_blind_rotate_quad49), lds, configured)) return rc;
+    hipLaunchKernelGGL(k_blind_rotate_quad49, dim3(count), dim3(Q_THREADS), lds, s, small_cts, lut_ids, luts, bsk_quad, g_tw,
+                       g_t, out, count, n);
+    BMI49_LAUNCH_CHECK();
+    return 0;
+}
 
 int launch_bsk_to_wide(const u64 *std_polys, double *wide_polys, const double *g_tw, const double *g_tw_wide,
                        uint32_t n_polys, hipStream_t s) {

@@ -24,7 +24,7 @@ int main(void) {
 
     bmi_ctx *ctx = NULL;
     bmi_params bad = P;
-    bad.log_N = 12; /* no HIP kernel for N = 4096 in this build (N = 2048 exists on the 49-bit field) */
+    bad.log_N = 13; /* no HIP kernel for N = 8192 in this build (N = 2048 and 4096 exist on the 49-bit field) */
     CHECK(bmi_ctx_create(&bad, 0, &ctx) < 0 && ctx == NULL, "unsupported parameters rejected");
     CHECK(strlen(bmi_last_error(NULL)) > 0, "create error text available");
     CHECK(bmi_ctx_create(&P, 99, &ctx) < 0, "bad device index rejected");

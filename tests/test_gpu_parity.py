@@ -433,18 +433,20 @@ def test_key_import_and_evaluation_only_context(tmp_path):
         a.close(); b.close(); c.close()
 
 
-def test_second_parameter_set_N2048_bit_exact():
-    """N = 2048 (k = 1, l = 3, n = 630) on the 49-bit field: the 2048-point transform as two 1024-point wave transforms
-    (even / odd coefficients) combined on the fly.  Keygen, keyswitch (16,384-row matrix-core product), blind rotation
-    and the fused PBS against the oracle; every 4-bit message through a random table; ragged batch; the noise margin
-    doubles against N = 1024 (look-up boxes twice as wide at the same mod-switch noise)."""
+@pytest.mark.parametrize("log_N", [11, 12], ids=["N2048", "N4096"])
+def test_wider_parameter_sets_bit_exact(log_N):
+    """N = 2048 and N = 4096 (k = 1, l = 3, n = 630) on the 49-bit field: the transform as two / four 1024-point wave
+    transforms (coefficients by index mod 2 / mod 4) combined on the fly.  Keygen, keyswitch (16,384 / 32,768-row
+    matrix-core product), blind rotation and the fused PBS against the oracle; every 4-bit message through a random
+    table; ragged batch; one more message bit per doubling of N at the same margin (5-bit / 6-bit look-ups)."""
     from bmi_amd import tfhe
     from oracle import tfhe_oracle as to
-    e = tfhe.Engine(tfhe.default_params(q_bits=49, log_N=11))
+    N = 1 << log_N
+    e = tfhe.Engine(tfhe.default_params(q_bits=49, log_N=log_N))
     try:
         e.keygen(SEED + 2)
         to.set_field(49)
-        P = to.default_params(q_bits=49, log_N=11)
+        P = to.default_params(q_bits=49, log_N=log_N)
         sk_small, sk_big, bsk, ksk = e.export_keys()
         K = to.keygen(P, SEED + 2)
         assert np.array_equal(K.bsk, bsk) and np.array_equal(K.ksk, ksk) and np.array_equal(K.sk_big, sk_big)
@@ -453,10 +455,10 @@ def test_second_parameter_set_N2048_bit_exact():
         dl = e.delta_log()
         table = rng.integers(-8, 8, 16)
         lid = e.lut_register(table, 4, dl)
-        assert np.array_equal(e.lut_get(lid), to.make_test_vector(11, 4, table, dl))
+        assert np.array_equal(e.lut_get(lid), to.make_test_vector(log_N, 4, table, dl))
         msgs = np.concatenate([np.arange(-8, 8), rng.integers(-8, 8, 5)])   # 21: ragged against every tile size
         ct = e.encrypt(msgs, dl)
-        assert ct.shape == (21, 2049)
+        assert ct.shape == (21, N + 1)
         small = e.keyswitch_host(ct)
         assert np.array_equal(small, ctx.keyswitch(ct))
         ids = np.full(msgs.size, lid, np.uint32)
@@ -467,15 +469,16 @@ def test_second_parameter_set_N2048_bit_exact():
         assert np.array_equal(out[pick], want)
         assert np.array_equal(e.blind_rotate_host(small[pick], ids[pick]), want)
         with pytest.raises(tfhe.BmiError):
-            e.negacyclic_mul_host(np.zeros((1, 2048), np.uint64), np.zeros((1, 2048), np.uint64))
-        # 5-bit messages fit this ring at the margin 4-bit ones have at N = 1024
-        t5 = rng.integers(-16, 16, 32)
-        l5 = e.lut_register(t5, 5, e.q_bits - 1 - 5)
-        m5 = rng.integers(-16, 16, 12)
-        o5 = e.pbs_host(e.encrypt(m5, e.q_bits - 1 - 5), np.full(12, l5, np.uint32))
-        assert list(e.decrypt(o5, e.q_bits - 1 - 5)) == list(t5[m5 + 16])
+            e.negacyclic_mul_host(np.zeros((1, N), np.uint64), np.zeros((1, N), np.uint64))
+        # 5-bit (N = 2048) / 6-bit (N = 4096) messages fit these rings at the margin 4-bit ones have at N = 1024
+        pw = log_N - 6
+        tw = rng.integers(-(1 << (pw - 1)), 1 << (pw - 1), 1 << pw)
+        lw = e.lut_register(tw, pw, e.q_bits - 1 - pw)
+        mw = np.concatenate([rng.integers(-(1 << (pw - 1)), 1 << (pw - 1), 10), [-(1 << (pw - 1)), (1 << (pw - 1)) - 1]])
+        ow = e.pbs_host(e.encrypt(mw, e.q_bits - 1 - pw), np.full(mw.size, lw, np.uint32))
+        assert list(e.decrypt(ow, e.q_bits - 1 - pw)) == list(tw[mw + (1 << (pw - 1))])
         ctx.close()
     finally:
         e.close()
     with pytest.raises(tfhe.BmiError):
-        tfhe.Engine(tfhe.default_params(q_bits=64, log_N=11))    # N = 2048 exists on the 49-bit field only
+        tfhe.Engine(tfhe.default_params(q_bits=64, log_N=log_N))    # the wider rings exist on the 49-bit field only
