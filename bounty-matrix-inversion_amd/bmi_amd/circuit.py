@@ -153,7 +153,11 @@ def _NE0(v):
 
 
 class Circuit:
-    def __init__(self):
+    def __init__(self, msg_bits=MSG_BITS):
+        """msg_bits: message bits of every ciphertext of this circuit (look-ups take 2^msg_bits values, lut_odd twice
+        that).  4 is what N = 1024 carries at 6.2 sigma (the QFloat layer uses it); the N = 2048 / 4096 parameter sets
+        carry 5 / 6 at the same margin."""
+        self.msg_bits = int(msg_bits)
         self.n_inputs = 0
         self.leaf_level = []     # per leaf
         self.leaf_lo = []
@@ -195,14 +199,14 @@ class Circuit:
             self.stats["const_folds"] += 1
             return self.const(fn(x.const))
         width = x.hi - x.lo + 1
-        if width > (1 << MSG_BITS):
-            raise RangeError(f"look-up input interval [{x.lo}, {x.hi}] wider than {1 << MSG_BITS} values")
+        if width > (1 << self.msg_bits):
+            raise RangeError(f"look-up input interval [{x.lo}, {x.hi}] wider than {1 << self.msg_bits} values")
         vals = [int(fn(v)) for v in range(x.lo, x.hi + 1)]
         olo, ohi = min(vals), max(vals)
         if olo == ohi:
             self.stats["const_folds"] += 1
             return self.const(olo)
-        if not (-(1 << MSG_BITS) <= olo and ohi < (1 << MSG_BITS)):
+        if not (-(1 << self.msg_bits) <= olo and ohi < (1 << self.msg_bits)):
             raise RangeError(f"look-up output interval [{olo}, {ohi}] does not fit the message space")
         p = 1
         while (1 << p) < width:
@@ -217,7 +221,7 @@ class Circuit:
             li = len(self.luts)
             self.luts.append(key)
             self._lut_index[key] = li
-        scale = 1 << (MSG_BITS - p)
+        scale = 1 << (self.msg_bits - p)
         pin = (x - off) * scale
         snap = self._snapshot(pin)
         ck = (snap, li)
@@ -235,9 +239,9 @@ class Circuit:
         return Lin(self, {leaf: 1}, 0, olo, ohi)
 
     def lut_odd(self, x, fn):
-        """Look-up on a FIVE-bit input for functions with f(v - 2^MSG_BITS) = -f(v) (sign-like functions).
+        """Look-up on a (msg_bits + 1)-bit input for functions with f(v - 2^msg_bits) = -f(v) (sign-like functions).
 
-        A MSG_BITS-bit message occupies half of the torus; the negacyclic test polynomial returns -f(v - 16) for an
+        A msg_bits-bit message occupies half of the torus; the negacyclic test polynomial returns -f(v - 16) for an
         input v in [8, 16) and -f(v + 16) for v in [-16, -8).  For a function with exactly that symmetry the look-up is
         therefore correct on the whole interval [-15, 15] with the ordinary 16-entry table, the same box width and
         the same noise margin as any 4-bit look-up.  This packs FOUR binary digit differences (8 d3 + 4 d2 + 2 d1 + d0)
@@ -248,8 +252,8 @@ class Circuit:
         if x.is_const:
             self.stats["const_folds"] += 1
             return self.const(fn(x.const))
-        half = 1 << (MSG_BITS - 1)
-        period = 1 << MSG_BITS      # f(v - period) = -f(v); the torus holds 2 * period boxes
+        half = 1 << (self.msg_bits - 1)
+        period = 1 << self.msg_bits      # f(v - period) = -f(v); the torus holds 2 * period boxes
         if x.lo < -(period - 1) or x.hi > period - 1:
             raise RangeError(f"wide look-up input interval [{x.lo}, {x.hi}] outside [-{period - 1}, {period - 1}]")
         if -half <= x.lo and x.hi < half:
@@ -279,7 +283,7 @@ class Circuit:
                 table[i] = last
             else:
                 last = table[i]
-        key = (MSG_BITS, tuple(table))
+        key = (self.msg_bits, tuple(table))
         li = self._lut_index.get(key)
         if li is None:
             li = len(self.luts)
@@ -314,8 +318,8 @@ class Circuit:
         if y.is_const:
             return self.lut(x, lambda v, b=y.const: fn(v, b))
         nx, ny = x.hi - x.lo + 1, y.hi - y.lo + 1
-        if nx * ny > (1 << MSG_BITS):
-            raise RangeError(f"bivariate look-up needs {nx}x{ny} > {1 << MSG_BITS} packed values")
+        if nx * ny > (1 << self.msg_bits):
+            raise RangeError(f"bivariate look-up needs {nx}x{ny} > {1 << self.msg_bits} packed values")
         xlo, ylo = x.lo, y.lo
         z = (x - xlo) * ny + (y - ylo)
         z.lo, z.hi = 0, nx * ny - 1
@@ -333,9 +337,9 @@ class Circuit:
         if y.is_const:
             return x * y.const
         nx, ny = x.hi - x.lo + 1, y.hi - y.lo + 1
-        if nx * ny <= (1 << MSG_BITS):
+        if nx * ny <= (1 << self.msg_bits):
             return self.lut2(x, y, lambda a, b: a * b)
-        if nx + ny - 1 <= (1 << MSG_BITS):
+        if nx + ny - 1 <= (1 << self.msg_bits):
             return self.lut(x + y, lambda s: (s * s) // 4) - self.lut(x - y, lambda d: (d * d) // 4)
         raise RangeError(f"product of intervals [{x.lo},{x.hi}] x [{y.lo},{y.hi}] does not fit")
 
@@ -465,11 +469,11 @@ class Circuit:
             if check and not (self.leaf_lo[i] <= v <= self.leaf_hi[i]):
                 raise RangeError(f"input {i} = {v} outside its declared interval [{self.leaf_lo[i]}, {self.leaf_hi[i]}]")
             val[i] = v
-        half_space = 1 << (MSG_BITS - 1)
+        half_space = 1 << (self.msg_bits - 1)
         for terms, const, li, leaf in self.nodes:
             p, table = self.luts[li]
             x = const + sum(cf * val[t] for t, cf in terms)
-            scale = 1 << (MSG_BITS - p)
+            scale = 1 << (self.msg_bits - p)
             wide = leaf in self.wide_leaves
             if check and not ((-2 * half_space < x < 2 * half_space) if wide else (-half_space <= x < half_space)):
                 raise RangeError(f"PBS input {x} outside the message space")

@@ -58,7 +58,7 @@ class Executor:
             self.level_rows.append(rows)
             nxt += rows
         self.n_leaves = nxt
-        self.delta_log = engine.delta_log(MSG_BITS)
+        self.delta_log = engine.delta_log(getattr(circuit, "msg_bits", MSG_BITS))
         q, dl = engine.modulus, self.delta_log
         lut_ids = [engine.lut_register(np.array(tab, dtype=np.int64), p, dl) for p, tab in circuit.luts]
 

@@ -207,3 +207,28 @@ def test_encrypted_2x2_inverse_on_the_N2048_parameter_set():
         assert out.tolist() == c["out"]
     finally:
         e.close()
+
+
+def test_six_bit_circuit_on_the_N4096_parameter_set():
+    """Circuit(msg_bits=6) through the executor on the N = 4096 set: a 64-entry look-up, an 8 x 8 packed bivariate one
+    and a 7-bit odd one on ciphertexts, against the plaintext simulation."""
+    from bmi_amd import tfhe
+    from bmi_amd.circuit import Circuit
+    from bmi_amd.executor import Executor
+    e = tfhe.Engine(tfhe.default_params(q_bits=49, log_N=12))
+    try:
+        e.keygen(0x5EED)
+        c = Circuit(msg_bits=6)
+        x, a, b, w = c.input(-32, 31), c.input(0, 7), c.input(0, 7), c.input(-63, 63)
+        f = lambda v: (v * v) % 64 - 32  # noqa: E731
+        c.set_outputs([c.lut(x, f), c.lut2(a, b, lambda u, v: (u * v) % 61 - 30), c.lut_odd(w, lambda v: (v > 0) - (v < 0))])
+        ex = Executor(c, e)
+        dl = e.delta_log(6)
+        rng = np.random.default_rng(21)
+        for _ in range(12):
+            vals = [int(rng.integers(-32, 32)), int(rng.integers(0, 8)), int(rng.integers(0, 8)), int(rng.integers(-63, 64))]
+            assert list(e.decrypt(ex.run(e.encrypt(vals, dl)), dl)) == c.simulate(vals), vals
+        for vals in ([-32, 7, 7, 63], [31, 0, 0, -63]):
+            assert list(e.decrypt(ex.run(e.encrypt(vals, dl)), dl)) == c.simulate(vals), vals
+    finally:
+        e.close()

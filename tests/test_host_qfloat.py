@@ -257,6 +257,26 @@ def test_wide_odd_lookup_and_lookahead_networks():
         bpa.WIDE_LOOKAHEAD = saved
 
 
+def test_circuit_message_width_is_configurable():
+    """Circuit(msg_bits=6): 64-value look-ups, 8 x 8 packed bivariate ones and 7-bit odd ones (what the N = 4096
+    parameter set carries); the default stays 4 bits and rejects the same look-ups."""
+    import random
+    c = Circuit(msg_bits=6)
+    x, a, b, w = c.input(-32, 31), c.input(0, 7), c.input(0, 7), c.input(-63, 63)
+    f = lambda v: (v * v) % 64 - 32  # noqa: E731
+    g = lambda u, v: (u * v) % 61 - 30  # noqa: E731
+    sgn = lambda v: (v > 0) - (v < 0)  # noqa: E731
+    c.set_outputs([c.lut(x, f), c.lut2(a, b, g), c.lut_odd(w, sgn)])
+    assert c.luts[0][0] == 6 and len(c.luts[0][1]) == 64
+    rng = random.Random(1)
+    for _ in range(200):
+        xv, av, bv, wv = rng.randint(-32, 31), rng.randint(0, 7), rng.randint(0, 7), rng.randint(-63, 63)
+        assert c.simulate([xv, av, bv, wv]) == [f(xv), g(av, bv), sgn(wv)]
+    c4 = Circuit()
+    with pytest.raises(RangeError):
+        c4.lut(c4.input(-32, 31), f)
+
+
 def test_width_aware_level_schedule_properties():
     """Circuit.levels(): same depth as ASAP, every node after its producers, all nodes scheduled exactly once, and no
     level wider than the rounds its critical nodes need (random layered circuits + the traced 2x2 inverse)."""
