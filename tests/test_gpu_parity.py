@@ -482,3 +482,34 @@ def test_wider_parameter_sets_bit_exact(log_N):
         e.close()
     with pytest.raises(tfhe.BmiError):
         tfhe.Engine(tfhe.default_params(q_bits=64, log_N=log_N))    # the wider rings exist on the 49-bit field only
+
+
+def test_pbs_known_answer_digests_on_gpu():
+    """The committed known-answer digests (tests/golden/pbs_kat.json, produced by the oracle): the library's keys,
+    ciphertexts, keyswitch and PBS outputs hash to the same values on every supported (field, N) - no oracle needed
+    at run time."""
+    import hashlib
+    import json
+    import os
+    from bmi_amd import tfhe
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pbs_kat.json")))
+    h = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint64).tobytes()).hexdigest()  # noqa: E731
+    for case in kat["cases"]:
+        e = tfhe.Engine(tfhe.default_params(q_bits=case["q_bits"], log_N=case["log_N"]))
+        try:
+            e.keygen(kat["seed"])
+            sk_small, sk_big, bsk, ksk = e.export_keys()
+            assert (h(sk_big), h(bsk), h(ksk)) == (case["sk_big"], case["bsk"], case["ksk"]), case
+            dl = e.delta_log()
+            lid = e.lut_register(np.array(kat["table"]), 4, dl)
+            assert h(e.lut_get(lid)) == case["test_vector"]
+            ct = e.encrypt(np.array(kat["msgs"]), dl)
+            assert h(ct) == case["ciphertexts"]
+            assert h(e.keyswitch_host(ct)) == case["keyswitched"]
+            out = e.pbs_host(ct, np.full(len(kat["msgs"]), lid, np.uint32))
+            assert h(out) == case["bootstrapped"]
+            for variant in ((1, 2, 3, 4) if case["log_N"] == 10 else ()):
+                e.set_kernel_variant(variant)
+                assert h(e.pbs_host(ct, np.full(len(kat["msgs"]), lid, np.uint32))) == case["bootstrapped"], variant
+        finally:
+            e.close()

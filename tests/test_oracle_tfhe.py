@@ -206,3 +206,27 @@ def test_p49_pbs_default_params(field49):
         e = (int(x) - (int(m) << dl)) % q
         e = e - q if e > q // 2 else e
         assert abs(e) < 2 ** (dl - 6)
+
+
+def test_pbs_known_answer_digests():
+    """tests/golden/pbs_kat.json (tools/gen_pbs_golden.py): SHA-256 of keys, test vector, ciphertexts, keyswitched and
+    bootstrapped outputs of a fixed seed / messages / table, for every supported (field, N).  The oracle must still
+    produce them (the GPU suite checks the library against the same file)."""
+    import hashlib
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pbs_kat.json")))
+    h = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint64).tobytes()).hexdigest()  # noqa: E731
+    case = next(c for c in kat["cases"] if c["q_bits"] == 49 and c["log_N"] == 10)   # one case keeps the CPU suite short
+    to.set_field(49)
+    P = to.default_params(q_bits=49, log_N=10)
+    K = to.keygen(P, kat["seed"])
+    assert (h(K.sk_big), h(K.bsk), h(K.ksk)) == (case["sk_big"], case["bsk"], case["ksk"])
+    dl = 49 - 1 - 4
+    tv = to.make_test_vector(10, 4, np.array(kat["table"]), dl)
+    ct = to.lwe_encrypt(K.sk_big, P.glwe_noise, kat["seed"], 0, to.encode(kat["msgs"], dl))
+    ctx = to.Ctx(P, K.bsk, K.ksk)
+    assert h(tv) == case["test_vector"] and h(ct) == case["ciphertexts"]
+    assert h(ctx.keyswitch(ct)) == case["keyswitched"]
+    assert h(ctx.pbs(ct, tv[None, :], np.zeros(len(kat["msgs"]), np.uint32))) == case["bootstrapped"]
+    ctx.close()
