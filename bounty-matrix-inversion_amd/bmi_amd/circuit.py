@@ -350,6 +350,30 @@ class Circuit:
         hi = max(_hi(x), _hi(y))
         return r.assume(lo, hi) if isinstance(r, Lin) else r
 
+    # ---- (de)serialisation: a circuit as plain data (fixtures of traced functions, tests/golden/) -------------------
+    def to_dict(self):
+        return {"msg_bits": self.msg_bits, "n_inputs": self.n_inputs,
+                "leaf_level": list(self.leaf_level), "leaf_lo": list(self.leaf_lo), "leaf_hi": list(self.leaf_hi),
+                "nodes": [[[list(t) for t in terms], const, li, leaf] for terms, const, li, leaf in self.nodes],
+                "luts": [[p, list(tab)] for p, tab in self.luts],
+                "outputs": [[[list(t) for t in terms], const] for terms, const in self.outputs],
+                "claims": [[[[list(t) for t in snap[0]], snap[1]], lo, hi] for snap, lo, hi in self.claims],
+                "wide_leaves": sorted(self.wide_leaves)}
+
+    @classmethod
+    def from_dict(cls, d):
+        c = cls(msg_bits=d["msg_bits"])
+        c.n_inputs = d["n_inputs"]
+        c.leaf_level, c.leaf_lo, c.leaf_hi = list(d["leaf_level"]), list(d["leaf_lo"]), list(d["leaf_hi"])
+        c.nodes = [(tuple(tuple(t) for t in terms), const, li, leaf) for terms, const, li, leaf in d["nodes"]]
+        c.luts = [(p, tuple(tab)) for p, tab in d["luts"]]
+        c._lut_index = {k: i for i, k in enumerate(c.luts)}
+        c.outputs = [(tuple(tuple(t) for t in terms), const) for terms, const in d["outputs"]]
+        c.claims = [((tuple(tuple(t) for t in snap[0]), snap[1]), lo, hi) for snap, lo, hi in d["claims"]]
+        c.wide_leaves = set(d["wide_leaves"])
+        c.stats["pbs"] = len(c.nodes)
+        return c
+
     def set_outputs(self, lins):
         self.outputs = [self._snapshot(x if isinstance(x, Lin) else self.const(x)) for x in lins]
         self.out_ranges = [(_lo(x), _hi(x)) for x in lins]

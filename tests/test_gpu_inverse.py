@@ -232,3 +232,23 @@ def test_six_bit_circuit_on_the_N4096_parameter_set():
             assert list(e.decrypt(ex.run(e.encrypt(vals, dl)), dl)) == c.simulate(vals), vals
     finally:
         e.close()
+
+
+def test_reference_functions_traced_unmodified_on_gpu(eng):
+    """The reference's unmodified functions (tests/golden/ref_traced.json, see the CPU test of the same name) evaluated on
+    ciphertexts: addition, subtraction with overflow flag, comparisons, long division and QFloat + - * > of the reference,
+    every look-up on the GPU, against the reference's recorded plaintext outputs.  At these sizes every look-up fits 4
+    bits, so they run on the default parameter set, both fields."""
+    from bmi_amd.circuit import Circuit
+    from bmi_amd.executor import Executor
+    data = load("ref_traced.json")
+    for case in data["cases"]:
+        assert case["widest_lookup_bits"] <= 4
+        c = Circuit.from_dict(case["circuit"])
+        assert c.msg_bits == 4
+        ex = Executor(c, eng)
+        dl = eng.delta_log(4)
+        for v in case["vectors"][:6]:
+            got = eng.decrypt(ex.run(eng.encrypt(v["inputs"], dl)), dl)
+            assert list(got) == v["expected"], case["name"]
+

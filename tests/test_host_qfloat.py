@@ -404,3 +404,17 @@ def test_evaluate_without_gpu_fails_loudly():
     emi = EncryptedMatrixInversion(2, None, 2, 16, 7)
     with pytest.raises(tfhe.BmiError):
         emi.keygen()
+
+
+def test_reference_functions_traced_unmodified_simulate():
+    """tests/golden/ref_traced.json (tools/gen_ref_traced.py): the reference's UNMODIFIED base_p_arrays / QFloat functions,
+    traced in the build container through the Tracer-compatible shim (tools/encshim) into this IR and stored as data.
+    The deserialised circuits must reproduce the reference's own plaintext outputs recorded beside them."""
+    data = load("ref_traced.json")
+    assert len(data["cases"]) >= 9
+    for case in data["cases"]:
+        c = Circuit.from_dict(case["circuit"])
+        assert len(c.nodes) == case["pbs"] and len(c.levels()) == case["depth"]
+        assert Circuit.from_dict(c.to_dict()).to_dict() == c.to_dict()
+        for v in case["vectors"]:
+            assert c.simulate(v["inputs"]) == v["expected"], case["name"]

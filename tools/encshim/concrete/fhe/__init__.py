@@ -1,0 +1,373 @@
+"""Tracer-compatible stand-in for `concrete.fhe` that runs the reference's UNMODIFIED base_p_arrays.py / qfloat.py on
+this repo's circuit IR (bmi_amd.circuit), i.e. on MI355X ciphertexts.  Development tooling: it needs /root/reference at
+run time, so it lives under tools/ and is used to produce data fixtures (traced circuits + expected outputs), never
+imported by the product or on the GPU box.
+
+How it works (the reference is data-oblivious, so its sequence of operations is the same on every input):
+  1. MEASURE: the function runs on an inputset; every encrypted scalar carries the vector of its sample values, and
+     every non-linear operation (comparison, //, %, abs, sign, bit-wise op, ciphertext product, fhe.univariate) records
+     the range its operand takes - what Concrete's compiler does with its inputset (main.py:41-66).
+  2. BUILD: the function runs again on symbolic values (Lin); the k-th non-linear operation claims the range measured
+     for it (`Lin.assume`, verified by `Circuit.simulate`) and becomes a table look-up of the circuit.
+Operator surface: SURVEY.md section 8b."""
+import numpy as np
+
+from .tracing.tracer import Tracer
+from . import tracing  # noqa: F401
+
+_S = {"mode": None, "circuit": None, "ranges": [], "site": 0, "margin": 0}
+
+
+def _site(vals):
+    """one operand of one non-linear operation: records (measure) or returns (build) its range"""
+    k = _S["site"]
+    _S["site"] += 1
+    if _S["mode"] == "measure":
+        lo, hi = int(np.min(vals)), int(np.max(vals))
+        if k == len(_S["ranges"]):
+            _S["ranges"].append([lo, hi])
+        else:
+            r = _S["ranges"][k]
+            r[0], r[1] = min(r[0], lo), max(r[1], hi)
+        return None
+    return _S["ranges"][k]
+
+
+class Enc(Tracer):
+    """one encrypted scalar: sample vector (measure), Lin (build) - plain ints stay ints"""
+    __slots__ = ("v",)
+    __array_priority__ = 1000
+
+    def __init__(self, v):
+        self.v = v
+
+    # ---- helpers
+    @staticmethod
+    def _raw(x):
+        return x.v if isinstance(x, Enc) else (int(x) if isinstance(x, (int, np.integer, bool, np.bool_)) else x)
+
+    @staticmethod
+    def _wrap(v):
+        if isinstance(v, (int, np.integer)):
+            return int(v)
+        return Enc(v)
+
+    def _lut(self, fn):
+        """univariate non-linear operation on this value"""
+        if _S["mode"] == "measure":
+            _site(self.v)
+            return Enc(np.array([int(fn(int(t))) for t in self.v], dtype=np.int64))
+        lo, hi = _site(None)
+        c = _S["circuit"]
+        x = self.v.assume(lo, hi) if hasattr(self.v, "assume") else self.v
+        out = c.lut(x, lambda t: int(fn(int(t))))
+        return Enc._wrap(out.const if getattr(out, "is_const", False) else out)
+
+    # ---- linear
+    def __add__(self, o):
+        if isinstance(o, (np.ndarray, EncArray)):
+            return NotImplemented
+        return Enc._wrap(self.v + Enc._raw(o))
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        if isinstance(o, (np.ndarray, EncArray)):
+            return NotImplemented
+        return Enc._wrap(self.v - Enc._raw(o))
+
+    def __rsub__(self, o):
+        return Enc._wrap(Enc._raw(o) - self.v)
+
+    def __neg__(self):
+        return Enc._wrap(-self.v)
+
+    def __pos__(self):
+        return self
+
+    def __mul__(self, o):
+        if isinstance(o, (np.ndarray, EncArray)):
+            return NotImplemented
+        if not isinstance(o, Enc):
+            return Enc._wrap(self.v * int(o))
+        if _S["mode"] == "measure":
+            _site(self.v)
+            _site(o.v)
+            return Enc(self.v * o.v)
+        ra, rb = _site(None), _site(None)
+        c = _S["circuit"]
+        out = c.mul(self.v.assume(*ra), o.v.assume(*rb))
+        return Enc._wrap(out.const if getattr(out, "is_const", False) else out)
+    __rmul__ = __mul__
+
+    # ---- non-linear, univariate on a linear combination
+    def _cmp(self, o, fn):
+        d = self - o
+        return fn(0) if not isinstance(d, Enc) else d._lut(fn)
+
+    def __lt__(self, o):
+        return self._cmp(o, lambda t: int(t < 0))
+
+    def __le__(self, o):
+        return self._cmp(o, lambda t: int(t <= 0))
+
+    def __gt__(self, o):
+        return self._cmp(o, lambda t: int(t > 0))
+
+    def __ge__(self, o):
+        return self._cmp(o, lambda t: int(t >= 0))
+
+    def __eq__(self, o):  # noqa: PLW1641 (hash not needed: Enc lives in object arrays)
+        return self._cmp(o, lambda t: int(t == 0))
+
+    def __ne__(self, o):
+        return self._cmp(o, lambda t: int(t != 0))
+
+    def __floordiv__(self, k):
+        return self._lut(lambda t, k=int(k): t // k)
+
+    def __mod__(self, k):
+        return self._lut(lambda t, k=int(k): t % k)
+
+    def __rshift__(self, k):
+        return self._lut(lambda t, k=int(k): t >> k)
+
+    def __abs__(self):
+        return self._lut(abs)
+
+    def sign(self):
+        return self._lut(lambda t: (t > 0) - (t < 0))
+
+    # bit-wise operations: both operands are bits (what the reference uses them for) -> a look-up on their sum
+    def _bits(self, o, fn):
+        if not isinstance(o, Enc):
+            o = int(o)
+            return self._lut(lambda t, o=o: fn(t, o))
+        return (self + o)._lut(lambda s: fn(int(s >= 1), int(s >= 2)) if fn is not _xor else int(s == 1))
+
+    def __and__(self, o):
+        return self._bits(o, lambda a, b: a & b)
+    __rand__ = __and__
+
+    def __or__(self, o):
+        return self._bits(o, lambda a, b: a | b)
+    __ror__ = __or__
+
+    def __xor__(self, o):
+        return self._bits(o, _xor)
+    __rxor__ = __xor__
+
+    # ---- numpy-facing
+    def reshape(self, *shape):
+        a = np.empty(1, dtype=object)
+        a[0] = self
+        return EncArray(a).reshape(*shape)
+
+    @property
+    def size(self):
+        return 1
+
+    @property
+    def shape(self):
+        return ()
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        if method != "__call__":
+            return NotImplemented
+        if ufunc is np.sign:
+            return self.sign()
+        if ufunc is np.absolute:
+            return abs(self)
+        table = {np.add: lambda a, b: a + b, np.subtract: lambda a, b: a - b, np.multiply: lambda a, b: a * b,
+                 np.negative: lambda a: -a, np.less: lambda a, b: a < b, np.greater: lambda a, b: a > b,
+                 np.less_equal: lambda a, b: a <= b, np.greater_equal: lambda a, b: a >= b,
+                 np.equal: lambda a, b: a == b, np.not_equal: lambda a, b: a != b,
+                 np.floor_divide: lambda a, b: a // b, np.remainder: lambda a, b: a % b,
+                 np.bitwise_and: lambda a, b: a & b, np.bitwise_or: lambda a, b: a | b, np.bitwise_xor: lambda a, b: a ^ b}
+        if ufunc not in table:
+            return NotImplemented
+        if any(isinstance(x, (np.ndarray, EncArray)) for x in inputs):
+            return _elementwise(table[ufunc], *inputs)
+        return table[ufunc](*inputs)
+
+
+def _xor(a, b):
+    return a ^ b
+
+
+import operator as _op
+
+_UFUNC_OPS = {np.add: _op.add, np.subtract: _op.sub, np.multiply: _op.mul, np.negative: _op.neg, np.positive: _op.pos,
+              np.less: _op.lt, np.greater: _op.gt, np.less_equal: _op.le, np.greater_equal: _op.ge, np.equal: _op.eq,
+              np.not_equal: _op.ne, np.floor_divide: _op.floordiv, np.remainder: _op.mod, np.bitwise_and: _op.and_,
+              np.bitwise_or: _op.or_, np.bitwise_xor: _op.xor, np.right_shift: _op.rshift, np.absolute: abs,
+              np.sign: lambda t: t.sign() if isinstance(t, Enc) else int((t > 0) - (t < 0))}
+
+
+def _unwrap(x):
+    if isinstance(x, EncArray):
+        return x._a
+    if isinstance(x, (list, tuple)):
+        return type(x)(_unwrap(e) for e in x)
+    return x
+
+
+def _wrap_result(r):
+    if isinstance(r, np.ndarray) and r.dtype == object:
+        return EncArray(r)
+    if isinstance(r, (list, tuple)):
+        return type(r)(_wrap_result(e) for e in r)
+    return r
+
+
+def _elementwise(fn, *operands):
+    """fn applied element by element with numpy broadcasting; the elements' own operators build the circuit"""
+    arrs = [np.asarray(_unwrap(x), dtype=object) if isinstance(x, (EncArray, np.ndarray)) else None for x in operands]
+    shape = np.broadcast(*[a for a in arrs if a is not None]).shape
+    bc = [np.broadcast_to(a, shape) if a is not None else None for a in arrs]
+    out = np.empty(shape, dtype=object)
+    for idx in np.ndindex(shape):
+        out[idx] = fn(*[b[idx] if b is not None else x for b, x in zip(bc, operands)])
+    return EncArray(out)
+
+
+class EncArray(Tracer):
+    """An encrypted tensor as the reference sees it: NOT an np.ndarray (qfloat.py:278 treats ndarrays as cleartext),
+    but with the array surface the reference uses - shape/size/len, indexing and slice assignment, reshape/flatten,
+    element-wise arithmetic, comparisons and bit-wise operations, and the numpy functions sum / concatenate / abs /
+    sign / ... through the __array_function__ / __array_ufunc__ protocols.  Elements are Enc scalars or plain ints."""
+    __array_priority__ = 2000
+
+    def __init__(self, a):
+        self._a = np.asarray(a, dtype=object)
+
+    shape = property(lambda self: self._a.shape)
+    size = property(lambda self: self._a.size)
+    ndim = property(lambda self: self._a.ndim)
+    T = property(lambda self: EncArray(self._a.T))
+
+    def __len__(self):
+        return len(self._a)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self._a)))
+
+    def __getitem__(self, k):
+        r = self._a[_unwrap(k)]
+        return EncArray(r) if isinstance(r, np.ndarray) else r
+
+    def __setitem__(self, k, v):
+        v = _unwrap(v)
+        if isinstance(v, np.ndarray) and v.dtype != object:
+            v = v.astype(object)
+        self._a[_unwrap(k)] = v
+
+    def reshape(self, *shape):
+        return EncArray(self._a.reshape(*shape))
+
+    def flatten(self):
+        return EncArray(self._a.flatten())
+
+    def copy(self):
+        return EncArray(self._a.copy())
+
+    def astype(self, _dtype):
+        return self
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        if method != "__call__" or ufunc not in _UFUNC_OPS:
+            return NotImplemented
+        return _elementwise(_UFUNC_OPS[ufunc], *inputs)
+
+    def __array_function__(self, func, types, args, kwargs):
+        return _wrap_result(func(*_unwrap(args), **{k: _unwrap(v) for k, v in kwargs.items()}))
+
+    def _bin(fn, swap=False):  # noqa: N805
+        def method(self, o):
+            return _elementwise((lambda a, b: fn(b, a)) if swap else fn, self, o)
+        return method
+
+    __add__, __radd__ = _bin(_op.add), _bin(_op.add, True)
+    __sub__, __rsub__ = _bin(_op.sub), _bin(_op.sub, True)
+    __mul__, __rmul__ = _bin(_op.mul), _bin(_op.mul, True)
+    __floordiv__, __mod__, __rshift__ = _bin(_op.floordiv), _bin(_op.mod), _bin(_op.rshift)
+    __and__, __rand__ = _bin(_op.and_), _bin(_op.and_, True)
+    __or__, __ror__ = _bin(_op.or_), _bin(_op.or_, True)
+    __xor__, __rxor__ = _bin(_op.xor), _bin(_op.xor, True)
+    __lt__, __le__, __gt__, __ge__ = _bin(_op.lt), _bin(_op.le), _bin(_op.gt), _bin(_op.ge)
+    __eq__, __ne__ = _bin(_op.eq), _bin(_op.ne)
+
+    def __neg__(self):
+        return _elementwise(_op.neg, self)
+
+    def __abs__(self):
+        return _elementwise(abs, self)
+
+
+def zeros(shape):
+    a = np.empty(shape, dtype=object)
+    a.fill(0)
+    return EncArray(a)
+
+
+def ones(shape):
+    a = np.empty(shape, dtype=object)
+    a.fill(1)
+    return EncArray(a)
+
+
+def univariate(f):
+    """fhe.univariate(f)(x): an arbitrary table look-up (base_p_arrays.py:365)"""
+    def apply(x):
+        g = lambda t: int(f(np.int64(t)))  # noqa: E731
+        if isinstance(x, Enc):
+            return x._lut(g)
+        if isinstance(x, (np.ndarray, EncArray)):
+            return _elementwise(lambda t: t._lut(g) if isinstance(t, Enc) else g(t), x)
+        return g(x)
+    return apply
+
+
+# ------------------------------------------------------------------------------------------ the two-phase tracer
+def trace(fn, input_ranges, inputset, msg_bits=6):
+    """fn(*arrays) -> array/scalar/tuple of them; input_ranges: per argument a list of (lo, hi) per element;
+    inputset: list of argument tuples (lists of ints).  Returns (circuit, n_outputs)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "..", "..",
+                                    "bounty-matrix-inversion_amd"))
+    from bmi_amd.circuit import Circuit
+
+    def flat(res):
+        if isinstance(res, tuple):
+            return [e for r in res for e in flat(r)]
+        if isinstance(res, (np.ndarray, EncArray)):
+            return list(np.asarray(_unwrap(res), dtype=object).reshape(-1))
+        return [res]
+
+    # 1. measure
+    _S.update(mode="measure", ranges=[], site=0, circuit=None)
+    samples = np.array([[v for arg in one for v in arg] for one in inputset], dtype=np.int64)   # [S][n_in]
+    args, col = [], 0
+    for rng in input_ranges:
+        a = np.empty(len(rng), dtype=object)
+        for i in range(len(rng)):
+            a[i] = Enc(samples[:, col].copy())
+            col += 1
+        args.append(EncArray(a))
+    _S["site"] = 0
+    fn(*args)
+    n_sites = _S["site"]
+    # 2. build
+    c = Circuit(msg_bits=msg_bits)
+    _S.update(mode="build", site=0, circuit=c)
+    args = []
+    for rng in input_ranges:
+        a = np.empty(len(rng), dtype=object)
+        for i, (lo, hi) in enumerate(rng):
+            a[i] = Enc(c.input(lo, hi))
+        args.append(EncArray(a))
+    outs = flat(fn(*args))
+    assert _S["site"] == n_sites, "the function is not data-oblivious: different operation sequence"
+    c.set_outputs([Enc._raw(o) for o in outs])
+    _S.update(mode=None)
+    return c, len(outs)

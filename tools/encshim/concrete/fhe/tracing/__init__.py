@@ -1,0 +1,1 @@
+from . import tracer  # noqa: F401
