@@ -252,3 +252,27 @@ def test_reference_functions_traced_unmodified_on_gpu(eng):
             got = eng.decrypt(ex.run(eng.encrypt(v["inputs"], dl)), dl)
             assert list(got) == v["expected"], case["name"]
 
+
+
+def test_reference_whole_inverse_traced_unmodified_on_gpu():
+    """The reference's UNMODIFIED qfloat_matrix_inverse (tests/golden/ref_traced_inverse.json.gz, see the CPU test of the
+    same name) on ciphertexts: its unfused operator sequence needs 5-bit look-ups, so it runs on the N = 2048 parameter
+    set; 2x2 (len 20, ints 8: 2,395 PBS in 374 levels) on two matrices and 3x3 (len 30, ints 12: 34,032 PBS in 3,056
+    levels) on one, decrypted digits against the reference's plaintext outputs."""
+    import gzip
+    from bmi_amd import tfhe
+    from bmi_amd.circuit import Circuit
+    from bmi_amd.executor import Executor
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_traced_inverse.json.gz"), "rt") as f:
+        data = json.load(f)
+    e = tfhe.Engine(tfhe.default_params(q_bits=49, log_N=11))
+    try:
+        e.keygen(0x5EED)
+        dl = e.delta_log(5)
+        for case, n_vec in zip(data["cases"], (2, 1)):
+            ex = Executor(Circuit.from_dict(case["circuit"]), e)
+            for v in case["vectors"][:n_vec]:
+                got = e.decrypt(ex.run(e.encrypt(v["inputs"], dl)), dl)
+                assert list(got) == v["expected"], case["name"]
+    finally:
+        e.close()

@@ -418,3 +418,29 @@ def test_reference_functions_traced_unmodified_simulate():
         assert Circuit.from_dict(c.to_dict()).to_dict() == c.to_dict()
         for v in case["vectors"]:
             assert c.simulate(v["inputs"]) == v["expected"], case["name"]
+
+
+def load_gz(name):
+    import gzip
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name), "rt") as f:
+        return json.load(f)
+
+
+def test_reference_whole_inverse_traced_unmodified_simulate():
+    """tests/golden/ref_traced_inverse.json.gz: the reference's UNMODIFIED `qfloat_matrix_inverse`
+    (qfloat_matrix_inversion.py:672-720, with everything it calls in qfloat.py / base_p_arrays.py) traced through
+    tools/encshim at BASELINE.json's sizes (2x2 len 20 ints 8; 3x3 len 30 ints 12), ranges measured on a 2,000-matrix
+    inputset as Concrete's compiler does.  The stored circuits reproduce the reference's own plaintext outputs, and our
+    restated, fused circuits give the same digits on the same matrices at a fraction of the depth."""
+    data = load_gz("ref_traced_inverse.json.gz")
+    assert [c["n"] for c in data["cases"]] == [2, 3]
+    for case in data["cases"]:
+        c = Circuit.from_dict(case["circuit"])
+        assert c.msg_bits == 5 and case["widest_lookup_bits"] <= 5
+        assert len(c.nodes) == case["pbs"] and len(c.levels()) == case["depth"]
+        n, ln, ints = case["n"], case["len"], case["ints"]
+        ours = trace_inverse(n, ln, ints, 2, False, False)
+        assert len(ours.levels()) * 5 < case["depth"]
+        for v in case["vectors"]:
+            assert c.simulate(v["inputs"]) == v["expected"]
+            assert ours.simulate(v["inputs"]) == v["expected"]

@@ -61,7 +61,7 @@ class Enc(Tracer):
         c = _S["circuit"]
         x = self.v.assume(lo, hi) if hasattr(self.v, "assume") else self.v
         out = c.lut(x, lambda t: int(fn(int(t))))
-        return Enc._wrap(out.const if getattr(out, "is_const", False) else out)
+        return Enc(out)   # stays encrypted even when the look-up folds to a constant: both phases must see the same sites
 
     # ---- linear
     def __add__(self, o):
@@ -96,13 +96,13 @@ class Enc(Tracer):
         ra, rb = _site(None), _site(None)
         c = _S["circuit"]
         out = c.mul(self.v.assume(*ra), o.v.assume(*rb))
-        return Enc._wrap(out.const if getattr(out, "is_const", False) else out)
+        return Enc(out)   # stays encrypted even when the look-up folds to a constant: both phases must see the same sites
     __rmul__ = __mul__
 
     # ---- non-linear, univariate on a linear combination
     def _cmp(self, o, fn):
         d = self - o
-        return fn(0) if not isinstance(d, Enc) else d._lut(fn)
+        return fn(int(d)) if not isinstance(d, Enc) else d._lut(fn)
 
     def __lt__(self, o):
         return self._cmp(o, lambda t: int(t < 0))
@@ -185,6 +185,7 @@ class Enc(Tracer):
                  np.bitwise_and: lambda a, b: a & b, np.bitwise_or: lambda a, b: a | b, np.bitwise_xor: lambda a, b: a ^ b}
         if ufunc not in table:
             return NotImplemented
+        inputs = tuple(int(x) if isinstance(x, (np.integer, np.bool_)) else x for x in inputs)   # numpy scalar (op) Enc
         if any(isinstance(x, (np.ndarray, EncArray)) for x in inputs):
             return _elementwise(table[ufunc], *inputs)
         return table[ufunc](*inputs)
@@ -253,7 +254,9 @@ class EncArray(Tracer):
 
     def __getitem__(self, k):
         r = self._a[_unwrap(k)]
-        return EncArray(r) if isinstance(r, np.ndarray) else r
+        if isinstance(r, np.ndarray):
+            return EncArray(r)
+        return np.int64(r) if isinstance(r, int) else r   # a cleartext element still answers .reshape() etc.
 
     def __setitem__(self, k, v):
         v = _unwrap(v)
@@ -304,12 +307,16 @@ class EncArray(Tracer):
 
 
 def zeros(shape):
+    if _S["mode"] is None:   # outside a trace Concrete's constructors are numpy's (the reference's plaintext path)
+        return np.zeros(shape, dtype=np.int64)
     a = np.empty(shape, dtype=object)
     a.fill(0)
     return EncArray(a)
 
 
 def ones(shape):
+    if _S["mode"] is None:
+        return np.ones(shape, dtype=np.int64)
     a = np.empty(shape, dtype=object)
     a.fill(1)
     return EncArray(a)
@@ -321,6 +328,8 @@ def univariate(f):
         g = lambda t: int(f(np.int64(t)))  # noqa: E731
         if isinstance(x, Enc):
             return x._lut(g)
+        if isinstance(x, np.ndarray) and x.dtype != object:
+            return np.array([g(t) for t in x.reshape(-1)], dtype=np.int64).reshape(x.shape)
         if isinstance(x, (np.ndarray, EncArray)):
             return _elementwise(lambda t: t._lut(g) if isinstance(t, Enc) else g(t), x)
         return g(x)
