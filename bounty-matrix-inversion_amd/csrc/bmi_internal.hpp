@@ -26,6 +26,12 @@
 #define BMI_TPX49_SYNC 0  // pair synchronisation of the exchange-once kernel: 0 = LDS counters (pairs only), 1 = workgroup barrier
 #endif
 
+#ifndef BMI_TPX49_PRIO
+#define BMI_TPX49_PRIO 3  // s_setprio inside a CMUX of the exchange-once kernel: 0 = none, 1 = raised until the partial sums are published, 2 = raised after, 3 = stepping down 3,3,2,1 over decomposition and the three levels, 0 from the exchange on (the wavefront that is behind on a SIMD gets the issue slots: 80.0 -> 78.1 ms), 4 = raised for the inverse only (no gain)
+#endif
+#ifndef BMI_LAT2_PRIO
+#define BMI_LAT2_PRIO 2  // s_setprio in the forward tasks of the latency kernels (N = 1024 two-wave transforms, N = 2048, N = 4096): tasks sharing a SIMD step down 3,2,1,0 as they advance, so they finish together instead of the last one running its tail alone (4.02 -> 3.57 ms per bootstrap at N = 1024; 1: three steps, 3.60 ms; 0: none)
+#endif
 #ifndef BMI_KS_MFMA_MIN
 #define BMI_KS_MFMA_MIN 1  // smallest batch that takes the matrix-core keyswitch (0.05 ms against 0.14 ms scalar even at one ciphertext)
 #endif

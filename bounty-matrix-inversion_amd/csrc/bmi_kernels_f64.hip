@@ -294,6 +294,13 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
 #endif
         const uint32_t a_t = at[i];
         const double *bsk_c = bsk + ((size_t)i * 12 + c * 6) * N;  // this wavefront's three GGSW rows (two columns each)
+#if BMI_TPX49_PRIO == 1
+        __builtin_amdgcn_s_setprio(1);
+#elif BMI_TPX49_PRIO == 2 || BMI_TPX49_PRIO == 4
+        __builtin_amdgcn_s_setprio(0);
+#elif BMI_TPX49_PRIO == 3
+        __builtin_amdgcn_s_setprio(3);
+#endif
         wave_sync();
         double r[16];
         {
@@ -321,6 +328,9 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
             auto load_m = [&]() { static_for<0, 8>([&](auto VP) { bm[VP] = row_m[VP * 64 + lane]; }); };
             auto load_o = [&]() { static_for<0, 8>([&](auto VP) { bo[VP] = row_o[VP * 64 + lane]; }); };
             pin();
+#if BMI_TPX49_PRIO == 3
+            __builtin_amdgcn_s_setprio(lev + 1);
+#endif
             if constexpr (PM == 0) load_m();
             if constexpr (PO == 0) load_o();
             double x[16];
@@ -366,6 +376,11 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
             reinterpret_cast<double2 *>(tile)[VP * 64 + lane] = double2{ao[2 * VP], ao[2 * VP + 1]};
         });
         pair_post(f_pub, i + 1);
+#if BMI_TPX49_PRIO == 1 || BMI_TPX49_PRIO == 3
+        __builtin_amdgcn_s_setprio(0);
+#elif BMI_TPX49_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
         pair_wait(f_pub_partner, i + 1);
         static_for<0, 8>([&](auto VP) {
             const double2 p = reinterpret_cast<const double2 *>(ptile)[VP * 64 + lane];
@@ -374,6 +389,9 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
         });
         pair_post(f_ack, i + 1);          // release: the reads above have landed
         pair_wait(f_ack_partner, i + 1);  // the partner has read this tile: the inverse transform may overwrite it
+#if BMI_TPX49_PRIO == 4
+        __builtin_amdgcn_s_setprio(1);
+#endif
         inverse(am, lane, lds, tile);
         static_for<0, 16>([&](auto J) { accl[lane + 64 * J] = f49::red(accl[lane + 64 * J] + am[J]); });
     }
@@ -575,9 +593,14 @@ __global__ void __launch_bounds__(L2_THREADS)
             b[r][1] = bi[(size_t)(r * 2 + mo) * N + ntth::HALF + mp];
         }
         if (wave < 12) {
+            // (tasks -> SIMDs so that no SIMD gets three of the heavier odd halves: measured 4 % slower)
             const int c = wave / 6, lev = (wave % 6) >> 1, h = wave & 1;
+            const int pz = wave >> 1;
             const double *ac = acc + c * N;
             double x[8];
+#if BMI_LAT2_PRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
             static_for<0, 8>([&](auto J) {
                 const uint32_t m = lane + 64 * J;
                 const uint32_t e = (2 * m + h + 2 * N - a_t) & (2 * N - 1);
@@ -586,11 +609,14 @@ __global__ void __launch_bounds__(L2_THREADS)
                 v = (e & N) ? -v : v;
                 x[J] = digit_of(__builtin_rint(f49::red(v - ac[h * ntth::HALF + m]) * 0x1p-4), lev);
             });
-            double *tile = tiles + wave * ntth::HSCRATCH;
+            double *tile = tiles + (2 * pz + h) * ntth::HSCRATCH;
             if (h) ntth::forward_half<true>(x, lane, lds, tile);
             else ntth::forward_half<false>(x, lane, lds, tile);
             wave_sync();
             static_for<0, 8>([&](auto R) { tile[R * 64 + lane] = x[R]; });
+#if BMI_LAT2_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         PH_MARK(0);
         __syncthreads();
@@ -648,17 +674,41 @@ __global__ void __launch_bounds__(L2_THREADS)
 // (nttf::forward / inverse on the even and the odd coefficients, root psi_4096^2 = the 2048th root they are built on)
 // combined exactly like the two halves of ntt_half_f64.hpp:  A[kk] = E[kk] + T[kk] O[kk],  A[kk + 1024] = E - T O,
 // T = psi_4096^(2 kk + 1) in the slot order of the wave transform.  One workgroup of 8 wavefronts per ciphertext;
-// per CMUX the six digit polynomials are transformed in two rounds (input polynomial 0, then 1: six half-transform
-// tasks each, so that six LDS tiles suffice), every thread multiply-accumulates four (output, slot) items against
-// the key (own copy in slot order, already scaled by 1/2 for the split), four wavefronts run the inverse halves.
+// per CMUX the twelve half-transform tasks of the six digit polynomials run in two rounds, eight (GGSW rows 0-3: two
+// per SIMD) and four (rows 4-5: one per SIMD) - three task times on the critical path where rounds of six took four;
+// every thread multiply-accumulates four (output, slot) items against the key (own copy in slot order, already
+// scaled by 1/2 for the split), four wavefronts run the inverse halves; the sums handed to them live in the first
+// four tiles (rows padded like a tile, so each inverse task transposes in the row it has just read).
 // Twice the polynomial at the same n doubles the look-up boxes: 4-bit look-ups sit at 12.5 sigma instead of 6.2.
 constexpr int W_N = 2 * N;                 // 2048
 constexpr int W_THREADS = 512;
 constexpr int W_T = TW_WORDS;              // T table [reg][lane] (1024 words), then T^-1 (1024 words)
-constexpr int W_LDS_WORDS = TW_WORDS + 2 * N + 2 * W_N + 6 * SCRATCH_WORDS + 2 * W_N + 264;
+constexpr int W_LDS_WORDS = TW_WORDS + 2 * N + 2 * W_N + 8 * SCRATCH_WORDS + 264;
 
+// Issue priority of a wavefront (0..3).  Tasks that share a SIMD start at 3 and step down as they advance: the one that
+// is ahead yields issue slots to the others, so they finish together instead of the last one running its tail alone
+// (measured on the N = 1024 latency kernel: 4.02 -> 3.57 ms per bootstrap).
+template <int P>
+__device__ __forceinline__ void prio() {
+#if BMI_LAT2_PRIO
+    __builtin_amdgcn_s_setprio(P);
+#endif
+}
+struct PrioStep1 {
+    __device__ __forceinline__ void operator()() const { prio<1>(); }
+};
+struct PrioStep0 {
+    __device__ __forceinline__ void operator()() const { prio<0>(); }
+};
+
+template <bool PRIO = false>
 __device__ __forceinline__ void wide_forward_task(double (&x)[16], int h, int lane, const double *lds, double *tile) {
-    forward(x, lane, lds, tile);
+    if constexpr (PRIO) {
+        prio<2>();
+        forward(x, lane, lds, tile, PrioStep1(), PrioStep0());
+    } else {
+        forward(x, lane, lds, tile);
+    }
     if (h) static_for<0, 16>([&](auto V) { x[V] = f49::mul(x[V], lds[W_T + V * 64 + lane]); });
     wave_sync();
     static_for<0, 16>([&](auto V) { tile[V * 64 + lane] = f49::red(x[V]); });
@@ -694,9 +744,8 @@ __global__ void __launch_bounds__(W_THREADS)
                           uint32_t count, uint32_t n) {
     extern __shared__ double lds[];
     double *acc = lds + TW_WORDS + 2 * N;            // [2 components][2 parities][1024]
-    double *tiles = acc + 2 * W_N;                   // [6][SCRATCH_WORDS]
-    double *SD = tiles + 6 * SCRATCH_WORDS;          // [2 outputs][sum, difference][1024]
-    uint16_t *at = reinterpret_cast<uint16_t *>(SD + 2 * W_N);
+    double *tiles = acc + 2 * W_N;                   // [8][SCRATCH_WORDS]; rows 0-3 also carry the sums to the inverse
+    uint16_t *at = reinterpret_cast<uint16_t *>(tiles + 8 * SCRATCH_WORDS);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < TW_WORDS; i += W_THREADS) lds[i] = g_tw[i];
     for (int i = tid; i < 2 * N; i += W_THREADS) lds[W_T + i] = g_tw_wide[i];
@@ -716,30 +765,34 @@ __global__ void __launch_bounds__(W_THREADS)
     }
     __syncthreads();
 
+    PH_DECL();
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t a_t = at[i];
         if (a_t == 0) continue;  // uniform over the workgroup
         const double *bi = bsk_wide + (size_t)i * 12 * W_N;
+        PH_MARK(7);
         double ylo[4], yhi[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) ylo[q] = yhi[q] = 0.0;
-#pragma unroll 1
-        for (int c = 0; c < 2; c++) {      // input polynomial of this round
-            double b[4][3][2];             // key words of this thread's four (output, slot) items, rows 3 c .. 3 c + 2
+        // one round: GGSW rows R0 .. R0 + NR - 1 (row = 3 * input polynomial + level), 2 NR half-transform tasks
+        auto round = [&](auto R0_, auto NR_) {
+            constexpr int R0 = R0_, NR = NR_;
+            double b[4][NR][2];            // key words of this thread's four (output, slot) items
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int idx = tid + W_THREADS * q, o = idx >> 10, p = idx & (N - 1);
 #pragma unroll
-                for (int lev = 0; lev < 3; lev++) {
-                    const double *row = bi + (size_t)((c * 3 + lev) * 2 + o) * W_N;
-                    b[q][lev][0] = row[p];
-                    b[q][lev][1] = row[N + p];
+                for (int r = 0; r < NR; r++) {
+                    const double *row = bi + (size_t)((R0 + r) * 2 + o) * W_N;
+                    b[q][r][0] = row[p];
+                    b[q][r][1] = row[N + p];
                 }
             }
-            if (wave < 6) {
-                const int lev = wave >> 1, h = wave & 1;
+            if (wave < 2 * NR) {
+                const int row = R0 + (wave >> 1), c = row / 3, lev = row % 3, h = wave & 1;
                 const double *ac = acc + c * W_N;
                 double x[16];
+                prio<3>();
                 static_for<0, 16>([&](auto J) {
                     const uint32_t m = lane + 64 * J;
                     const uint32_t e = (2 * m + h + 2 * W_N - a_t) & (2 * W_N - 1);
@@ -748,40 +801,55 @@ __global__ void __launch_bounds__(W_THREADS)
                     v = (e & W_N) ? -v : v;
                     x[J] = digit_of(__builtin_rint(f49::red(v - ac[h * N + m]) * 0x1p-4), lev);
                 });
-                wide_forward_task(x, h, lane, lds, tiles + wave * SCRATCH_WORDS);
+                wide_forward_task<true>(x, h, lane, lds, tiles + wave * SCRATCH_WORDS);
             }
+            PH_MARK(0);
             __syncthreads();
+            PH_MARK(1);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int p = (tid + W_THREADS * q) & (N - 1);
 #pragma unroll
-                for (int lev = 0; lev < 3; lev++) {
-                    const double e = tiles[(2 * lev) * SCRATCH_WORDS + p], od = tiles[(2 * lev + 1) * SCRATCH_WORDS + p];
-                    ylo[q] += f49::mul(e + od, b[q][lev][0]);   // e, od reduced (<= q/2): lazy sums of six products
-                    yhi[q] += f49::mul(e - od, b[q][lev][1]);
+                for (int r = 0; r < NR; r++) {
+                    const double e = tiles[(2 * r) * SCRATCH_WORDS + p], od = tiles[(2 * r + 1) * SCRATCH_WORDS + p];
+                    ylo[q] += f49::mul(e + od, b[q][r][0]);   // e, od reduced (<= q/2): lazy sums of six products
+                    yhi[q] += f49::mul(e - od, b[q][r][1]);
                 }
             }
-            __syncthreads();   // the tiles are rewritten by the next round / the inverse transforms
-        }
+            PH_MARK(2);
+            __syncthreads();   // the tiles are rewritten by the next round / the sums below
+            PH_MARK(3);
+        };
+        round(std::integral_constant<int, 0>(), std::integral_constant<int, 4>());
+        round(std::integral_constant<int, 4>(), std::integral_constant<int, 2>());
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int idx = tid + W_THREADS * q, o = idx >> 10, p = idx & (N - 1);
             const double lo = f49::red(ylo[q]), hi = f49::red(yhi[q]);
-            SD[(o * 2 + 0) * N + p] = f49::red(lo + hi);   // inverse() takes |.| <= 0.51 q
-            SD[(o * 2 + 1) * N + p] = lo - hi;             // reduced by the multiplication with T^-1
+            tiles[(o * 2 + 0) * SCRATCH_WORDS + p] = f49::red(lo + hi);   // inverse() takes |.| <= 0.51 q
+            tiles[(o * 2 + 1) * SCRATCH_WORDS + p] = lo - hi;             // reduced by the multiplication with T^-1
         }
         __syncthreads();
+        PH_MARK(4);
         if (wave < 4) {
             const int o = wave >> 1, h = wave & 1;
+            double *tile = tiles + wave * SCRATCH_WORDS;   // row (o, h): read into registers, then the transpose scratch
             double x[16];
-            static_for<0, 16>([&](auto V) { x[V] = SD[(o * 2 + h) * N + V * 64 + lane]; });
+            static_for<0, 16>([&](auto V) { x[V] = tile[V * 64 + lane]; });
             if (h) static_for<0, 16>([&](auto V) { x[V] = f49::mul(x[V], lds[W_T + N + V * 64 + lane]); });
-            inverse(x, lane, lds, tiles + wave * SCRATCH_WORDS);
+            wave_sync();
+            inverse(x, lane, lds, tile);
             double *ao = acc + o * W_N + h * N;
             static_for<0, 16>([&](auto J) { ao[lane + 64 * J] = f49::red(ao[lane + 64 * J] + x[J]); });
         }
+        PH_MARK(5);
         __syncthreads();
+        PH_MARK(6);
     }
+#ifdef BMI_PHASE_PROF
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k_ = 0; k_ < 8; k_++) g_phase[wave * 8 + k_] = ph_[k_];
+#endif
     u64 *o = out + (size_t)ct * (W_N + 1);
     for (uint32_t nn = tid; nn < (uint32_t)W_N; nn += W_THREADS) {
         const double a0 = acc[(nn & 1) * N + (nn >> 1)];
@@ -811,13 +879,19 @@ constexpr double I4_INV = f49::centred_c(f49::powmod_c(f49::GEN, 3 * ((f49::Q - 
 static_assert(f49::mulmod_c(f49::powmod_c(f49::GEN, (f49::Q - 1) / 4), f49::powmod_c(f49::GEN, (f49::Q - 1) / 4)) == f49::Q - 1, "i^2 = -1");
 
 // part transform of part j (0..3): forward, twist by T_j (j >= 1; g_t = tables [3][1024] in (reg, lane) order), store reduced
+template <bool PRIO = false>
 __device__ __forceinline__ void quad_forward_task(double (&x)[16], int j, int lane, const double *lds, const double *g_t,
                                                   double *tile) {
     double t[16];   // requested before the transform that hides the latency (part 0 reads T_1 and ignores it)
     const double *tp = g_t + (j ? j - 1 : 0) * N;
     static_for<0, 16>([&](auto V) { t[V] = tp[V * 64 + lane]; });
     sched_fence();
-    forward(x, lane, lds, tile);
+    if constexpr (PRIO) {
+        prio<2>();
+        forward(x, lane, lds, tile, PrioStep1(), PrioStep0());
+    } else {
+        forward(x, lane, lds, tile);
+    }
     if (j) static_for<0, 16>([&](auto V) { x[V] = f49::mul(x[V], t[V]); });
     wave_sync();
     static_for<0, 16>([&](auto V) { tile[V * 64 + lane] = f49::red(x[V]); });
@@ -897,6 +971,7 @@ __global__ void __launch_bounds__(Q_THREADS)
                 const int row = 2 * rnd + (wave >> 2), c = row / 3, lev = row % 3, j = wave & 3;
                 const double *ac = acc + c * Q_N;
                 double x[16];
+                prio<3>();
                 static_for<0, 16>([&](auto J) {
                     const uint32_t m = lane + 64 * J;
                     const uint32_t e = (4 * m + j + 2 * Q_N - a_t) & (2 * Q_N - 1);
@@ -905,7 +980,7 @@ __global__ void __launch_bounds__(Q_THREADS)
                     v = (e & Q_N) ? -v : v;
                     x[J] = digit_of(__builtin_rint(f49::red(v - ac[j * N + m]) * 0x1p-4), lev);
                 });
-                quad_forward_task(x, j, lane, lds, g_t, tiles + wave * SCRATCH_WORDS);
+                quad_forward_task<true>(x, j, lane, lds, g_t, tiles + wave * SCRATCH_WORDS);
             }
             __syncthreads();
             {

@@ -78,6 +78,9 @@ __device__ __forceinline__ void dft8(double (&x)[8]) {
 template <bool ODD>
 __device__ __forceinline__ void forward_half(double (&x)[8], int lane, const double *tw, double *scratch) {
     double wa[8], wb[8];
+#if BMI_LAT2_PRIO == 2
+    __builtin_amdgcn_s_setprio(2);
+#endif
     static_for<0, 8>([&](auto K) { wa[K] = tw[HT_W1 + K * 64 + lane]; });
     sched_fence();
     static_for<1, 8>([&](auto J) { x[J] = f49::mul(x[J], psi_pow<false, 128 * J>()); });
@@ -88,6 +91,9 @@ __device__ __forceinline__ void forward_half(double (&x)[8], int lane, const dou
     wave_sync();
     const int k1 = lane >> 3, l0 = lane & 7;
     double *row = scratch + k1 * HROW;
+#if BMI_LAT2_PRIO
+    __builtin_amdgcn_s_setprio(BMI_LAT2_PRIO == 2 ? 1 : 2);   // a wave that is ahead yields issue slots to the ones sharing its SIMD
+#endif
     static_for<0, 8>([&](auto L1) { x[L1] = row[l0 + 8 * L1]; });
     static_for<1, 8>([&](auto K) { wb[K] = tw[HT_W2 + K * 8 + l0]; });
     if constexpr (ODD) static_for<0, 8>([&](auto R) { wa[R] = tw[HT_T + R * 64 + lane]; });
@@ -99,6 +105,9 @@ __device__ __forceinline__ void forward_half(double (&x)[8], int lane, const dou
     static_for<0, 8>([&](auto K) { row[8 * K + ((l0 + K) & 7)] = x[K]; });   // lane (k1, l0), reg k2a = K
     wave_sync();
     static_for<0, 8>([&](auto L0) { x[L0] = row[8 * l0 + ((L0 + l0) & 7)]; });  // this lane is (k1, k2a = lane & 7)
+#if BMI_LAT2_PRIO
+    __builtin_amdgcn_s_setprio(BMI_LAT2_PRIO == 2 ? 0 : 1);
+#endif
     dft8<false>(x);
     if constexpr (ODD) static_for<0, 8>([&](auto R) { x[R] = f49::mul(x[R], wa[R]); });
 }

@@ -12,16 +12,17 @@ LAT_NAMES = ["key loads issue + decompose + forward (waves 0-5)", "barrier 1 wai
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-    eng = tfhe.Engine(tfhe.default_params(q_bits=49)); eng.keygen(0x5EED)
+    log_N = int(sys.argv[3]) if len(sys.argv) > 3 else 10   # 11: k_blind_rotate_wide49 (8 waves; pass variant 0)
+    eng = tfhe.Engine(tfhe.default_params(q_bits=49, log_N=log_N)); eng.keygen(0x5EED)
     DL = eng.delta_log()
     lid = eng.lut_register(np.arange(-8, 8), 4, DL)
     ct = eng.encrypt(np.random.default_rng(1).integers(-8, 8, B), DL)
     dev = torch.device("cuda:0")
     s = torch.cuda.current_stream().cuda_stream
     d_in = torch.from_numpy(ct.view(np.int64)).to(dev)
-    d_small = torch.empty((B, 631), dtype=torch.int64, device=dev)
+    d_small = torch.empty((B, eng.P.n + 1), dtype=torch.int64, device=dev)
     d_ids = torch.full((B,), lid, dtype=torch.int32, device=dev)
-    d_out = torch.empty((B, 1025), dtype=torch.int64, device=dev)
+    d_out = torch.empty((B, (1 << log_N) + 1), dtype=torch.int64, device=dev)
     variant = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # 1: pair kernel (4 waves), 2: latency kernel (8 waves)
     eng.set_kernel_variant(variant)
     eng.keyswitch(d_in, B, d_small, s)
@@ -32,9 +33,10 @@ def main():
     rc = tfhe.load_library().bmi_debug_phase_prof(buf)
     assert rc == 0, rc
     a = np.array(buf[:], dtype=np.float64).reshape(16, 8)
-    for w in range({1: 4, 2: 16, 3: 4, 4: 8}[variant]):
+    WIDE_NAMES = ["decompose + forward tasks (both rounds)", "barrier after tasks", "MAC (both rounds)", "barrier after MAC", "sums + barrier", "inverse + update (waves 0-3)", "barrier after inverse", "loop head"]
+    for w in range(8 if log_N > 10 else {1: 4, 2: 16, 3: 4, 4: 8}[variant]):
         tot = a[w].sum()
-        print(json.dumps({"wave": w, "total_cycles": tot, "per_cmux": round(tot / 630, 1),
-                          "phases_cycles_per_cmux": {n: round(v / 630, 0) for n, v in zip(LAT_NAMES if variant in (2, 4) else NAMES, a[w]) if n != "-"}}))
+        print(json.dumps({"wave": w, "total_cycles": tot, "per_cmux": round(tot / eng.P.n, 1),
+                          "phases_cycles_per_cmux": {n: round(v / eng.P.n, 0) for n, v in zip(WIDE_NAMES if log_N > 10 else (LAT_NAMES if variant in (2, 4) else NAMES), a[w]) if n != "-"}}))
 
 main()
