@@ -444,3 +444,48 @@ def test_reference_whole_inverse_traced_unmodified_simulate():
         for v in case["vectors"]:
             assert c.simulate(v["inputs"]) == v["expected"]
             assert ours.simulate(v["inputs"]) == v["expected"]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/matrix_inversion"), reason="needs the reference checkout (build container only)")
+def test_shim_retraces_the_reference_to_the_committed_fixture():
+    """Generator guard, build container only: the Tracer-compatible shim (tools/encshim) run again on the reference's
+    unmodified `base_p_subtraction` and `QFloat.__mul__` gives circuits that agree with the committed fixture on its
+    vectors (the trace is deterministic up to the random inputset, so outputs are compared, not node lists)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import json, os, random, sys
+repo = sys.argv[1]
+sys.path[:0] = [os.path.join(repo, "tools", "encshim"), "/root/reference/matrix_inversion", os.path.join(repo, "bounty-matrix-inversion_amd")]
+import numpy as np
+from concrete import fhe
+import base_p_arrays as ref
+import qfloat as rq
+data = {c["name"]: c for c in json.load(open(os.path.join(repo, "tests", "golden", "ref_traced.json")))["cases"]}
+rng = random.Random(5)
+bits = lambda k: [rng.randint(0, 1) for _ in range(k)]
+sub = lambda a, b: ref.base_p_subtraction(a, b, 2, True)
+inputset = [(bits(10), bits(10)) for _ in range(400)] + [([0] * 10, [1] * 10), ([1] * 10, [0] * 10)]
+c, _ = fhe.trace(sub, [[(0, 1)] * 10] * 2, inputset, msg_bits=4)
+for v in data["base_p_subtraction_overflow"]["vectors"]:
+    assert c.simulate(v["inputs"]) == v["expected"]
+def mul(a, sa, b, sb):
+    r = rq.QFloat(a, 4, 2, True, sa[0]) * rq.QFloat(b, 4, 2, True, sb[0])
+    return (r._array, r._sign)
+inputset = [(bits(8), [rng.choice((-1, 1))], bits(8), [rng.choice((-1, 1))]) for _ in range(1500)]
+inputset += [([1] * 8, [s], [1] * 8, [t]) for s in (-1, 1) for t in (-1, 1)] + [([0] * 8, [1], bits(8), [-1])]
+c, _ = fhe.trace(mul, [[(0, 1)] * 8, [(-1, 1)], [(0, 1)] * 8, [(-1, 1)]], inputset, msg_bits=4)
+ok = 0
+from bmi_amd.circuit import RangeError
+for v in data["QFloat.__mul__"]["vectors"]:
+    try:
+        assert c.simulate(v["inputs"]) == v["expected"]
+        ok += 1
+    except RangeError:
+        pass
+assert ok >= 12, ok
+print("ok")
+'''
+    out = subprocess.run([sys.executable, "-c", code, repo], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
