@@ -65,10 +65,31 @@ _SIGS = {
     "bmi_sync": [C.c_void_p, C.c_void_p],
     "bmi_reserve": [C.c_void_p, C.c_uint32],
     "bmi_import_keys": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "bmi_keygen_from_secret": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64],
+    "bmi_torus64_to_field": [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p],
+    "bmi_field_to_torus64": [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p],
     "bmi_set_kernel_variant": [C.c_void_p, C.c_int],
     "bmi_set_keyswitch_variant": [C.c_void_p, C.c_int],
     "bmi_key_bytes": [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
 }
+
+
+def torus64_to_field(ct, q_bits):
+    """modulus switch round(x * q / 2^64) of u64 torus words; context-free (bmi_torus64_to_field)"""
+    a = np.ascontiguousarray(ct, dtype=np.uint64)
+    out = np.empty_like(a)
+    if load_library().bmi_torus64_to_field(int(q_bits), _ptr(a), a.size, _ptr(out)):
+        raise BmiError("bmi_torus64_to_field failed")
+    return out
+
+
+def field_to_torus64(ct, q_bits):
+    """round(x * 2^64 / q) mod 2^64 of words mod q; context-free (bmi_field_to_torus64)"""
+    a = np.ascontiguousarray(ct, dtype=np.uint64)
+    out = np.empty_like(a)
+    if load_library().bmi_field_to_torus64(int(q_bits), _ptr(a), a.size, _ptr(out)):
+        raise BmiError("bmi_field_to_torus64 failed (words must be reduced mod q)")
+    return out
 
 
 def _load_hip_runtime():
@@ -206,6 +227,22 @@ class Engine:
             if sk_small.size != P.n or sk_big.size != P.k * P.N:
                 raise BmiError("secret key arrays do not match this context's parameters")
         self._ck(self.lib.bmi_import_keys(self.h, _ptr(sk_small), _ptr(sk_big), _ptr(bsk), _ptr(ksk)), "bmi_import_keys")
+
+    def keygen_from_secret(self, sk_small, sk_big, seed=0):
+        """evaluation keys for binary secret keys made elsewhere (e.g. by a Concrete client), deterministic in seed"""
+        sk_small = np.ascontiguousarray(sk_small, dtype=np.uint64)
+        sk_big = np.ascontiguousarray(sk_big, dtype=np.uint64)
+        if sk_small.size != self.P.n or sk_big.size != self.P.k * self.P.N:
+            raise BmiError("secret key arrays do not match this context's parameters")
+        self._ck(self.lib.bmi_keygen_from_secret(self.h, _ptr(sk_small), _ptr(sk_big), int(seed)), "bmi_keygen_from_secret")
+
+    def from_torus64(self, ct):
+        """ciphertext words on the 2^64 torus (Concrete's representation) -> words mod q (same shape)"""
+        return torus64_to_field(ct, self.q_bits)
+
+    def to_torus64(self, ct):
+        """ciphertext words mod q -> words on the 2^64 torus (same shape)"""
+        return field_to_torus64(ct, self.q_bits)
 
     _PARAM_FIELDS = ("n", "log_N", "k", "bs_levels", "bs_base_log", "ks_levels", "ks_base_log", "q_bits", "lwe_noise", "glwe_noise")
 

@@ -355,20 +355,64 @@ namespace {
 int upload_eval_keys(bmi_ctx *c);
 }
 
+namespace {
+int gen_eval_keys(bmi_ctx *c, uint64_t seed);
+}
+
 int bmi_keygen(bmi_ctx *c, uint64_t seed) {
     if (!c) return -1;
+    const uint32_t n = c->P.n, kN = c->P.k * c->N;
+    c->sk_small.assign(n, 0);
+    c->sk_big.assign(kN, 0);
+    Stream s1(seed, S_SK_SMALL, c->f), s2(seed, S_SK_BIG, c->f);
+    for (uint32_t i = 0; i < n; i++) c->sk_small[i] = s1.bit(i);
+    for (uint32_t i = 0; i < kN; i++) c->sk_big[i] = s2.bit(i);
+    return gen_eval_keys(c, seed);
+}
+
+int bmi_keygen_from_secret(bmi_ctx *c, const uint64_t *sk_small, const uint64_t *sk_big, uint64_t seed) {
+    if (!c || !sk_small || !sk_big) return -1;
+    const uint32_t n = c->P.n, kN = c->P.k * c->N;
+    for (uint32_t i = 0; i < n; i++)
+        if (sk_small[i] > 1) return fail(c, -1, "secret keys are binary");
+    for (uint32_t i = 0; i < kN; i++)
+        if (sk_big[i] > 1) return fail(c, -1, "secret keys are binary");
+    c->sk_small.assign(sk_small, sk_small + n);
+    c->sk_big.assign(sk_big, sk_big + kN);
+    return gen_eval_keys(c, seed);
+}
+
+// ct words on the 2^64 torus <-> words mod q: the modulus switch round(x * q / 2^64) and back.  Context-free (host).
+int bmi_torus64_to_field(uint32_t q_bits, const uint64_t *in, uint64_t words, uint64_t *out) {
+    if (!in || !out || (q_bits != 64 && q_bits != 49)) return -1;
+    const u64 q = q_bits == 49 ? f49::Q : gl::P;
+    for (u64 i = 0; i < words; i++) {
+        const unsigned __int128 t = (unsigned __int128)in[i] * q + ((unsigned __int128)1 << 63);
+        const u64 r = (u64)(t >> 64);
+        out[i] = r >= q ? r - q : r;
+    }
+    return 0;
+}
+
+int bmi_field_to_torus64(uint32_t q_bits, const uint64_t *in, uint64_t words, uint64_t *out) {
+    if (!in || !out || (q_bits != 64 && q_bits != 49)) return -1;
+    const u64 q = q_bits == 49 ? f49::Q : gl::P;
+    for (u64 i = 0; i < words; i++) {
+        if (in[i] >= q) return -1;
+        const unsigned __int128 t = ((unsigned __int128)in[i] << 64) + (q >> 1);   // round(in * 2^64 / q) mod 2^64
+        out[i] = (u64)(t / q);
+    }
+    return 0;
+}
+
+namespace {
+// evaluation keys for the secret keys held in c->sk_small / c->sk_big, deterministic in `seed`
+int gen_eval_keys(bmi_ctx *c, uint64_t seed) {
     HIP_OK(c, hipSetDevice(c->device));
     const bmi_params &P = c->P;
     const uint32_t n = P.n, N = c->N, k = P.k, l = P.bs_levels, lk = P.ks_levels, rows = c->rows;
     c->seed = seed;
     c->enc_counter = 0;
-    c->sk_small.assign(n, 0);
-    c->sk_big.assign((size_t)k * N, 0);
-    {
-        Stream s1(seed, S_SK_SMALL, c->f), s2(seed, S_SK_BIG, c->f);
-        for (uint32_t i = 0; i < n; i++) c->sk_small[i] = s1.bit(i);
-        for (uint32_t i = 0; i < k * N; i++) c->sk_big[i] = s2.bit(i);
-    }
     // --- bootstrap key: GGSW(s_i) rows, standard domain.  B = sum_j A_j * S_j + E by shifted adds (S binary).
     c->bsk_std.assign((size_t)n * rows * (k + 1) * N, 0);
     {
@@ -419,7 +463,6 @@ int bmi_keygen(bmi_ctx *c, uint64_t seed) {
     return upload_eval_keys(c);
 }
 
-namespace {
 // Evaluation keys (host copies in c->bsk_std / c->ksk) -> device: bootstrap key to the NTT domain (both layouts for
 // the 49-bit field), keyswitch key in word form (+ bias vector) and in limb form.
 int upload_eval_keys(bmi_ctx *c) {

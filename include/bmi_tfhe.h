@@ -77,6 +77,17 @@ int bmi_export_keys(const bmi_ctx *ctx, uint64_t *sk_small, uint64_t *sk_big, ui
  * qfloat_matrix_inversion.py:997-998). */
 int bmi_import_keys(bmi_ctx *ctx, const uint64_t *sk_small, const uint64_t *sk_big, const uint64_t *bsk, const uint64_t *ksk);
 
+/* Evaluation keys for secret keys made elsewhere (binary, sizes as in bmi_export_keys), deterministic in `seed`: the
+ * trusted-benchmark half of interoperating with a Concrete client, whose LWE secret keys are binary vectors too
+ * (SURVEY.md section 8 f4). */
+int bmi_keygen_from_secret(bmi_ctx *ctx, const uint64_t *sk_small, const uint64_t *sk_big, uint64_t seed);
+/* 2^64-torus interop (context-free, host): ciphertext words as Concrete stores them (u64, the torus scaled by 2^64)
+ * to words mod q and back, by the modulus switch round(x * q / 2^64) resp. round(x * 2^64 / q).  A message m * 2^(63-p)
+ * on the torus becomes m * 2^(q_bits-1-p) up to a relative 2^-30; the rounding adds < sqrt(kN/12) units of 1/q to
+ * the phase.  `words` counts u64 words (count * (k*N+1) for a batch of big-key ciphertexts). */
+int bmi_torus64_to_field(uint32_t q_bits, const uint64_t *in, uint64_t words, uint64_t *out);
+int bmi_field_to_torus64(uint32_t q_bits, const uint64_t *in, uint64_t words, uint64_t *out);
+
 /* replaces circuit.encrypt (main.py:76): big-key LWE encryptions of msgs[i] * 2^delta_log. */
 int bmi_encrypt(bmi_ctx *ctx, const int64_t *msgs, uint32_t count, uint32_t delta_log, uint64_t *ct_out);
 /* replaces circuit.decrypt (main.py:86): msgs[i] = round(phase / 2^delta_log), signed. */

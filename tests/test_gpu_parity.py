@@ -513,3 +513,44 @@ def test_pbs_known_answer_digests_on_gpu():
                 assert h(e.pbs_host(ct, np.full(len(kat["msgs"]), lid, np.uint32))) == case["bootstrapped"], variant
         finally:
             e.close()
+
+
+@pytest.mark.parametrize("q_bits", [49, 64], ids=["p49_f64", "goldilocks64"])
+def test_torus64_client_interop(q_bits):
+    """a client that works on the 2^64 torus the way Concrete does (binary LWE secret keys,
+    u64 ciphertext words, message m * 2^(63 - p)) - here a numpy stand-in - encrypts under its own keys; the server
+    derives evaluation keys for those secrets (bmi_keygen_from_secret), switches the ciphertexts to its field
+    (bmi_torus64_to_field), bootstraps on the GPU and switches back; the client decrypts LUT[m] on the torus."""
+    from bmi_amd import tfhe
+    rng = np.random.default_rng(2064)
+    e = tfhe.Engine(tfhe.default_params(q_bits=q_bits))
+    try:
+        P = e.P
+        kN = P.k * P.N
+        sk_small = rng.integers(0, 2, P.n, dtype=np.uint64)
+        sk_big = rng.integers(0, 2, kN, dtype=np.uint64)
+        e.keygen_from_secret(sk_small, sk_big, seed=77)
+        got_small, got_big, _, _ = e.export_keys()
+        assert np.array_equal(got_small, sk_small) and np.array_equal(got_big, sk_big)
+        p = 4
+        table = rng.integers(-8, 8, 16)
+        lid = e.lut_register(table, p, e.delta_log(p))
+        msgs = np.concatenate([np.arange(-8, 8), rng.integers(-8, 8, 112)])
+        # client-side encryption on the 2^64 torus (uint64 arithmetic wraps mod 2^64)
+        a = rng.integers(0, 1 << 63, (msgs.size, kN), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (msgs.size, kN), dtype=np.uint64)
+        noise = np.rint(rng.normal(0.0, P.glwe_noise * 2.0**64, msgs.size)).astype(np.int64).astype(np.uint64)
+        body = (a * sk_big[None, :]).sum(axis=1, dtype=np.uint64) + (msgs.astype(np.int64) << (63 - p)).astype(np.uint64) + noise
+        ct_torus = np.concatenate([a, body[:, None]], axis=1)
+        out_field = e.pbs_host(e.from_torus64(ct_torus), np.full(msgs.size, lid, dtype=np.uint32))
+        out_torus = e.to_torus64(out_field)
+        # client-side decryption on the torus
+        phase = (out_torus[:, kN] - (out_torus[:, :kN] * sk_big[None, :]).sum(axis=1, dtype=np.uint64)).astype(np.int64)
+        dec = (phase + (1 << (62 - p))) >> (63 - p)
+        want = table[msgs + 8]
+        assert np.array_equal(dec, want)
+        assert np.array_equal(e.decrypt(out_field, e.delta_log(p)), want)      # and the field-side view agrees
+        # distance of the torus phase from the exact encoding: well inside half a box (2^(62-p))
+        err = np.abs(phase - (want.astype(np.int64) << (63 - p)))
+        assert err.max() < (1 << (62 - p)) // 4
+    finally:
+        e.close()
