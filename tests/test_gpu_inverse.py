@@ -258,7 +258,8 @@ def test_reference_whole_inverse_traced_unmodified_on_gpu():
     """The reference's UNMODIFIED qfloat_matrix_inverse (tests/golden/ref_traced_inverse.json.gz, see the CPU test of the
     same name) on ciphertexts: its unfused operator sequence needs 5-bit look-ups, so it runs on the N = 2048 parameter
     set; 2x2 (len 20, ints 8: 2,395 PBS in 374 levels) on two matrices and 3x3 (len 30, ints 12: 34,032 PBS in 3,056
-    levels) on one, decrypted digits against the reference's plaintext outputs."""
+    levels) on one, the 2x2 traced with lazy look-up fusion (306 levels) on two, decrypted digits against the reference's
+    plaintext outputs."""
     import gzip
     from bmi_amd import tfhe
     from bmi_amd.circuit import Circuit
@@ -269,7 +270,7 @@ def test_reference_whole_inverse_traced_unmodified_on_gpu():
     try:
         e.keygen(0x5EED)
         dl = e.delta_log(5)
-        for case, n_vec in zip(data["cases"], (2, 1)):
+        for case, n_vec in zip(data["cases"], (2, 1, 2)):
             ex = Executor(Circuit.from_dict(case["circuit"]), e)
             for v in case["vectors"][:n_vec]:
                 got = e.decrypt(ex.run(e.encrypt(v["inputs"], dl)), dl)

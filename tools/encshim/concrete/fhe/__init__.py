@@ -10,12 +10,14 @@ How it works (the reference is data-oblivious, so its sequence of operations is 
   2. BUILD: the function runs again on symbolic values (Lin); the k-th non-linear operation claims the range measured
      for it (`Lin.assume`, verified by `Circuit.simulate`) and becomes a table look-up of the circuit.
 Operator surface: SURVEY.md section 8b."""
+import operator as _op
+
 import numpy as np
 
 from .tracing.tracer import Tracer
 from . import tracing  # noqa: F401
 
-_S = {"mode": None, "circuit": None, "ranges": [], "site": 0, "margin": 0}
+_S = {"mode": None, "circuit": None, "ranges": [], "site": 0, "margin": 0, "fuse": False}
 
 
 def _site(vals):
@@ -31,6 +33,67 @@ def _site(vals):
             r[0], r[1] = min(r[0], lo), max(r[1], hi)
         return None
     return _S["ranges"][k]
+
+
+class Def:
+    """Build phase, lazy look-up fusion (trace(..., fuse=True)): a value known as a univariate function of ONE linear
+    combination `base` of ciphertexts - its table over base's interval - and not yet computed.  Further univariate
+    operations, constants, and values deferred on the same base compose into the table for free; a look-up (one PBS)
+    is emitted only when the value meets a different base in a linear combination or a product, or is an output.  This
+    is the fusion the restated layer in bmi_amd/ does by hand (e.g. the reference's abs -> // base -> * sign ->
+    c - carry * base chain of qfloat.py:617-621 becomes two look-ups on c)."""
+    __slots__ = ("base", "tab", "_lin")
+
+    def __init__(self, base, tab):
+        self.base, self.tab, self._lin = base, tab, None
+
+    @property
+    def key(self):
+        return _lin_key(self.base)
+
+    def lin(self):
+        if self._lin is None:
+            lo, tab = self.base.lo, self.tab
+            self._lin = _S["circuit"].lut(self.base, lambda t: tab[t - lo])
+        return self._lin
+
+
+def _lin_key(lin):
+    return (tuple(sorted(lin.terms.items())), lin.const)
+
+
+def _mat(v):
+    return v.lin() if isinstance(v, Def) else v
+
+
+def _as_def(v):
+    """v as a deferred univariate value, if it is one (or a narrow linear combination: the identity on itself)"""
+    if isinstance(v, Def):
+        return v
+    if hasattr(v, "terms") and v.terms and v.hi - v.lo + 1 <= (1 << _S["circuit"].msg_bits):
+        return Def(v, list(range(v.lo, v.hi + 1)))
+    return None
+
+
+def _fused(a, b, op):
+    """op(a, b) without a PBS when a and b are univariate in the same base (or one is a constant); None otherwise"""
+    if not _S["fuse"]:
+        return None
+    ia, ib = isinstance(a, (int, np.integer)), isinstance(b, (int, np.integer))
+    if ia and isinstance(b, Def):
+        return Def(b.base, [int(op(int(a), y)) for y in b.tab])
+    if ib and isinstance(a, Def):
+        return Def(a.base, [int(op(x, int(b))) for x in a.tab])
+    if not (isinstance(a, Def) or isinstance(b, Def)):
+        return None
+    da, db = _as_def(a), _as_def(b)
+    if da is None or db is None or da.key != db.key:
+        return None
+    lo, hi = max(da.base.lo, db.base.lo), min(da.base.hi, db.base.hi)   # both interval claims hold
+    if lo > hi:
+        return None
+    base = da.base if (da.base.lo, da.base.hi) == (lo, hi) else (db.base if (db.base.lo, db.base.hi) == (lo, hi) else da.base.assume(lo, hi))
+    return Def(base, [int(op(da.tab[t - da.base.lo], db.tab[t - db.base.lo])) for t in range(lo, hi + 1)])
 
 
 class Enc(Tracer):
@@ -59,27 +122,40 @@ class Enc(Tracer):
             return Enc(np.array([int(fn(int(t))) for t in self.v], dtype=np.int64))
         lo, hi = _site(None)
         c = _S["circuit"]
+        if isinstance(self.v, Def):
+            return Enc(Def(self.v.base, [int(fn(int(y))) for y in self.v.tab]))
         x = self.v.assume(lo, hi) if hasattr(self.v, "assume") else self.v
+        if _S["fuse"] and hasattr(x, "terms") and x.terms and x.hi - x.lo + 1 <= (1 << c.msg_bits):
+            return Enc(Def(x, [int(fn(t)) for t in range(x.lo, x.hi + 1)]))
         out = c.lut(x, lambda t: int(fn(int(t))))
         return Enc(out)   # stays encrypted even when the look-up folds to a constant: both phases must see the same sites
 
     # ---- linear
+    @staticmethod
+    def _linear(a, b, op):
+        if _S["mode"] == "build":
+            r = _fused(a, b, op)
+            if r is not None:
+                return Enc(r)
+            a, b = _mat(a), _mat(b)
+        return Enc._wrap(op(a, b))
+
     def __add__(self, o):
         if isinstance(o, (np.ndarray, EncArray)):
             return NotImplemented
-        return Enc._wrap(self.v + Enc._raw(o))
+        return Enc._linear(self.v, Enc._raw(o), _op.add)
     __radd__ = __add__
 
     def __sub__(self, o):
         if isinstance(o, (np.ndarray, EncArray)):
             return NotImplemented
-        return Enc._wrap(self.v - Enc._raw(o))
+        return Enc._linear(self.v, Enc._raw(o), _op.sub)
 
     def __rsub__(self, o):
-        return Enc._wrap(Enc._raw(o) - self.v)
+        return Enc._linear(Enc._raw(o), self.v, _op.sub)
 
     def __neg__(self):
-        return Enc._wrap(-self.v)
+        return Enc._linear(0, self.v, _op.sub)
 
     def __pos__(self):
         return self
@@ -88,14 +164,17 @@ class Enc(Tracer):
         if isinstance(o, (np.ndarray, EncArray)):
             return NotImplemented
         if not isinstance(o, Enc):
-            return Enc._wrap(self.v * int(o))
+            return Enc._linear(self.v, int(o), _op.mul)
         if _S["mode"] == "measure":
             _site(self.v)
             _site(o.v)
             return Enc(self.v * o.v)
         ra, rb = _site(None), _site(None)
         c = _S["circuit"]
-        out = c.mul(self.v.assume(*ra), o.v.assume(*rb))
+        r = _fused(self.v, o.v, _op.mul)
+        if r is not None:
+            return Enc(r)
+        out = c.mul(_mat(self.v).assume(*ra), _mat(o.v).assume(*rb))
         return Enc(out)   # stays encrypted even when the look-up folds to a constant: both phases must see the same sites
     __rmul__ = __mul__
 
@@ -337,7 +416,7 @@ def univariate(f):
 
 
 # ------------------------------------------------------------------------------------------ the two-phase tracer
-def trace(fn, input_ranges, inputset, msg_bits=6):
+def trace(fn, input_ranges, inputset, msg_bits=6, fuse=False):
     """fn(*arrays) -> array/scalar/tuple of them; input_ranges: per argument a list of (lo, hi) per element;
     inputset: list of argument tuples (lists of ints).  Returns (circuit, n_outputs)."""
     import os
@@ -368,7 +447,7 @@ def trace(fn, input_ranges, inputset, msg_bits=6):
     n_sites = _S["site"]
     # 2. build
     c = Circuit(msg_bits=msg_bits)
-    _S.update(mode="build", site=0, circuit=c)
+    _S.update(mode="build", site=0, circuit=c, fuse=bool(fuse))
     args = []
     for rng in input_ranges:
         a = np.empty(len(rng), dtype=object)
@@ -377,6 +456,6 @@ def trace(fn, input_ranges, inputset, msg_bits=6):
         args.append(EncArray(a))
     outs = flat(fn(*args))
     assert _S["site"] == n_sites, "the function is not data-oblivious: different operation sequence"
-    c.set_outputs([Enc._raw(o) for o in outs])
-    _S.update(mode=None)
+    c.set_outputs([_mat(Enc._raw(o)) for o in outs])
+    _S.update(mode=None, fuse=False)
     return c, len(outs)

@@ -19,10 +19,10 @@ bits = lambda k: [rng.randint(0, 1) for _ in range(k)]   # noqa: E731
 cases = []
 
 
-def add_case(name, cite, fn, plain, gen, ranges, n_vec=16, n_set=1500, msg_bits=4, into=None):
+def add_case(name, cite, fn, plain, gen, ranges, n_vec=16, n_set=1500, msg_bits=4, into=None, fuse=False):
     from bmi_amd.circuit import RangeError
     inputset = [gen() for _ in range(n_set)]
-    circ, _ = fhe.trace(fn, ranges, inputset, msg_bits=msg_bits)
+    circ, _ = fhe.trace(fn, ranges, inputset, msg_bits=msg_bits, fuse=fuse)
     vectors, outside = [], 0
     while len(vectors) < n_vec:
         args = gen()
@@ -39,7 +39,7 @@ def add_case(name, cite, fn, plain, gen, ranges, n_vec=16, n_set=1500, msg_bits=
         vectors.append({"inputs": flat, "expected": want})
     width = max(p for p, _ in circ.luts)
     (cases if into is None else into).append(
-        {"name": name, "reference": cite, "msg_bits": msg_bits, "pbs": len(circ.nodes), "depth": len(circ.levels()),
+        {"name": name, "reference": cite, "msg_bits": msg_bits, "lazy_lookup_fusion": bool(fuse), "pbs": len(circ.nodes), "depth": len(circ.levels()),
          "widest_lookup_bits": width, "inputset": n_set, "outside_inputset_ranges": outside,
          "circuit": circ.to_dict(), "vectors": vectors})
     print(f"{name}: pbs {len(circ.nodes)} depth {len(circ.levels())} widest look-up {width} bits, "
@@ -113,20 +113,21 @@ import qfloat_matrix_inversion as rmi
 nrng = np.random.RandomState(99)
 
 
-def inverse_case(n, ln, ints, n_vec, into):
+def inverse_case(n, ln, ints, n_vec, into, fuse=False):
     def gen():
         M = nrng.randn(n, n) * 100                                   # the sampler of SURVEY.md section 8d
         a, sg = rmi.float_matrix_to_qfloat_arrays(M, ln, ints, 2)
         return ([int(v) for v in np.asarray(a).reshape(-1)], [int(v) for v in np.asarray(sg).reshape(-1)])
     run = lambda a, sg: rmi.qfloat_matrix_inverse(a.reshape(n * n, ln), sg, n, ln, ints, 2, False, False)  # noqa: E731
-    add_case(f"qfloat_matrix_inverse_{n}x{n}", "qfloat_matrix_inversion.py:672-720", run, run, gen,
-             [[(0, 1)] * (n * n * ln), [(-1, 1)] * (n * n)], n_vec=n_vec, n_set=2000, msg_bits=5, into=into)
+    add_case(f"qfloat_matrix_inverse_{n}x{n}" + ("_fused" if fuse else ""), "qfloat_matrix_inversion.py:672-720", run, run, gen,
+             [[(0, 1)] * (n * n * ln), [(-1, 1)] * (n * n)], n_vec=n_vec, n_set=2000, msg_bits=5, into=into, fuse=fuse)
     into[-1].update(n=n, len=ln, ints=ints)
 
 
 inverses = []
 inverse_case(2, 20, 8, 4, inverses)
 inverse_case(3, 30, 12, 2, inverses)
+inverse_case(2, 20, 8, 4, inverses, fuse=True)   # the same trace with the shim's lazy look-up fusion switched on
 with gzip.GzipFile(os.path.join(REPO, "tests", "golden", "ref_traced_inverse.json.gz"), "wb", mtime=0) as f:
     f.write(json.dumps({"generator": "tools/gen_ref_traced.py", "cases": inverses}).encode())
 print("wrote tests/golden/ref_traced_inverse.json.gz",
