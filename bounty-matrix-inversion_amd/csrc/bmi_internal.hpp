@@ -32,6 +32,9 @@
 #ifndef BMI_LAT2_PRIO
 #define BMI_LAT2_PRIO 2  // s_setprio in the forward tasks of the latency kernels (N = 1024 two-wave transforms, N = 2048, N = 4096): tasks sharing a SIMD step down 3,2,1,0 as they advance, so they finish together instead of the last one running its tail alone (4.02 -> 3.57 ms per bootstrap at N = 1024; 1: three steps, 3.60 ms; 0: none)
 #endif
+#ifndef BMI_WIDE_STAGE
+#define BMI_WIDE_STAGE 2  // key-word requests of the N = 2048 kernel: 0 = all before the task, 1 = half before / half after the decomposition, 2 = a quarter each before the task, after the decomposition, mid-transform and before its last transpose (8.95 -> 8.55 ms per bootstrap in one session)
+#endif
 #ifndef BMI_KS_MFMA_MIN
 #define BMI_KS_MFMA_MIN 1  // smallest batch that takes the matrix-core keyswitch (0.05 ms against 0.14 ms scalar even at one ciphertext)
 #endif

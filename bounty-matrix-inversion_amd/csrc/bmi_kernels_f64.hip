@@ -778,17 +778,29 @@ __global__ void __launch_bounds__(W_THREADS)
         auto round = [&](auto R0_, auto NR_) {
             constexpr int R0 = R0_, NR = NR_;
             double b[4][NR][2];            // key words of this thread's four (output, slot) items
+            // One CU takes its key words in at ~20 B per cycle (131 KB in the first round), and a wavefront cannot run
+            // ahead of a load it has not been able to issue: the rows are requested in stages between the pieces of
+            // the task instead of all up front (BMI_WIDE_STAGE: 0 = all first, 1 = two stages, 2 = four).
+            auto load_rows = [&](auto RA_, auto RB_) {
+                static_for<RA_, RB_>([&](auto R) {
+                    constexpr int r = R;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int idx = tid + W_THREADS * q, o = idx >> 10, p = idx & (N - 1);
-#pragma unroll
-                for (int r = 0; r < NR; r++) {
-                    const double *row = bi + (size_t)((R0 + r) * 2 + o) * W_N;
-                    b[q][r][0] = row[p];
-                    b[q][r][1] = row[N + p];
-                }
-            }
+                    for (int q = 0; q < 4; q++) {
+                        const int idx = tid + W_THREADS * q, o = idx >> 10, p = idx & (N - 1);
+                        const double *row = bi + (size_t)((R0 + r) * 2 + o) * W_N;
+                        b[q][r][0] = row[p];
+                        b[q][r][1] = row[N + p];
+                    }
+                });
+            };
+            using IC0 = std::integral_constant<int, 0>;
+            using ICN = std::integral_constant<int, NR>;
+            constexpr int S1 = BMI_WIDE_STAGE == 0 ? NR : (BMI_WIDE_STAGE == 1 ? NR / 2 : NR / 4);   // rows requested first
+            constexpr int S2 = BMI_WIDE_STAGE == 2 ? NR / 2 : NR;                                    // ... by the end of the decomposition
+            constexpr int S3 = BMI_WIDE_STAGE == 2 ? (3 * NR + 3) / 4 : NR;                          // ... by the middle of the transform
             if (wave < 2 * NR) {
+                load_rows(IC0(), std::integral_constant<int, S1>());
+                pin();
                 const int row = R0 + (wave >> 1), c = row / 3, lev = row % 3, h = wave & 1;
                 const double *ac = acc + c * W_N;
                 double x[16];
@@ -801,7 +813,26 @@ __global__ void __launch_bounds__(W_THREADS)
                     v = (e & W_N) ? -v : v;
                     x[J] = digit_of(__builtin_rint(f49::red(v - ac[h * N + m]) * 0x1p-4), lev);
                 });
-                wide_forward_task<true>(x, h, lane, lds, tiles + wave * SCRATCH_WORDS);
+                pin();
+                load_rows(std::integral_constant<int, S1>(), std::integral_constant<int, S2>());
+                pin();
+                double *tile = tiles + wave * SCRATCH_WORDS;
+                prio<2>();
+                forward(
+                    x, lane, lds, tile,
+                    [&]() {
+                        prio<1>();
+                        load_rows(std::integral_constant<int, S2>(), std::integral_constant<int, S3>());
+                    },
+                    [&]() {
+                        prio<0>();
+                        load_rows(std::integral_constant<int, S3>(), ICN());
+                    });
+                if (h) static_for<0, 16>([&](auto V) { x[V] = f49::mul(x[V], lds[W_T + V * 64 + lane]); });
+                wave_sync();
+                static_for<0, 16>([&](auto V) { tile[V * 64 + lane] = f49::red(x[V]); });
+            } else {
+                load_rows(IC0(), ICN());
             }
             PH_MARK(0);
             __syncthreads();
