@@ -141,15 +141,16 @@ def main():
     total_pbs = B * world * args.steps
     value = total_pbs / elapsed
     achieved_gbs = BSK_BYTES_PER_PBS * B / (br_ms * 1e-3) / 1e9
-    traffic = None
+    traffic = valu_busy = None
     tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("batch") == B:
+            if tj.get("batch") == B and tj.get("kernel") == ("k_blind_rotate_tp" if eng.q_bits == 64 else "k_blind_rotate_tpx49"):
                 traffic = tj.get("bytes_per_launch")
+                valu_busy = tj.get("valu_busy_frac")
         except Exception:
-            traffic = None
+            traffic = valu_busy = None
     res = {
         "metric": "PBS/sec per GPU + encrypted n x n inverse wall-clock (n=2,3,4)", "value": value, "unit": "PBS/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,7 +166,8 @@ def main():
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "k_blind_rotate_tp" if eng.q_bits == 64 else "k_blind_rotate_tpx49", "kernel_ms": br_ms,
                      "algorithmic_bytes_per_pbs": BSK_BYTES_PER_PBS,
-                     "alu": {"modmul_per_s": MODMUL_PER_PBS * B / (br_ms * 1e-3), "modmul_per_pbs": MODMUL_PER_PBS}},
+                     "alu": {"modmul_per_s": MODMUL_PER_PBS * B / (br_ms * 1e-3), "modmul_per_pbs": MODMUL_PER_PBS,
+                             "valu_busy_frac_profiled": valu_busy}},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

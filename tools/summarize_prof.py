@@ -46,8 +46,15 @@ h = counters[hot]
 if "FETCH_SIZE" in h and "WRITE_SIZE" in h:
     # MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64-byte units as 32 -> x2
     h["hbm_bytes_per_launch_corrected"] = (2 * h["FETCH_SIZE"] + h["WRITE_SIZE"]) * 1024
+    extra = {}
+    if "SQ_ACTIVE_INST_VALU" in h and "SQ_WAVE_CYCLES" in h:
+        # share of the resident wavefronts' cycles in which a VALU instruction of theirs is executing, summed over the
+        # wavefronts of a SIMD (waves_per_simd of them resident): how busy the vector ALUs are - what bounds this kernel
+        wps = 2.0
+        extra = {"valu_busy_frac": wps * h["SQ_ACTIVE_INST_VALU"] / h["SQ_WAVE_CYCLES"], "waves_per_simd": wps,
+                 "valu_formula": "waves_per_simd * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES"}
     json.dump({"batch": batch, "bytes_per_launch": h["hbm_bytes_per_launch_corrected"], "kernel": hot,
-               "source": f"profiles/{tag}_pmc_B{batch}.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024"},
+               "source": f"profiles/{tag}_pmc_B{batch}.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", **extra},
               open(os.path.join(REPO, "profiles", "hbm_traffic.json"), "w"), indent=1)
 json.dump({"tag": tag, "batch": batch, "kernel_trace_avg_ns": avg_ns, "counters_avg_per_launch": counters,
            "note": "rocprofv3 --kernel-trace --stats pass and three separate --pmc passes of `python3 bench.py --batch "
