@@ -51,8 +51,8 @@ def main():
     ap.add_argument("--no-inverse", action="store_true", help="skip the encrypted-inverse wall-clock leg")
     ap.add_argument("--no-second-field", action="store_true",
                     help="skip the short extra leg that reports PBS/s on the other ciphertext field (N=1, rank 0)")
-    ap.add_argument("--inverse-sizes", default="2,3", help="matrix sizes of the encrypted-inverse leg (N=1, rank 0); "
-                    "4 adds ~20 s (BASELINE configs 2, 3, 4)")
+    ap.add_argument("--inverse-sizes", default="2,3,4", help="matrix sizes of the encrypted-inverse leg (N=1, rank 0): "
+                    "BASELINE configs 2, 3, 4 (~45 s together, most of it tracing the circuits); 8 takes ~2 min more")
     ap.add_argument("--inverse-sharded", action="store_true",
                     help="N > 1 only (opt-in): also run the encrypted-inverse leg with its wide levels split across the "
                          "ranks (executor.py; one RCCL all-gather per split level)")
