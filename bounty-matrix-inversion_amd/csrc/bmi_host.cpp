@@ -853,8 +853,19 @@ int bmi_sync(bmi_ctx *c, void *stream) {
 }
 
 // ------------------------------------------------------------------- host-buffer convenience forms
+namespace {
+// a look-up id beyond the registered tables would make the kernels read past the table buffer: refused on the host
+// (the device-pointer entry points cannot look at their ids without a synchronisation; their contract is ids < count)
+int check_lut_ids(bmi_ctx *c, const uint32_t *lut_ids, uint32_t count) {
+    for (uint32_t i = 0; i < count; i++)
+        if (lut_ids[i] >= c->n_luts) return fail(c, -1, "look-up id " + std::to_string(lut_ids[i]) + " is not registered");
+    return 0;
+}
+}  // namespace
+
 int bmi_pbs_batch_host(bmi_ctx *c, const uint64_t *in, const uint32_t *lut_ids, uint32_t count, uint64_t *out) {
     if (!c || !in || !lut_ids || !out) return -1;
+    if (int bad = check_lut_ids(c, lut_ids, count)) return bad;
     HIP_OK(c, hipSetDevice(c->device));
     int rc = ensure_io(c, count);
     if (rc) return rc;
@@ -886,6 +897,7 @@ int bmi_keyswitch_batch_host(bmi_ctx *c, const uint64_t *in, uint32_t count, uin
 int bmi_blind_rotate_batch_host(bmi_ctx *c, const uint64_t *small_in, const uint32_t *lut_ids, uint32_t count,
                                 uint64_t *out) {
     if (!c || !small_in || !lut_ids || !out) return -1;
+    if (int bad = check_lut_ids(c, lut_ids, count)) return bad;
     HIP_OK(c, hipSetDevice(c->device));
     int rc = ensure_io(c, count);
     if (rc) return rc;

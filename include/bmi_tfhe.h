@@ -106,7 +106,8 @@ int bmi_lut_get(const bmi_ctx *ctx, uint32_t lut_id, uint64_t *test_vector);
 /* ---- the hot path: replaces circuit.run (main.py:81) -------------------------------------------- */
 /* Programmable bootstrap of `count` big-key ciphertexts, Concrete order:
  *   keyswitch (big -> small) -> modulus switch to 2N -> blind rotation -> sample extraction.
- * d_in/d_out: [count][k*N+1] device words (may alias); d_lut_ids: [count] device uint32. */
+ * d_in/d_out: [count][k*N+1] device words (may alias); d_lut_ids: [count] device uint32, every id one returned by
+ * bmi_lut_register (the device-pointer entry points cannot inspect their ids; the *_host forms refuse unknown ones). */
 int bmi_pbs_batch(bmi_ctx *ctx, const uint64_t *d_in, const uint32_t *d_lut_ids, uint32_t count, uint64_t *d_out,
                   void *stream);
 /* the two stages, separately (d_small: [count][n+1]) */
