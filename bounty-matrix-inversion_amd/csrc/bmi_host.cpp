@@ -327,7 +327,7 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
         if (hipMemcpy(c->d_tw_wide, tw.data(), tw.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(wide twiddles) failed");
     }
-    c->lut_cap = 1024;
+    c->lut_cap = BMI_LUT_CAP;
     if (hipMalloc(&c->d_luts, (size_t)c->lut_cap * c->N * 8) != hipSuccess) return bail("hipMalloc(luts) failed");
     *out = c;
     return 0;

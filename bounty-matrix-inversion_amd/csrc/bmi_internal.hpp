@@ -35,6 +35,10 @@
 #ifndef BMI_WIDE_STAGE
 #define BMI_WIDE_STAGE 2  // key-word requests of the N = 2048 kernel: 0 = all before the task, 1 = half before / half after the decomposition, 2 = a quarter each before the task, after the decomposition, mid-transform and before its last transpose (8.95 -> 8.55 ms per bootstrap in one session)
 #endif
+// Capacity of a context's look-up table buffer (tables of N words, allocated at creation).  A power of two: the kernels
+// mask the ids they are handed with it, so that a wrong id in a device-resident id array reads a wrong (possibly
+// unregistered) table instead of faulting; the host-buffer entry points refuse unknown ids outright.
+#define BMI_LUT_CAP 1024
 #ifndef BMI_KS_MFMA_MIN
 #define BMI_KS_MFMA_MIN 1  // smallest batch that takes the matrix-core keyswitch (0.05 ms against 0.14 ms scalar even at one ciphertext)
 #endif

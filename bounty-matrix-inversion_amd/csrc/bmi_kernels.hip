@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(128 * CTS, 2)
     // ACC = X^(-b~) * (0, tv): component 0 starts at zero, component 1 at the rotated test polynomial
     u64 acc[16];
     {
-        const u64 *tv = luts + (size_t)lut_ids[ct] * N;
+        const u64 *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
         const uint32_t bt = at[n];
         static_for<0, 16>([&](auto J) {
             const uint32_t e = (lane + 64 * J + bt) & (2 * N - 1);
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(LAT_THREADS)
     for (uint32_t i = tid; i <= n; i += LAT_THREADS) at[i] = (uint16_t)gl::modswitch(lwe[i], LOG_N + 1);
     __syncthreads();
     {
-        const u64 *tv = luts + (size_t)lut_ids[ct] * N;
+        const u64 *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
         const uint32_t bt = at[n];
         for (int m = tid; m < N; m += LAT_THREADS) {
             const uint32_t e = (m + bt) & (2 * N - 1);

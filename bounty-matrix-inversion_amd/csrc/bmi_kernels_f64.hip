@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
 
     double acc[16];
     {
-        const double *tv = luts + (size_t)lut_ids[ct] * N;
+        const double *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
         const uint32_t bt = at[n];
         static_for<0, 16>([&](auto J) {
             const uint32_t e = (lane + 64 * J + bt) & (2 * N - 1);
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
     for (uint32_t i = lane + 64 * c; i <= n; i += 128) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 1);
     __syncthreads();
     {
-        const double *tv = luts + (size_t)lut_ids[ct] * N;
+        const double *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
         const uint32_t bt = at[n];
         static_for<0, 16>([&](auto J) {
             const uint32_t e = (lane + 64 * J + bt) & (2 * N - 1);
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(LAT_THREADS)
     for (uint32_t i = tid; i <= n; i += LAT_THREADS) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 1);
     __syncthreads();
     {
-        const double *tv = luts + (size_t)lut_ids[ct] * N;
+        const double *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
         const uint32_t bt = at[n];
         for (int m = tid; m < N; m += LAT_THREADS) {
             const uint32_t e = (m + bt) & (2 * N - 1);
@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(L2_THREADS)
     for (uint32_t i = tid; i <= n; i += L2_THREADS) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 1);
     __syncthreads();
     {
-        const double *tv = luts + (size_t)lut_ids[ct] * N;
+        const double *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
         const uint32_t bt = at[n];
         const uint32_t nn = tid;  // coefficient index
         const uint32_t e = (nn + bt) & (2 * N - 1);
@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(W_THREADS)
     for (uint32_t i = tid; i <= n; i += W_THREADS) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 2);
     __syncthreads();
     {
-        const double *tv = luts + (size_t)lut_ids[ct] * W_N;
+        const double *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * W_N;
         const uint32_t bt = at[n];
         for (uint32_t nn = tid; nn < (uint32_t)W_N; nn += W_THREADS) {
             const uint32_t e = (nn + bt) & (2 * W_N - 1);
@@ -976,7 +976,7 @@ __global__ void __launch_bounds__(Q_THREADS)
     for (uint32_t i = tid; i <= n; i += Q_THREADS) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 3);
     __syncthreads();
     {
-        const double *tv = luts + (size_t)lut_ids[ct] * Q_N;
+        const double *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * Q_N;
         const uint32_t bt = at[n];
         for (uint32_t nn = tid; nn < (uint32_t)Q_N; nn += Q_THREADS) {
             const uint32_t e = (nn + bt) & (2 * Q_N - 1);
