@@ -277,3 +277,32 @@ def test_reference_whole_inverse_traced_unmodified_on_gpu():
                 assert list(got) == v["expected"], case["name"]
     finally:
         e.close()
+
+
+def test_reference_own_fhe_tests_replayed_on_ciphertexts():
+    """The circuits the reference's own FHE test file compiled (tests/golden/ref_own_fhe_tests.json.gz, see the CPU test
+    of the same name) on ciphertexts: the inputs its tests used are encrypted, every look-up runs on the GPU (4-bit
+    circuits on the N = 1024 set, 5-bit ones on N = 2048), and the decrypted digits equal the outputs on which the
+    reference's own assertions passed."""
+    import gzip
+    from bmi_amd import tfhe
+    from bmi_amd.circuit import Circuit
+    from bmi_amd.executor import Executor
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_own_fhe_tests.json.gz"), "rt") as f:
+        data = json.load(f)
+    engines = {}
+    try:
+        for case in data["cases"]:
+            bits = case["msg_bits"]
+            if bits not in engines:
+                engines[bits] = tfhe.Engine(tfhe.default_params(q_bits=49, log_N={4: 10, 5: 11}[bits]))
+                engines[bits].keygen(0x5EED)
+            e = engines[bits]
+            ex = Executor(Circuit.from_dict(case["circuit"]), e)
+            dl = e.delta_log(bits)
+            for r in case["runs"]:
+                got = e.decrypt(ex.run(e.encrypt(r["inputs"], dl)), dl)
+                assert list(got) == r["outputs"], case["function"]
+    finally:
+        for e in engines.values():
+            e.close()

@@ -515,3 +515,20 @@ print("ok")
 '''
     out = subprocess.run([sys.executable, "-c", code, repo], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_reference_own_fhe_tests_replayed_in_simulation():
+    """tests/golden/ref_own_fhe_tests.json.gz (tools/gen_ref_fhe_tests.py): the reference's own FHE test file
+    (tests/test_qfloat_fhe.py, unmodified, 7 tests: add/sub, mul, mul by SignedBinary, from_mul, neg, div, multi) was run
+    against the Compiler-compatible shim and passed its own assertions; the circuits it compiled and the inputs it ran are
+    kept as data.  Every kept circuit reproduces the recorded outputs, and its look-ups fit the parameter set it names."""
+    data = load_gz("ref_own_fhe_tests.json.gz")
+    assert data["unittest_summary"].startswith("Ran 7 tests") and data["unittest_summary"].endswith("OK")
+    names = {c["function"] for c in data["cases"]}
+    assert {"add_qfloats", "mul_qfloats", "mul_sb_qfloat", "from_mul_qfloats", "neg_qfloats", "div_qfloats", "multi_qfloats"} <= names
+    for case in data["cases"]:
+        c = Circuit.from_dict(case["circuit"])
+        assert c.msg_bits == case["msg_bits"] <= 5 and len(c.nodes) == case["pbs"]
+        assert all(p <= c.msg_bits + 1 for p, _ in c.luts)
+        for r in case["runs"]:
+            assert c.simulate(r["inputs"]) == r["outputs"], case["function"]

@@ -32,7 +32,16 @@ def _site(vals):
             r = _S["ranges"][k]
             r[0], r[1] = min(r[0], lo), max(r[1], hi)
         return None
-    return _S["ranges"][k]
+    lo, hi = _S["ranges"][k]
+    if _S.get("bitwidth"):
+        # Concrete derives a BIT WIDTH from the inputset, not an interval: an intermediate seen in [7, 17] is a 5-bit
+        # unsigned value and 5 or 31 are as good as 12.  Round the measured interval out to its bit width.
+        if lo >= 0:
+            lo, hi = 0, (1 << max(hi.bit_length(), 1)) - 1
+        else:
+            b = max((-lo - 1).bit_length(), hi.bit_length()) + 1
+            lo, hi = -(1 << (b - 1)), (1 << (b - 1)) - 1
+    return [lo, hi]
 
 
 class Def:
@@ -416,7 +425,7 @@ def univariate(f):
 
 
 # ------------------------------------------------------------------------------------------ the two-phase tracer
-def trace(fn, input_ranges, inputset, msg_bits=6, fuse=False):
+def trace(fn, input_ranges, inputset, msg_bits=6, fuse=False, bitwidth=False):
     """fn(*arrays) -> array/scalar/tuple of them; input_ranges: per argument a list of (lo, hi) per element;
     inputset: list of argument tuples (lists of ints).  Returns (circuit, n_outputs)."""
     import os
@@ -447,7 +456,7 @@ def trace(fn, input_ranges, inputset, msg_bits=6, fuse=False):
     n_sites = _S["site"]
     # 2. build
     c = Circuit(msg_bits=msg_bits)
-    _S.update(mode="build", site=0, circuit=c, fuse=bool(fuse))
+    _S.update(mode="build", site=0, circuit=c, fuse=bool(fuse), bitwidth=bool(bitwidth))
     args = []
     for rng in input_ranges:
         a = np.empty(len(rng), dtype=object)
@@ -457,5 +466,108 @@ def trace(fn, input_ranges, inputset, msg_bits=6, fuse=False):
     outs = flat(fn(*args))
     assert _S["site"] == n_sites, "the function is not data-oblivious: different operation sequence"
     c.set_outputs([_mat(Enc._raw(o)) for o in outs])
-    _S.update(mode=None, fuse=False)
+    _S.update(mode=None, fuse=False, bitwidth=False)
     return c, len(outs)
+
+
+# ------------------------------------------------------------------- the Compiler / Circuit surface of concrete.fhe
+# What the reference drives (main.py:53-86, qfloat_matrix_inversion.py:989-1053, tests/test_qfloat_fhe.py:136-175):
+# fhe.Compiler(fn, {"x": "encrypted", ...}).compile(inputset, configuration, verbose) -> a circuit with keygen /
+# encrypt / run / decrypt / simulate.  Here the circuit is this repo's IR; `run` evaluates it with the plaintext
+# simulator (this shim only exists where the reference does, i.e. off the GPU box) and, with ENCSHIM_RECORD=<file>,
+# every compiled circuit and every input it was run on are written out as data, for the GPU suite to replay on
+# ciphertexts (tests/golden/ref_own_fhe_tests.json.gz, tools/gen_ref_fhe_tests.py).
+class Configuration:
+    def __init__(self, **options):
+        self.options = options
+
+
+_RECORDED = []
+
+
+def _inner_name(fn):
+    """the name of the function a `lambda x, y: circuit_function(x, y, params)` wrapper closes over"""
+    for cell in (fn.__closure__ or ()):
+        try:
+            v = cell.cell_contents
+        except ValueError:
+            continue
+        if callable(v) and hasattr(v, "__name__") and v.__name__ != "<lambda>":
+            return v.__name__
+    return getattr(fn, "__name__", "circuit")
+
+
+class Circuit:
+    def __init__(self, fn, inputset, fuse=False):
+        samples = [[np.asarray(a) for a in one] for one in inputset]
+        self.shapes = [a.shape for a in samples[0]]
+        flat_set = [tuple([int(v) for v in a.reshape(-1)] for a in one) for one in samples]
+        ranges = []
+        for k in range(len(self.shapes)):
+            cols = np.array([one[k] for one in flat_set], dtype=np.int64)
+            lo, hi = cols.min(axis=0), cols.max(axis=0)
+            # like Concrete, the bit width of an input comes from the inputset; values in {-1, 0, 1} (digits of base 2,
+            # signs) always get the whole of it, so that a test input of the other sign is inside the claim
+            ranges.append([(min(int(a), -1 if int(a) < 0 or int(b) <= 1 and cols.min() < 0 else 0), max(int(b), 1)) for a, b in zip(lo, hi)])
+        self._out_shape = None
+
+        def flat_fn(*flat_args):
+            res = fn(*[EncArray(a._a.reshape(shape)) for a, shape in zip(flat_args, self.shapes)])
+            if isinstance(res, (np.ndarray, EncArray)):
+                self._out_shape = res.shape
+            return res
+        probe, _ = trace(flat_fn, ranges, flat_set, msg_bits=8, fuse=fuse, bitwidth=True)
+        bits = max([4] + [p for p, _ in probe.luts])
+        self.circuit, self.n_out = trace(flat_fn, ranges, flat_set, msg_bits=bits, fuse=fuse, bitwidth=True)
+        self.name = _inner_name(fn)
+        self.runs = []
+        if os.environ.get("ENCSHIM_RECORD"):
+            _RECORDED.append(self)
+
+    def keygen(self, *a, **k):
+        return None
+
+    def encrypt(self, *args):
+        return [int(v) for a in args for v in np.asarray(a).reshape(-1)]
+
+    def run(self, enc):
+        out = self.circuit.simulate(list(enc))
+        self.runs.append({"inputs": list(enc), "outputs": [int(v) for v in out]})
+        return out
+
+    def decrypt(self, res):
+        r = np.array(res, dtype=np.int64)
+        return r.reshape(self._out_shape) if self._out_shape is not None else r
+
+    def simulate(self, *args):
+        return self.decrypt(self.run(self.encrypt(*args)))
+
+    def encrypt_run_decrypt(self, *args):
+        return self.simulate(*args)
+
+
+class Compiler:
+    def __init__(self, function, parameter_encryption_statuses):
+        self.function, self.statuses = function, dict(parameter_encryption_statuses)
+
+    def compile(self, inputset, configuration=None, verbose=False, **_):
+        return Circuit(self.function, list(inputset))
+
+
+def _dump_recorded():
+    path = os.environ.get("ENCSHIM_RECORD")
+    if not path or not _RECORDED:
+        return
+    import gzip
+    import json
+    cases = [{"function": c.name, "msg_bits": c.circuit.msg_bits, "pbs": len(c.circuit.nodes), "depth": len(c.circuit.levels()),
+              "input_shapes": [list(s) for s in c.shapes], "output_shape": list(c._out_shape or ()),
+              "circuit": c.circuit.to_dict(), "runs": c.runs} for c in _RECORDED if c.runs]
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(json.dumps({"cases": cases}).encode())
+
+
+import atexit  # noqa: E402
+import os  # noqa: E402
+
+atexit.register(_dump_recorded)
