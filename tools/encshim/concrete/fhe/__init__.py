@@ -571,3 +571,11 @@ import atexit  # noqa: E402
 import os  # noqa: E402
 
 atexit.register(_dump_recorded)
+
+
+class PublicArguments(list):
+    """what circuit.encrypt returns (main.py:73-76 annotates with it)"""
+
+
+class PublicResult(list):
+    """what circuit.run returns (main.py:78-81)"""
