@@ -306,3 +306,47 @@ def test_reference_own_fhe_tests_replayed_on_ciphertexts():
     finally:
         for e in engines.values():
             e.close()
+
+
+def test_shim_compiler_surface_runs_on_the_gpu(monkeypatch):
+    """tools/encshim's `fhe.Compiler(...).compile(inputset)` circuit with ENCSHIM_BACKEND=gpu: encrypt / run / decrypt go
+    through the engine (LWE ciphertexts, every look-up a bootstrap on the GPU) - what a reference user gets by putting the
+    shim ahead of `concrete` on PYTHONPATH on an MI355X machine.  Exercised here with a small function written for this
+    test (binary addition with carries on encrypted digit arrays): the reference itself cannot travel to the GPU box."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "encshim"))
+    try:
+        from concrete import fhe
+        monkeypatch.setenv("ENCSHIM_BACKEND", "gpu")
+        D = 6
+
+        def add_digits(a, b):            # most significant digit first
+            s = a + b
+            out = fhe.zeros(D + 1)
+            carry = 0
+            for i in range(D - 1, -1, -1):
+                t = s[i] + carry
+                carry = t // 2
+                out[i + 1] = t % 2
+            out[0] = carry
+            return out
+
+        rng = np.random.default_rng(8)
+        inputset = [(rng.integers(0, 2, D), rng.integers(0, 2, D)) for _ in range(60)]
+        inputset += [(np.ones(D, dtype=np.int64), np.ones(D, dtype=np.int64)), (np.zeros(D, dtype=np.int64), np.zeros(D, dtype=np.int64))]
+        circuit = fhe.Compiler(lambda x, y: add_digits(x, y), {"x": "encrypted", "y": "encrypted"}).compile(inputset)
+        circuit.keygen()
+        for _ in range(5):
+            a, b = rng.integers(0, 2, D), rng.integers(0, 2, D)
+            enc = circuit.encrypt(a, b)
+            assert enc[0].shape == (2 * D, 1025)                       # ciphertexts, not integers
+            got = circuit.decrypt(circuit.run(enc))
+            want = int("".join(map(str, a)), 2) + int("".join(map(str, b)), 2)
+            assert int("".join(map(str, got)), 2) == want
+            assert list(got) == list(circuit.simulate(a, b))
+    finally:
+        from concrete import fhe as _f
+        for e in _f._ENGINES.values():
+            e.close()
+        _f._ENGINES.clear()
+        sys.path.pop(0)

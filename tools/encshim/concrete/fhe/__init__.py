@@ -483,6 +483,11 @@ class Configuration:
 
 
 _RECORDED = []
+_ENGINES = {}
+
+
+def _backend():
+    return os.environ.get("ENCSHIM_BACKEND", "simulate")
 
 
 def _inner_name(fn):
@@ -524,23 +529,60 @@ class Circuit:
         if os.environ.get("ENCSHIM_RECORD"):
             _RECORDED.append(self)
 
+    # ---- back ends.  ENCSHIM_BACKEND=gpu: encrypt / run / decrypt work on LWE ciphertexts through this repo's engine
+    # (bmi_amd.tfhe.Engine + executor: every look-up a programmable bootstrap on the MI355X; the parameter set follows
+    # the circuit's look-up width: 4 bits N = 1024, 5 bits N = 2048, 6 bits N = 4096).  Default: the plaintext simulator.
+    def _gpu(self):
+        if getattr(self, "_ex", None) is None:
+            from bmi_amd import tfhe
+            from bmi_amd.executor import Executor
+            bits = self.circuit.msg_bits
+            if bits not in _ENGINES:
+                if bits > 6:
+                    raise ValueError(f"a {bits}-bit look-up does not fit any parameter set of the engine (at most 6 bits)")
+                eng = tfhe.Engine(tfhe.default_params(q_bits=49, log_N={4: 10, 5: 11, 6: 12}[bits]))
+                eng.keygen(int(os.environ.get("ENCSHIM_KEY_SEED", "24301")))
+                _ENGINES[bits] = eng
+            self._eng = _ENGINES[bits]
+            self._ex = Executor(self.circuit, self._eng)
+            self._dl = self._eng.delta_log(bits)
+        return self._ex
+
     def keygen(self, *a, **k):
-        return None
+        if _backend() == "gpu":
+            self._gpu()
 
     def encrypt(self, *args):
-        return [int(v) for a in args for v in np.asarray(a).reshape(-1)]
+        flat = [int(v) for a in args for v in np.asarray(a).reshape(-1)]
+        if _backend() == "gpu":
+            self._gpu()
+            enc = PublicArguments([self._eng.encrypt(flat, self._dl)])
+            enc.plain = flat          # kept beside the ciphertexts only for ENCSHIM_RECORD
+            return enc
+        return PublicArguments(flat)
 
     def run(self, enc):
+        if _backend() == "gpu":
+            res = PublicResult([self._gpu().run(enc[0])])
+            res.plain_inputs = getattr(enc, "plain", None)
+            return res
         out = self.circuit.simulate(list(enc))
         self.runs.append({"inputs": list(enc), "outputs": [int(v) for v in out]})
-        return out
+        return PublicResult(out)
 
     def decrypt(self, res):
-        r = np.array(res, dtype=np.int64)
+        if _backend() == "gpu":
+            r = np.array(self._eng.decrypt(res[0], self._dl), dtype=np.int64)
+            if getattr(res, "plain_inputs", None) is not None:
+                self.runs.append({"inputs": res.plain_inputs, "outputs": [int(v) for v in r]})
+        else:
+            r = np.array(list(res), dtype=np.int64)
         return r.reshape(self._out_shape) if self._out_shape is not None else r
 
     def simulate(self, *args):
-        return self.decrypt(self.run(self.encrypt(*args)))
+        flat = [int(v) for a in args for v in np.asarray(a).reshape(-1)]
+        r = np.array(self.circuit.simulate(flat), dtype=np.int64)
+        return r.reshape(self._out_shape) if self._out_shape is not None else r
 
     def encrypt_run_decrypt(self, *args):
         return self.simulate(*args)
