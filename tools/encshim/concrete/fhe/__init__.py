@@ -513,7 +513,8 @@ class Circuit:
             lo, hi = cols.min(axis=0), cols.max(axis=0)
             # like Concrete, the bit width of an input comes from the inputset; values in {-1, 0, 1} (digits of base 2,
             # signs) always get the whole of it, so that a test input of the other sign is inside the claim
-            ranges.append([(min(int(a), -1 if int(a) < 0 or int(b) <= 1 and cols.min() < 0 else 0), max(int(b), 1)) for a, b in zip(lo, hi)])
+            sign_like = cols.min() < 0 and cols.max() <= 1 and cols.min() >= -1
+            ranges.append([(-1, 1) if sign_like else (min(int(a), 0), max(int(b), 1)) for a, b in zip(lo, hi)])
         self._out_shape = None
 
         def flat_fn(*flat_args):
