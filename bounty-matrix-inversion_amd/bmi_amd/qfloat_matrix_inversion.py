@@ -12,47 +12,49 @@ from .qfloat import QFloat, SignedBinary, Zero, _circ
 
 
 # ------------------------------------------------------------------------------------------- utils
-def matrix_column(M, j):
-    return [row[j] for row in M]
-
-
+# 2-D "list matrices" (lists of rows) of QFloat / SignedBinary / Zero entries, as in the reference (:145-219).
 def transpose_2D_list(list2D):
-    return [list(row) for row in zip(*list2D)]
+    width = len(list2D[0]) if list2D else 0
+    return [[row[j] for row in list2D] for j in range(width)]
+
+
+def matrix_column(M, j):
+    return transpose_2D_list(M)[j]
 
 
 def map_2D_list(list2D, function):
-    return [[function(f) for f in row] for row in list2D]
+    return [list(map(function, row)) for row in list2D]
 
 
 def binary_list_matrix(M):
-    """reference :166-173 — M is an n x n list of 0/1 scalars (ints or encrypted)"""
-    return [[SignedBinary(x) for x in row] for row in M]
+    """n x n 0/1 scalars (ints or encrypted) -> SignedBinary entries"""
+    return map_2D_list([list(row) for row in M], SignedBinary)
 
 
 def zero_list_matrix(n):
-    return [[Zero() for _ in range(n)] for _ in range(n)]
+    return [[Zero()] * n for _ in range(n)]   # Zero is immutable: sharing one object per row is safe
+
+
+def _accumulate(terms):
+    """left-to-right in-place sum t0 += t1 += ... (the accumulation order fixes the digits: `+=` truncates)"""
+    total = terms[0]
+    for t in terms[1:]:
+        total += t
+    return total
 
 
 def qfloat_list_dot_product(list1, list2, tensorize=False):
-    """reference :183-200."""
+    """sum_k list1[k] * list2[k], products formed one by one or (tensorize) by QFloat.multi_from_mul."""
     if len(list1) != len(list2):
         raise ValueError("Lists should have the same length.")
     if tensorize:
-        multiplications = QFloat.multi_from_mul(list1, list2, None, None)
-        result = multiplications[0]
-        for m in multiplications[1:]:
-            result += m
-        return result
-    result = list1[0] * list2[0]
-    for i in range(1, len(list1)):
-        result += list1[i] * list2[i]
-    return result
+        return _accumulate(QFloat.multi_from_mul(list1, list2, None, None))
+    return _accumulate([x * y for x, y in zip(list1, list2)])
 
 
 def qfloat_list_matrix_multiply(matrix1, matrix2):
-    """reference :203-219."""
-    return [[qfloat_list_dot_product(matrix1[i], matrix_column(matrix2, j)) for j in range(len(matrix2[0]))]
-            for i in range(len(matrix1))]
+    columns = transpose_2D_list(matrix2)
+    return [[qfloat_list_dot_product(row, col) for col in columns] for row in matrix1]
 
 
 # ------------------------------------------------------------------------------------- marshalling
@@ -152,95 +154,165 @@ def qfloat_pivot_matrix(M):
 
 
 # --------------------------------------------------------------------------------- LU decomposition
+class _Quotient:
+    """`numerator / pivot` for one pivot, in the mode the caller asked for: a true division per quotient, or ONE
+    reciprocal of the pivot into the pure-fraction format (len, 0) shared by every quotient of that pivot (the
+    reference's faster, less precise default: qfloat_matrix_inversion.py:421-425, 490-495)."""
+
+    def __init__(self, pivot, qfloat_len, qfloat_ints, true_division, reciprocal=None):
+        self.pivot, self.fmt, self.true_division = pivot, (qfloat_len, qfloat_ints), true_division
+        self.reciprocal = reciprocal
+        if not true_division and reciprocal is None:
+            self.reciprocal = pivot.invert(1, qfloat_len, 0)
+
+    def __call__(self, numerator):
+        if self.true_division:
+            return numerator / self.pivot
+        return QFloat.from_mul(numerator, self.reciprocal, *self.fmt)
+
+
+def _minus_dot(head, left, right, tensorize):
+    """head - <left, right> as the reference forms it inside the factorisation: head + (-dot)   (:412-417, 428-438)"""
+    return head + qfloat_list_dot_product(left, right, tensorize).neg()
+
+
 def qfloat_lu_decomposition(M, qfloat_len, qfloat_ints, true_division=False, tensorize=False):
-    """reference :377-453 — Doolittle LU of P*M; returns P (transposed), L, U."""
-    assert len(M) == len(M[0])
+    """Doolittle factorisation of the row-permuted matrix, P M = L U (L unit lower triangular), column by column:
+    the entries of U above and on the diagonal depend on each other top-down; the entries of L below the diagonal
+    are mutually independent and share the pivot's reciprocal.  Returns (P transposed, L, U) like the reference
+    (:377-453), so that M = P L U."""
     n = len(M)
-    L = zero_list_matrix(n)
-    U = zero_list_matrix(n)
-    P = binary_list_matrix(qfloat_pivot_matrix(M))
-    PM = qfloat_list_matrix_multiply(P, M)
-    for j in range(n):
-        L[j][j] = SignedBinary(1)
-        for i in range(j + 1):
-            if i > 0:
-                s1 = qfloat_list_dot_product([U[k][j] for k in range(i)], [L[i][k] for k in range(i)], tensorize)
-                U[i][j] = PM[i][j] + s1.neg()
-            else:
-                U[i][j] = PM[i][j].copy()
-        if not true_division:
-            inv_Ujj = U[j][j].invert(1, qfloat_len, 0)
-        for i in range(j + 1, n):
-            if j > 0:
-                s2 = qfloat_list_dot_product([U[k][j] for k in range(j)], [L[i][k] for k in range(j)], tensorize)
-                num = PM[i][j] + s2.neg()
-            else:
-                num = PM[i][j]
-            L[i][j] = (num / U[j][j]) if true_division else QFloat.from_mul(num, inv_Ujj, qfloat_len, qfloat_ints)
-    return transpose_2D_list(P), L, U
+    assert all(len(row) == n for row in M)
+    perm = binary_list_matrix(qfloat_pivot_matrix(M))
+    A = qfloat_list_matrix_multiply(perm, M)
+    lower, upper = zero_list_matrix(n), zero_list_matrix(n)
+    for col in range(n):
+        lower[col][col] = SignedBinary(1)
+        upper[0][col] = A[0][col].copy()
+        for row in range(1, col + 1):
+            upper[row][col] = _minus_dot(A[row][col], [upper[k][col] for k in range(row)], lower[row][:row], tensorize)
+        if col == n - 1:
+            if not true_division:      # the reference takes this reciprocal too (its last one is unused)
+                upper[col][col].invert(1, qfloat_len, 0)
+            break
+        over_pivot = _Quotient(upper[col][col], qfloat_len, qfloat_ints, true_division)
+        for row in range(col + 1, n):
+            rest = A[row][col] if col == 0 else \
+                _minus_dot(A[row][col], [upper[k][col] for k in range(col)], lower[row][:col], tensorize)
+            lower[row][col] = over_pivot(rest)
+    return transpose_2D_list(perm), lower, upper
+
+
+# --------------------------------------------------------------------------------------- LU inverse
+def _forward_row(rhs, lower, tensorize):
+    """one right-hand side of L y = rhs (unit diagonal: no division)   (reference :476-485)"""
+    y = [rhs[0].copy()]
+    for j in range(1, len(rhs)):
+        y.append(rhs[j] - qfloat_list_dot_product(lower[j][:j], y[:j], tensorize))
+    return y
+
+
+def _backward_row(y, upper, over_pivot, tensorize):
+    """one right-hand side of U x = y, last unknown first   (reference :496-513)"""
+    n = len(y)
+    x = [None] * n
+    x[n - 1] = over_pivot[n - 1](y[n - 1])
+    for j in range(n - 2, -1, -1):
+        x[j] = over_pivot[j](y[j] - qfloat_list_dot_product(upper[j][j + 1:], x[j + 1:], tensorize))
+    return x
 
 
 def qfloat_lu_inverse(P, L, U, qfloat_len, qfloat_ints, true_division=False, tensorize=False, debug=False):
-    """reference :461-518 — forward and back substitution."""
+    """M^-1 from M = P L U: for every row of P as right-hand side, a forward solve against L then a backward solve
+    against U; the n right-hand sides are independent of each other, so the scheduler sees them as one n-wide batch.
+    The diagonal of U is inverted once (all n reciprocals are independent) unless true_division is set."""
     n = len(L)
-    Y = zero_list_matrix(n)
-    for i in range(n):
-        Y[i][0] = P[i][0].copy()
-        for j in range(1, n):
-            Y[i][j] = P[i][j] - qfloat_list_dot_product([L[j][k] for k in range(j)], [Y[i][k] for k in range(j)],
-                                                        tensorize)
-    X = zero_list_matrix(n)
-    if not true_division:
-        if tensorize:
-            Ujj_inv = QFloat.multi_invert([U[j][j] for j in range(n)], 1, qfloat_len, 0)
-        else:
-            Ujj_inv = [U[j][j].invert(1, qfloat_len, 0) for j in range(n)]
-    for i in range(n - 1, -1, -1):
-        X[i][-1] = (Y[i][-1] / U[-1][-1]) if true_division else QFloat.from_mul(Y[i][-1], Ujj_inv[-1], qfloat_len,
-                                                                              qfloat_ints)
-        for j in range(n - 2, -1, -1):
-            temp = Y[i][j] - qfloat_list_dot_product([U[j][k] for k in range(j + 1, n)],
-                                                     [X[i][k] for k in range(j + 1, n)], tensorize)
-            X[i][j] = (temp / U[j][j]) if true_division else QFloat.from_mul(temp, Ujj_inv[j], qfloat_len, qfloat_ints)
-    if not debug:
-        return transpose_2D_list(X)
-    return transpose_2D_list(X), Y, X
+    Y = [_forward_row(P[i], L, tensorize) for i in range(n)]
+    if true_division:
+        recips = [None] * n
+    elif tensorize:
+        recips = QFloat.multi_invert([U[j][j] for j in range(n)], 1, qfloat_len, 0)
+    else:
+        recips = [U[j][j].invert(1, qfloat_len, 0) for j in range(n)]
+    over_pivot = [_Quotient(U[j][j], qfloat_len, qfloat_ints, true_division, recips[j]) for j in range(n)]
+    X = [None] * n
+    for i in reversed(range(n)):
+        X[i] = _backward_row(Y[i], U, over_pivot, tensorize)
+    inverse = transpose_2D_list(X)
+    return (inverse, Y, X) if debug else inverse
+
+
+# ------------------------------------------------------------------------------- 2x2 closed formula
+def _adjugate_over_det(entries, det_recip, qfloat_len, qfloat_ints, tensorize):
+    """[[d, -b], [-c, a]] * (1 / det) in the output format"""
+    a, b, c, d = entries
+    if tensorize:
+        pa, pb, pc, pd = QFloat.multi_from_mul([a, b, c, d], [det_recip] * 4, qfloat_len, qfloat_ints)
+    else:
+        pd, pb, pc, pa = (QFloat.from_mul(e, det_recip, qfloat_len, qfloat_ints) for e in (d, b, c, a))
+    return [[pd, pb.neg()], [pc.neg(), pa]]
+
+
+def _inverse_2x2(qfloat_M, qfloat_len, qfloat_ints, tensorize):
+    """adj(M) / det(M).  The determinant is formed in the wider format (2 ints + 3 digits, 2 ints of them integer)
+    so that a d - b c cannot overflow, then inverted into a pure fraction of `len` digits (reference :526-584)."""
+    (a, b), (c, d) = qfloat_M
+    wide = (2 * qfloat_ints + 3, 2 * qfloat_ints)
+    if tensorize:
+        ad, bc = QFloat.multi_from_mul([a, b], [d, c], *wide)
+    else:
+        ad, bc = QFloat.from_mul(a, d, *wide), QFloat.from_mul(b, c, *wide)
+    det = ad + bc.neg()
+    return _adjugate_over_det((a, b, c, d), det.invert(1, qfloat_len, 0), qfloat_len, qfloat_ints, tensorize)
 
 
 def qfloat_inverse_2x2(qfloat_M, qfloat_len, qfloat_ints):
-    """reference :526-555 — adj(M) / det(M), det in format (2*ints+3, 2*ints)."""
-    [a, b] = qfloat_M[0]
-    [c, d] = qfloat_M[1]
-    ad = QFloat.from_mul(a, d, 2 * qfloat_ints + 3, 2 * qfloat_ints)
-    bc = QFloat.from_mul(b, c, 2 * qfloat_ints + 3, 2 * qfloat_ints)
-    det = ad + bc.neg()
-    det_inv = det.invert(1, qfloat_len, 0)
-    mul = lambda x, y: QFloat.from_mul(x, y, qfloat_len, qfloat_ints)  # noqa: E731
-    return [[mul(d, det_inv), mul(b, det_inv).neg()], [mul(c, det_inv).neg(), mul(a, det_inv)]]
+    return _inverse_2x2(qfloat_M, qfloat_len, qfloat_ints, tensorize=False)
 
 
 def qfloat_inverse_2x2_multi(qfloat_M, qfloat_len, qfloat_ints):
-    """reference :558-584."""
-    [a, b] = qfloat_M[0]
-    [c, d] = qfloat_M[1]
-    [ad, bc] = QFloat.multi_from_mul([a, b], [d, c], 2 * qfloat_ints + 3, 2 * qfloat_ints)
-    det = ad + bc.neg()
-    det_inv = det.invert(1, qfloat_len, 0)
-    [mula, mulb, mulc, muld] = QFloat.multi_from_mul([a, b, c, d], [det_inv] * 4, qfloat_len, qfloat_ints)
-    return [[muld, mulb.neg()], [mulc.neg(), mula]]
+    return _inverse_2x2(qfloat_M, qfloat_len, qfloat_ints, tensorize=True)
+
+
+# --------------------------------------------------------------------------------- circuit bodies
+def _matrix_from_args(qfloat_arrays, qfloat_signs, n, qfloat_len, qfloat_ints, qfloat_base):
+    if len(qfloat_arrays) != n * n or len(qfloat_arrays[0]) != qfloat_len:
+        raise AssertionError("expected an (n^2, len) digit array")
+    return qfloat_arrays_to_qfloat_matrix(qfloat_arrays, qfloat_signs, qfloat_ints, qfloat_base)
+
+
+def qfloat_pivot(qfloat_arrays, qfloat_signs, params):
+    """partial circuit: the pivot matrix only (reference :592-609); params = [n, len, ints, base, ...]"""
+    n, qfloat_len, qfloat_ints, qfloat_base = params[:4]
+    return qfloat_pivot_matrix(_matrix_from_args(qfloat_arrays, qfloat_signs, n, qfloat_len, qfloat_ints, qfloat_base))
+
+
+def _lu_factor(qfloat_arrays, qfloat_signs, params, which):
+    n, qfloat_len, qfloat_ints, qfloat_base, true_division = params[:5]
+    M = _matrix_from_args(qfloat_arrays, qfloat_signs, n, qfloat_len, qfloat_ints, qfloat_base)
+    factors = qfloat_lu_decomposition(M, qfloat_len, qfloat_ints, true_division)
+    return qfloat_matrix_to_arrays_and_signs(factors[which], qfloat_len, qfloat_ints, qfloat_base)
+
+
+def qfloat_lu_L(qfloat_arrays, qfloat_signs, params):
+    """partial circuit: L of P M = L U (reference :612-639)"""
+    return _lu_factor(qfloat_arrays, qfloat_signs, params, 1)
+
+
+def qfloat_lu_U(qfloat_arrays, qfloat_signs, params):
+    """partial circuit: U of P M = L U (reference :642-669)"""
+    return _lu_factor(qfloat_arrays, qfloat_signs, params, 2)
 
 
 def qfloat_matrix_inverse(qfloat_arrays, qfloat_signs, n, qfloat_len, qfloat_ints, qfloat_base, true_division,
                           tensorize=False):
-    """reference :672-720 — the circuit body.  Input: (n^2, len) digits (>= 0, MSD first) and (n^2,) signs;
-    output: (n^2) x (len + 1) scalars, sign in the last column."""
-    assert n * n == len(qfloat_arrays)
-    assert qfloat_len == len(qfloat_arrays[0])
-    qfloat_M = qfloat_arrays_to_qfloat_matrix(qfloat_arrays, qfloat_signs, qfloat_ints, qfloat_base)
+    """The circuit body (reference :672-720).  Input: (n^2, len) digits (>= 0, most significant first) and (n^2,)
+    signs; output: (n^2) x (len + 1) scalars, sign in the last column.  n = 2 takes the closed formula, larger
+    matrices the pivoted LU factorisation and n pairs of triangular solves."""
+    M = _matrix_from_args(qfloat_arrays, qfloat_signs, n, qfloat_len, qfloat_ints, qfloat_base)
     if n == 2:
-        Minv = qfloat_inverse_2x2_multi(qfloat_M, qfloat_len, qfloat_ints) if tensorize \
-            else qfloat_inverse_2x2(qfloat_M, qfloat_len, qfloat_ints)
+        inverse = _inverse_2x2(M, qfloat_len, qfloat_ints, tensorize)
     else:
-        P, L, U = qfloat_lu_decomposition(qfloat_M, qfloat_len, qfloat_ints, true_division, tensorize)
-        Minv = qfloat_lu_inverse(P, L, U, qfloat_len, qfloat_ints, true_division, tensorize)
-    return qfloat_matrix_to_arrays_and_signs(Minv, qfloat_len, qfloat_ints, qfloat_base)
+        factors = qfloat_lu_decomposition(M, qfloat_len, qfloat_ints, true_division, tensorize)
+        inverse = qfloat_lu_inverse(*factors, qfloat_len, qfloat_ints, true_division, tensorize)
+    return qfloat_matrix_to_arrays_and_signs(inverse, qfloat_len, qfloat_ints, qfloat_base)
