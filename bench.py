@@ -12,6 +12,10 @@ parameter set (n=630, N=1024, k=1, l=3).  The batch shards over GPUs with no dat
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started without a launcher (`WORLD_SIZE` unset) and with --gpus N > 1, it starts the N ranks itself (a
+torch.distributed.run child process, one rank per GPU, before this process touches a GPU) and exits with the child's
+code; it never prints a line for fewer GPUs than were asked for.
+
 Rank 0 prints ONE JSON line.  `roofline` follows the north star's definition (bootstrap-key bytes per PBS,
 no-reuse convention, against peak HBM bandwidth) for the dominant kernel (blind rotation), whose launch
 duration is measured live with events on the launch stream; `alu` adds the integer-ALU view the path is
@@ -36,6 +40,50 @@ MODMUL_PER_PBS = 33_546_240                # SURVEY.md §8d (radix-2 count, the 
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n_gpus, argv):
+    """--gpus N > 1 without a launcher: run the same command under torch.distributed.run with N ranks (child process;
+    this parent has made no GPU call).  Returns the child's exit code; a failed start is an error, never an N = 1 line."""
+    import subprocess
+    import torch
+    share = os.environ.get("BMI_BENCH_SHARE_DEVICE") == "1" or os.environ.get("BMI_BENCH_REHEARSE") == "plumbing"
+    have = torch.cuda.device_count()      # counts devices without initialising the GPU
+    if not share and have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} requested but {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def rehearse_plumbing(args, rank, world):
+    """BMI_BENCH_REHEARSE=plumbing (tests only, never the driver): the rank start-up, rendezvous, barrier and MAX-over-ranks
+    timing of an N-rank run on a box without GPUs (gloo).  No PBS is executed and the line says so: value is null."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
+    assert dist.get_world_size() == world == args.gpus
+    dist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "PBS/sec per GPU + encrypted n x n inverse wall-clock (n=2,3,4)", "value": None,
+                          "unit": "PBS/s", "n_gpus": world, "world_size_seen": dist.get_world_size(), "steps": args.steps,
+                          "warmup": args.warmup, "rehearsal": "plumbing only: no PBS executed, nothing measured",
+                          "max_over_ranks_check": float(t.item())}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,15 +106,22 @@ def main():
                          "ranks (executor.py; one RCCL all-gather per split level)")
     ap.add_argument("--shard-threshold", type=int, default=1024, help="narrowest level that is split across ranks")
     args = ap.parse_args()
-
-    import torch
-    from bmi_amd import tfhe
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for another GPU count")
+    if os.environ.get("BMI_BENCH_REHEARSE") == "plumbing":
+        return rehearse_plumbing(args, rank, world)
+
+    import torch
+    from bmi_amd import tfhe
+
     dist = None
     # Rehearsal knobs (not used by the driver): BMI_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 and
     # BMI_BENCH_BACKEND=gloo replaces RCCL, so that the N > 1 code path can be exercised on a one-GPU box.
@@ -153,7 +208,8 @@ def main():
             traffic = valu_busy = None
     res = {
         "metric": "PBS/sec per GPU + encrypted n x n inverse wall-clock (n=2,3,4)", "value": value, "unit": "PBS/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "world_size_seen": (dist.get_world_size() if dist is not None else 1),
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": ("u64" if eng.q_bits == 64 else "f64"), "data": "synthetic",
         "config": {"workload": f"pbs_batch: B={B} LWE ciphertexts per GPU per step, TFHE n=630 N=1024 k=1 l=3 "

@@ -1,38 +1,92 @@
-"""GPU executor: runs a traced `circuit.Circuit` level by level through the C ABI.
+"""GPU executor: runs a compiled `program.Program` level by level through the C ABI.
 
-Per ASAP level:  bmi_lincomb_batch (forms every PBS input of the level from the device-resident leaf store)
-followed by bmi_pbs_batch (keyswitch -> blind rotation -> extraction) writing the level's outputs straight
-into the store.  All index arrays are built once (at `compile`, the analogue of the reference's
-`compiler.compile`, main.py:66) and stay on the device; a run is ~2 launches per level on one stream with
-no host synchronisation until the outputs are read back.  PyTorch is used only as the device allocator.
+Per level:  bmi_lincomb_batch (forms the level's PBS inputs from the device-resident leaf store) ->
+bmi_pbs_batch (keyswitch -> blind rotation -> extraction, into a contiguous level buffer) -> bmi_scatter_rows (level
+buffer -> the store rows assigned to the outputs).  All index arrays are built once, vectorised, from the program's CSR
+arrays and stay on the device; a run is 3 launches per level plus the keyswitch's on one stream, with no host
+synchronisation until the outputs are read back.  PyTorch is used only as the device allocator.
 
-Several GPUs: every rank holds the keys (seeded keygen) and the whole leaf store and walks the
-same level list.  A level at least `shard_threshold` wide is split into contiguous row ranges (shard.shard_range
-on a padded width): each rank bootstraps its range in place and one all-gather (RCCL, in place on the level's
-store region) completes the region everywhere; this is the path's only exchange step.  Narrower levels are
-computed redundantly by every rank - cheaper than any transfer, since a level below ~256 ciphertexts costs one
-latency-kernel round whatever its width.
+Store rows are recycled: a leaf's row returns to the free list at the level of its last consumer (liveness is known
+at compile time), so the store holds the live set, not every look-up ever made (8x8 inverse: 2.6 M look-ups, a few
+hundred thousand rows).
+
+Several GPUs: every rank holds the keys (seeded keygen) and the whole store and walks the same level
+list.  A level at least `shard_threshold` wide is split into contiguous row ranges (shard.shard_range on a padded
+width): each rank forms and bootstraps ITS rows only, one all-gather (RCCL) on the level buffer completes it
+everywhere, then every rank scatters the whole level into its store; this is the path's only exchange step.  Narrower
+levels are computed redundantly by every rank - cheaper than any transfer, since a level below ~256 ciphertexts
+costs one latency-kernel round whatever its width.
 """
 from __future__ import annotations
 
 import numpy as np
 
-from .circuit import MSG_BITS
+from .circuit import Circuit
+from .program import Program
 
 
 def _torus(v, delta_log, q):
-    """signed integer -> v * 2^delta_log mod q, as an int64 bit pattern"""
-    t = (int(v) << delta_log) % q
-    return t - (1 << 64) if t >= (1 << 63) else t
+    """signed integers -> v * 2^delta_log mod q, as int64 bit patterns"""
+    out = np.empty(len(v), np.int64)
+    for i, x in enumerate(v):
+        t = (int(x) << delta_log) % q
+        out[i] = t - (1 << 64) if t >= (1 << 63) else t
+    return out
+
+
+def assign_rows(prog: Program, recycle=True):
+    """Store row of every leaf (inputs first).  With recycling, the rows of leaves whose last consumer is level t are
+    handed to the outputs of level t (the level's inputs are copied out by its lincomb before its PBS writes).
+    Returns (row per leaf, number of rows)."""
+    n_in, nn = prog.n_inputs, prog.n_nodes
+    n_leaves = n_in + nn
+    row = np.empty(n_leaves, np.int64)
+    row[:n_in] = np.arange(n_in)
+    order, counts = prog.level_order()
+    if not recycle:
+        row[n_in + order] = n_in + np.arange(nn)
+        return row, n_leaves
+    depth = prog.depth
+    # last level that reads each leaf: terms visited in level order, so the last write per leaf is the latest level
+    lens = np.diff(prog.node_ptr)
+    term_level = np.repeat(prog.node_level, lens)
+    by_level = np.argsort(term_level, kind="stable")
+    last_use = np.zeros(n_leaves, np.int64)
+    last_use[prog.term_leaf[by_level]] = term_level[by_level]
+    last_use[prog.out_leaf] = depth + 1          # outputs stay until the end
+    dying = np.argsort(last_use, kind="stable")  # leaves grouped by the level that frees them
+    dead_counts = np.bincount(last_use, minlength=depth + 2)
+    dead_start = np.concatenate([[0], np.cumsum(dead_counts)])
+    free = np.empty(n_leaves, np.int64)
+    nfree, top, pos = 0, n_in, 0
+    for t in range(1, depth + 1):
+        d = dying[dead_start[t]: dead_start[t + 1]]
+        if d.size:
+            free[nfree: nfree + d.size] = row[d]
+            nfree += d.size
+        k = int(counts[t - 1])
+        take = min(k, nfree)
+        nodes = order[pos: pos + k]
+        pos += k
+        if take:
+            row[n_in + nodes[:take]] = free[nfree - take: nfree]
+            nfree -= take
+        if k > take:
+            row[n_in + nodes[take:]] = top + np.arange(k - take)
+            top += k - take
+    return row, top
 
 
 class Executor:
-    def __init__(self, circuit, engine, group=None, shard_threshold=1024):
-        """group: a torch.distributed process group (None: the default group when initialised with more than one
-        rank, otherwise single-GPU execution); shard_threshold: narrowest level that is split across the ranks."""
+    def __init__(self, circuit, engine, group=None, shard_threshold=1024, recycle=True):
+        """circuit: a program.Program (or a circuit.Circuit, frozen here); group: a torch.distributed process group (None:
+        the default group when initialised with more than one rank, otherwise single-GPU execution); shard_threshold:
+        narrowest level that is split across the ranks; recycle: reuse store rows after a leaf's last consumer."""
         import torch
         self.torch = torch
-        self.c, self.eng = circuit, engine
+        prog = Program.from_circuit(circuit) if isinstance(circuit, Circuit) else circuit
+        self.c = self.prog = prog
+        self.eng = engine
         self.dev = engine.torch_device() if hasattr(engine, "torch_device") else torch.device("cuda", engine.device)
         self.on_gpu = self.dev.type == "cuda"
         self.dist, self.group, self.rank, self.world = None, group, 0, 1
@@ -40,84 +94,83 @@ class Executor:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             self.dist, self.rank, self.world = dist, dist.get_rank(group), dist.get_world_size(group)
         self.shard_threshold = max(int(shard_threshold), 1)
-        P = engine.P
-        self.big = P.big
-        levels = circuit.levels()
-        n_in = circuit.n_inputs
-        # renumber leaves so that every level's outputs are contiguous rows of the store; a sharded level's region
-        # is padded to a multiple of the world size so that the in-place all-gather has equal parts
-        new_id = {i: i for i in range(n_in)}
-        nxt = n_in
-        self.level_rows = []
-        for lv in levels:
-            for j, ni in enumerate(lv):
-                new_id[circuit.nodes[ni][3]] = nxt + j
-            rows = len(lv)
-            if self.world > 1 and rows >= self.shard_threshold:
-                rows = -(-rows // self.world) * self.world
-            self.level_rows.append(rows)
-            nxt += rows
-        self.n_leaves = nxt
-        self.delta_log = engine.delta_log(getattr(circuit, "msg_bits", MSG_BITS))
+        self.big = engine.P.big
+        n_in = prog.n_inputs
+        order, counts = prog.level_order()
+        self.row_of, self.n_rows = assign_rows(prog, recycle)
+        self.delta_log = engine.delta_log(prog.msg_bits)
         q, dl = engine.modulus, self.delta_log
-        lut_ids = [engine.lut_register(np.array(tab, dtype=np.int64), p, dl) for p, tab in circuit.luts]
+        lut_ids = np.asarray([engine.lut_register(prog.lut_tab[j, : 1 << int(prog.lut_p[j])].astype(np.int64),
+                                                  int(prog.lut_p[j]), dl) for j in range(prog.lut_p.size)], np.int32)
+        to_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.dev)  # noqa: E731
 
-        def csr(rows):
-            rp, ix, cf, cs = [0], [], [], []
-            for terms, const in rows:
-                for leaf, coef in terms:
-                    ix.append(new_id[leaf])
-                    cf.append(coef)
-                rp.append(len(ix))
-                cs.append(_torus(const, dl, q))
-            t = lambda a, dt: torch.from_numpy(np.asarray(a, dtype=dt)).to(self.dev)  # noqa: E731
-            return (t(rp, np.int32), t(ix if ix else [0], np.int32), t(cf if cf else [0], np.int64), t(cs, np.int64))
-
-        self.levels = []
-        base = n_in
-        for lv, padded in zip(levels, self.level_rows):
-            rows = [(circuit.nodes[ni][0], circuit.nodes[ni][1]) for ni in lv]
-            ids = torch.from_numpy(np.asarray([lut_ids[circuit.nodes[ni][2]] for ni in lv], dtype=np.int32)).to(self.dev)
-            self.levels.append((len(lv), base, csr(rows), ids, padded))
-            base += padded
-        self.out_csr = csr(circuit.outputs)
-        self.n_out = len(circuit.outputs)
-        self.max_width = max((w for w, *_ in self.levels), default=1)
-        self.sharded_levels = sum(1 for w, _, _, _, padded in self.levels if self.world > 1 and w >= self.shard_threshold)
-        self.store = torch.zeros((self.n_leaves, self.big), dtype=torch.int64, device=self.dev)
+        # every level's rows in level order: one set of flat arrays for the whole program, sliced per level
+        lens = np.diff(prog.node_ptr)[order]
+        starts = prog.node_ptr[:-1][order]
+        tot = int(lens.sum())
+        off = np.arange(tot) - np.repeat(np.cumsum(lens) - lens, lens) + np.repeat(starts, lens)
+        self.d_idx = to_dev(self.row_of[prog.term_leaf[off]] if tot else [0], np.int32)
+        self.d_coef = to_dev(prog.term_coef[off] if tot else [0], np.int64)
+        consts = prog.node_const[order]
+        uniq, inv = np.unique(consts, return_inverse=True)
+        self.d_const = to_dev(_torus(uniq, dl, q)[inv] if consts.size else [0], np.int64)
+        self.d_ids = to_dev(lut_ids[prog.node_lut[order]] if order.size else [0], np.int32)
+        self.d_rows = to_dev(self.row_of[n_in + order] if order.size else [0], np.int32)
+        # row_ptr of all nodes in level order, absolute term offsets: a level (or a rank's part of it) is a slice
+        self.d_rp = to_dev(np.concatenate([[0], np.cumsum(lens)]), np.int32)
+        self.levels = []          # (width, position of the level's first node, padded width)
+        pos = 0
+        for w in counts.tolist():
+            padded = -(-w // self.world) * self.world if (self.world > 1 and w >= self.shard_threshold) else w
+            self.levels.append((w, pos, padded))
+            pos += w
+        self.out_csr = (to_dev(prog.out_ptr, np.int32), to_dev(self.row_of[prog.out_leaf] if prog.out_leaf.size else [0], np.int32),
+                        to_dev(prog.out_coef if prog.out_coef.size else [0], np.int64),
+                        to_dev(_torus(prog.out_const, dl, q), np.int64))
+        self.n_out = prog.n_outputs
+        self.max_width = max((p for *_, p in self.levels), default=1)
+        self.sharded_levels = sum(1 for w, *_ in self.levels if self.world > 1 and w >= self.shard_threshold)
+        self.store = torch.zeros((max(self.n_rows, 1), self.big), dtype=torch.int64, device=self.dev)
         self.tmp = torch.zeros((max(self.max_width, 1), self.big), dtype=torch.int64, device=self.dev)
+        self.lvl = torch.zeros((max(self.max_width, 1), self.big), dtype=torch.int64, device=self.dev)
         self.out = torch.zeros((max(self.n_out, 1), self.big), dtype=torch.int64, device=self.dev)
         engine.reserve(self.max_width)
+
+    def store_bytes(self):
+        return int(self.store.numel() + self.tmp.numel() + self.lvl.numel()) * 8
 
     def run(self, ct_inputs):
         """ct_inputs: (n_inputs, k*N+1) uint64 ciphertexts (host) -> (n_outputs, k*N+1) uint64 (host)"""
         torch = self.torch
-        ct = np.ascontiguousarray(ct_inputs, dtype=np.uint64).reshape(self.c.n_inputs, self.big)
+        n_in = self.prog.n_inputs
+        ct = np.ascontiguousarray(ct_inputs, dtype=np.uint64).reshape(n_in, self.big)
         import contextlib
         with (torch.cuda.device(self.dev) if self.on_gpu else contextlib.nullcontext()):
             stream = torch.cuda.current_stream().cuda_stream if self.on_gpu else 0
-            self.store[: self.c.n_inputs].copy_(torch.from_numpy(ct.view(np.int64)), non_blocking=False)
-            from .shard import shard_range
-            for width, base, (rp, ix, cf, cs), ids, padded in self.levels:
-                # every rank forms all of the level's PBS inputs (a few hundred bytes of index data per row)
-                self.eng.lincomb(self.store, rp, ix, cf, cs, width, self.tmp, stream)
-                if self.world > 1 and width >= self.shard_threshold:
+            self.store[:n_in].copy_(torch.from_numpy(ct.view(np.int64)), non_blocking=False)
+            eng, tmp, lvl = self.eng, self.tmp, self.lvl
+            for width, pos, padded in self.levels:
+                lo, hi = 0, width
+                sharded = self.world > 1 and width >= self.shard_threshold
+                if sharded:
                     per = padded // self.world
                     lo = min(self.rank * per, width)
                     hi = min(lo + per, width)
-                    if hi > lo:
-                        self.eng.pbs(self.tmp[lo:hi], ids[lo:hi], hi - lo, self.store[base + lo: base + hi], stream)
-                    self._all_gather_rows(self.store[base: base + padded], per)
-                else:
-                    self.eng.pbs(self.tmp, ids, width, self.store[base: base + width], stream)
+                if hi > lo:
+                    eng.lincomb(self.store, self.d_rp[pos + lo:], self.d_idx, self.d_coef, self.d_const[pos + lo:], hi - lo, tmp[lo:], stream)
+                    eng.pbs(tmp[lo:], self.d_ids[pos + lo:], hi - lo, lvl[lo:], stream)
+                if sharded:
+                    self._all_gather_rows(lvl[:padded], padded // self.world)
+                eng.scatter_rows(lvl, width, self.store, self.d_rows[pos:], stream)
             rp, ix, cf, cs = self.out_csr
-            self.eng.lincomb(self.store, rp, ix, cf, cs, self.n_out, self.out, stream)
+            eng.lincomb(self.store, rp, ix, cf, cs, self.n_out, self.out, stream)
             if self.on_gpu:
                 torch.cuda.synchronize(self.dev)
             return self.out[: self.n_out].cpu().numpy().view(np.uint64)
 
     def _all_gather_rows(self, region, per):
-        """in-place all-gather of a level's store region: rank r contributed rows [r*per, (r+1)*per)"""
+        """in-place all-gather of a level buffer: rank r contributed rows [r*per, (r+1)*per) (rows of the last rank past
+        the level's width are padding: gathered, never scattered)"""
         dist, torch = self.dist, self.torch
         mine = region[self.rank * per: (self.rank + 1) * per]
         if dist.get_backend(self.group) == "nccl":

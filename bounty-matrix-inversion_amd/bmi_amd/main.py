@@ -12,6 +12,8 @@ from typing import Tuple
 import numpy as np
 
 from .circuit import Circuit, MSG_BITS
+from .program import Program, compile_cached
+from .program import estimated_evaluate_ms as _estimate_widths
 from .qfloat import QFloat
 from .qfloat_matrix_inversion import (float_matrix_to_qfloat_arrays, qfloat_and_signs_arrays_to_float_matrix,
                                       qfloat_matrix_inverse)
@@ -21,11 +23,8 @@ def estimated_evaluate_ms(circuit):
     """Cost model of one evaluation on one MI355X (measured): a level up to 512 ciphertexts wide runs
     ceil(width / 256) rounds of the latency kernel (4.4 ms each: one workgroup per ciphertext, 256 CUs), a wider one
     the throughput kernel (10.8 ms per started 1,024 ciphertexts, 96 PBS per ms once the chip is full)."""
-    ms = 0.0
-    for lv in circuit.levels():
-        w = len(lv)
-        ms += 4.4 * -(-w // 256) if w <= 512 else max(10.8 * -(-w // 1024), w / 96.0)
-    return ms
+    widths = circuit.level_widths() if isinstance(circuit, Program) else [len(lv) for lv in circuit.levels()]
+    return _estimate_widths(widths)
 
 
 def trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base=2, true_division=False, tensorize=False, division_bits=None):
@@ -67,11 +66,37 @@ def _trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tenso
     return c
 
 
+def compile_inverse(n, qfloat_len, qfloat_ints, qfloat_base=2, true_division=False, tensorize=False, division_bits=None,
+                    cache=True):
+    """The compiled program of qfloat_matrix_inverse for one configuration: traced, pruned, scheduled and frozen into
+    arrays (program.Program) once, then loaded from the on-disk cache (BMI_CACHE_DIR, default <package>/cache) on every
+    later start.  The analogue of fhe.Compiler(...).compile (main.py:53-66), whose seconds the reference pays on
+    every run.  Returns (program, info); info = {"cached", "seconds", "path"}."""
+    key = dict(kind="inverse", n=int(n), len=int(qfloat_len), ints=int(qfloat_ints), base=int(qfloat_base),
+               truediv=bool(true_division), tensorize=bool(tensorize), divbits=division_bits or 0, msg=MSG_BITS)
+
+    def build():
+        from . import base_p_arrays as bpa
+        cands = (division_bits,) if division_bits else ((2, 3) if (n <= 3 and qfloat_base == 2) else (2,))
+        best = None
+        for bits in cands:
+            cir = trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize, bits)
+            stats = {"additions": QFloat.ADDITIONS, "multiplications": QFloat.MULTIPLICATION, "divisions": QFloat.DIVISION}
+            prog = Program.from_circuit(cir, meta=dict(key, division_bits=bits, **stats))
+            est = estimated_evaluate_ms(prog)
+            if best is None or est < best[0]:
+                best = (est, prog)
+        del bpa
+        return best[1]
+
+    return compile_cached(key, build, cache=cache)
+
+
 class EncryptedMatrixInversion:
     shape: Tuple[int, int]
 
     def __init__(self, n, sampler=None, qfloat_base=2, qfloat_len=32, qfloat_ints=16, true_division=False,
-                 tensorize=False, engine=None, device=0, shard_threshold=1024):
+                 tensorize=False, engine=None, device=0, shard_threshold=1024, cache=True):
         """The reference's seven arguments (main.py:17-36), then: engine / device (the GPU context to use) and
         shard_threshold (with torch.distributed initialised on several ranks, levels at least this wide are split
         across the ranks' GPUs, see executor.py)."""
@@ -84,7 +109,9 @@ class EncryptedMatrixInversion:
             s = sampler()
             assert isinstance(s, np.ndarray) and np.issubdtype(s.dtype, np.floating) and s.shape == self.shape
         t0 = time.time()
-        self.circuit = trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize)
+        self.program, self.compile_info = compile_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division,
+                                                          tensorize, cache=cache)
+        self.circuit = self.program      # what the reference calls the compiled circuit
         self.trace_seconds = time.time() - t0
         self.engine = engine
         self.device = device

@@ -1,0 +1,363 @@
+"""Program: a traced circuit frozen into flat arrays — what `compile` produces, what the executor runs and what the
+on-disk cache stores.
+
+The reference pays for compilation on every start (`fhe.Compiler(...).compile`, matrix_inversion/main.py:53-66; its
+README counts those seconds in the published totals) and softens it with Concrete's key cache
+(qfloat_matrix_inversion.py:997-998).  Here the traced PBS graph of a configuration is a pure function of
+(n, len, ints, base, true_division, tensorize), so it is traced once (`circuit.Circuit`, Python), then
+
+  * pruned: look-ups no output depends on are dropped (dead-code elimination),
+  * scheduled: every look-up gets its level (same depth as ASAP, width-aware: `schedule_levels`),
+  * frozen into CSR arrays (terms of every PBS input, tables, outputs, interval claims),
+  * written to `<cache dir>/<key>.npz`; every later start is a load of that file (< 1 s even for the 8x8 inverse).
+
+`Program.simulate` is the vectorised plaintext evaluator (the analogue of `circuit.simulate`, main.py:107): one numpy
+pass per level instead of one Python step per look-up; it checks the same interval claims as `Circuit.simulate`.
+"""
+from __future__ import annotations
+
+import hashlib
+import heapq
+import os
+import time
+
+import numpy as np
+
+from .circuit import Circuit, RangeError
+
+FORMAT = 3
+ROUND = Circuit.ROUND
+WIDE_ROUND = Circuit.WIDE_ROUND
+
+
+def cache_dir():
+    d = os.environ.get("BMI_CACHE_DIR")
+    if not d:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cache")
+    return d
+
+
+def _tracer_fingerprint():
+    """hash of the modules that define what a trace looks like: a cached program is only valid for the code that made it"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    for name in ("circuit.py", "base_p_arrays.py", "qfloat.py", "qfloat_matrix_inversion.py", "program.py"):
+        with open(os.path.join(here, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def schedule_levels(n_in, node_ptr, term_leaf, asap, round_=ROUND, wide_round=WIDE_ROUND):
+    """Width-aware list schedule (same depth as ASAP).  A level costs one latency-kernel round per started `round_`
+    ciphertexts up to two rounds and one throughput-kernel round per started `wide_round` beyond that, so nodes with
+    slack (ALAP later than ASAP) are moved out of levels that would otherwise spill into one more round: levels are
+    filled in order, critical nodes (ALAP = this level) first, then ready nodes by ALAP while the rounds the critical
+    ones need anyway have room.  Returns the level (1-based) of every node."""
+    nn = len(asap)
+    if nn == 0:
+        return np.zeros(0, np.int32)
+    ptr = node_ptr.tolist()
+    tl = term_leaf.tolist()
+    asap_l = asap.tolist()
+    depth = max(asap_l)
+    preds = [[t - n_in for t in tl[ptr[i]:ptr[i + 1]] if t >= n_in] for i in range(nn)]
+    succs = [[] for _ in range(nn)]
+    for i, ps in enumerate(preds):
+        for q in ps:
+            succs[q].append(i)
+    alap = [depth] * nn
+    for i in np.argsort(-asap, kind="stable").tolist():   # successors (larger ASAP) are final before their producers
+        a = alap[i]
+        for sc in succs[i]:
+            if alap[sc] - 1 < a:
+                a = alap[sc] - 1
+        alap[i] = a
+    indeg = [len(ps) for ps in preds]
+    bucket, keys = {}, []
+    for i in range(nn):
+        if indeg[i] == 0:
+            b = bucket.get(alap[i])
+            if b is None:
+                b = bucket[alap[i]] = []
+                heapq.heappush(keys, alap[i])
+            b.append(i)
+    level = [0] * nn
+    done, t = 0, 0
+    while done < nn:
+        t += 1
+        must = len(bucket.get(t, ()))
+        cap = max(1, -(-must // round_)) * round_ if must <= 2 * round_ else -(-must // wide_round) * wide_round
+        chosen = []
+        while keys and len(chosen) < cap:
+            a = keys[0]
+            b = bucket[a]
+            room = cap - len(chosen)
+            if len(b) <= room:
+                chosen.extend(b)
+                del bucket[a]
+                heapq.heappop(keys)
+            else:
+                chosen.extend(b[-room:])
+                del b[-room:]
+        for i in chosen:
+            level[i] = t
+            for sc in succs[i]:
+                indeg[sc] -= 1
+                if indeg[sc] == 0:
+                    a = alap[sc]
+                    b = bucket.get(a)
+                    if b is None:
+                        b = bucket[a] = []
+                        heapq.heappush(keys, a)
+                    b.append(sc)
+        done += len(chosen)
+    assert t == depth, (t, depth)
+    return np.asarray(level, np.int32)
+
+
+class Program:
+    ARRAYS = ("in_lo", "in_hi", "node_ptr", "term_leaf", "term_coef", "node_const", "node_lut", "node_level",
+              "node_wide", "node_lo", "node_hi", "lut_p", "lut_tab", "out_ptr", "out_leaf", "out_coef", "out_const",
+              "claim_ptr", "claim_leaf", "claim_coef", "claim_const", "claim_lo", "claim_hi")
+
+    def __init__(self, msg_bits, arrays, meta=None):
+        self.msg_bits = int(msg_bits)
+        for k in self.ARRAYS:
+            setattr(self, k, arrays[k])
+        self.meta = dict(meta or {})
+        self.n_inputs = int(self.in_lo.size)
+        self.n_nodes = int(self.node_lut.size)
+        self.depth = int(self.node_level.max()) if self.n_nodes else 0
+        self._order = None
+
+    # ---- what the host layer reads off a circuit ----------------------------------------------------------------
+    @property
+    def leaf_lo(self):
+        return self.in_lo
+
+    @property
+    def leaf_hi(self):
+        return self.in_hi
+
+    @property
+    def n_outputs(self):
+        return int(self.out_const.size)
+
+    def level_order(self):
+        """(order, counts): node indices sorted by level (stable), number of nodes per level 1..depth"""
+        if self._order is None:
+            order = np.argsort(self.node_level, kind="stable")
+            counts = np.bincount(self.node_level, minlength=self.depth + 1)[1:]
+            self._order = (order, counts)
+        return self._order
+
+    def level_widths(self):
+        return self.level_order()[1]
+
+    def summary(self):
+        w = self.level_widths()
+        return {"inputs": self.n_inputs, "pbs": self.n_nodes, "depth": self.depth, "luts": int(self.lut_p.size),
+                "max_width": int(w.max()) if w.size else 0, "mean_width": float(w.mean()) if w.size else 0.0,
+                "median_width": float(np.median(w)) if w.size else 0.0, **{k: v for k, v in self.meta.items()
+                                                                           if isinstance(v, (int, float, str))}}
+
+    # ---- construction ---------------------------------------------------------------------------------------------
+    @classmethod
+    def from_circuit(cls, c: Circuit, meta=None, prune=True):
+        n_in, nn = c.n_inputs, len(c.nodes)
+        n_leaves = n_in + nn
+        for i, (_, _, _, leaf) in enumerate(c.nodes):
+            if leaf != n_in + i:
+                raise ValueError("circuit leaves are not numbered inputs-then-nodes")
+        live = np.zeros(n_leaves, bool)
+        for terms, _ in c.outputs:
+            for t, _ in terms:
+                live[t] = True
+        if prune:
+            lv = live.tolist()
+            for i in range(nn - 1, -1, -1):     # creation order is topological: consumers come after producers
+                if lv[n_in + i]:
+                    for t, _ in c.nodes[i][0]:
+                        lv[t] = True
+            live = np.asarray(lv, bool)
+            live[:n_in] = True
+        else:
+            live[:] = True
+        keep = np.flatnonzero(live[n_in:])
+        new_leaf = np.full(n_leaves, -1, np.int64)
+        new_leaf[:n_in] = np.arange(n_in)
+        new_leaf[n_in + keep] = n_in + np.arange(keep.size)
+        nl = new_leaf.tolist()
+        ptr, tleaf, tcoef, nconst, nlut = [0], [], [], [], []
+        for i in keep.tolist():
+            terms, const, li, _ = c.nodes[i]
+            for t, cf in terms:
+                tleaf.append(nl[t])
+                tcoef.append(cf)
+            ptr.append(len(tleaf))
+            nconst.append(const)
+            nlut.append(li)
+        leaf_lo, leaf_hi = np.asarray(c.leaf_lo, np.int64), np.asarray(c.leaf_hi, np.int64)
+        leaf_level = np.asarray(c.leaf_level, np.int32)
+        wide = np.zeros(n_leaves, bool)
+        if c.wide_leaves:
+            wide[np.fromiter(c.wide_leaves, np.int64)] = True
+        node_ptr = np.asarray(ptr, np.int64)
+        term_leaf = np.asarray(tleaf, np.int32)
+        asap = leaf_level[n_in + keep]
+        width = 1 << c.msg_bits
+        lut_tab = np.zeros((max(len(c.luts), 1), width), np.int16)
+        for j, (p, tab) in enumerate(c.luts):
+            lut_tab[j, : len(tab)] = tab
+        used_luts = np.unique(np.asarray(nlut, np.int64)) if nlut else np.zeros(0, np.int64)
+        lut_map = np.full(max(len(c.luts), 1), -1, np.int64)
+        lut_map[used_luts] = np.arange(used_luts.size)
+
+        def csr(rows, with_bounds=False):
+            rp, lf, cf, cs, lo, hi = [0], [], [], [], [], []
+            for row in rows:
+                (terms, const) = row[0] if with_bounds else row
+                if any(nl[t] < 0 for t, _ in terms):
+                    continue    # a claim about a value nothing depends on
+                for t, k in terms:
+                    lf.append(nl[t])
+                    cf.append(k)
+                rp.append(len(lf))
+                cs.append(const)
+                if with_bounds:
+                    lo.append(row[1])
+                    hi.append(row[2])
+            a = (np.asarray(rp, np.int64), np.asarray(lf, np.int32), np.asarray(cf, np.int64), np.asarray(cs, np.int64))
+            return a + (np.asarray(lo, np.int64), np.asarray(hi, np.int64)) if with_bounds else a
+
+        out_ptr, out_leaf, out_coef, out_const = csr(c.outputs)
+        claim_ptr, claim_leaf, claim_coef, claim_const, claim_lo, claim_hi = csr(c.claims, True)
+        arrays = dict(
+            in_lo=leaf_lo[:n_in].copy(), in_hi=leaf_hi[:n_in].copy(), node_ptr=node_ptr, term_leaf=term_leaf,
+            term_coef=np.asarray(tcoef, np.int32), node_const=np.asarray(nconst, np.int64),
+            node_lut=lut_map[np.asarray(nlut, np.int64)].astype(np.int32) if nlut else np.zeros(0, np.int32),
+            node_level=schedule_levels(n_in, node_ptr, term_leaf, asap), node_wide=wide[n_in + keep],
+            node_lo=leaf_lo[n_in + keep].astype(np.int16), node_hi=leaf_hi[n_in + keep].astype(np.int16),
+            lut_p=np.asarray([c.luts[j][0] for j in used_luts.tolist()], np.int8), lut_tab=lut_tab[used_luts],
+            out_ptr=out_ptr, out_leaf=out_leaf, out_coef=out_coef, out_const=out_const,
+            claim_ptr=claim_ptr, claim_leaf=claim_leaf, claim_coef=claim_coef, claim_const=claim_const,
+            claim_lo=claim_lo, claim_hi=claim_hi)
+        m = dict(meta or {})
+        m.update(traced_pbs=nn, pruned_pbs=int(nn - keep.size), cse_hits=int(c.stats.get("cse_hits", 0)),
+                 const_folds=int(c.stats.get("const_folds", 0)))
+        return cls(c.msg_bits, arrays, m)
+
+    # ---- disk ---------------------------------------------------------------------------------------------------------
+    def save(self, path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp.npz"
+        meta_keys = sorted(self.meta)
+        np.savez_compressed(tmp, __format=np.int64(FORMAT), __msg_bits=np.int64(self.msg_bits),
+                            __meta_keys=np.asarray(meta_keys), __meta_vals=np.asarray([repr(self.meta[k]) for k in meta_keys]),
+                            **{k: getattr(self, k) for k in self.ARRAYS})
+        os.replace(tmp, path)     # atomic: several ranks may compile the same configuration at once
+
+    @classmethod
+    def load(cls, path):
+        import ast
+        with np.load(path, allow_pickle=False) as z:
+            if int(z["__format"]) != FORMAT:
+                raise ValueError("cached program has another format")
+            meta = {str(k): ast.literal_eval(str(v)) for k, v in zip(z["__meta_keys"], z["__meta_vals"])}
+            return cls(int(z["__msg_bits"]), {k: z[k] for k in cls.ARRAYS}, meta)
+
+    # ---- plaintext evaluation ---------------------------------------------------------------------------------------
+    def simulate(self, inputs, check=True):
+        x = np.asarray([int(v) for v in inputs], np.int64)
+        if x.size != self.n_inputs:
+            raise ValueError("wrong number of inputs")
+        if check:
+            bad = np.flatnonzero((x < self.in_lo) | (x > self.in_hi))
+            if bad.size:
+                i = int(bad[0])
+                raise RangeError(f"input {i} = {int(x[i])} outside its declared interval [{int(self.in_lo[i])}, {int(self.in_hi[i])}]")
+        n_in = self.n_inputs
+        val = np.zeros(n_in + self.n_nodes, np.int64)
+        val[:n_in] = x
+        order, counts = self.level_order()
+        half_space = 1 << (self.msg_bits - 1)
+        lens = np.diff(self.node_ptr)
+        term_coef = self.term_coef.astype(np.int64)
+        pos = 0
+        for w in counts.tolist():
+            nodes = order[pos: pos + w]
+            pos += w
+            ln = lens[nodes]
+            starts = self.node_ptr[nodes]
+            # gather the terms of these nodes: offsets start[i] + (0 .. len[i] - 1)
+            tot = int(ln.sum())
+            seg = np.repeat(np.arange(w), ln)
+            off = np.arange(tot) - np.repeat(np.cumsum(ln) - ln, ln) + np.repeat(starts, ln)
+            contrib = term_coef[off] * val[self.term_leaf[off]]
+            xin = self.node_const[nodes] + np.bincount(seg, weights=contrib, minlength=w).astype(np.int64)
+            p = self.lut_p[self.node_lut[nodes]].astype(np.int64)
+            scale = np.left_shift(1, self.msg_bits - p)
+            widef = self.node_wide[nodes]
+            if check:
+                ok = np.where(widef, (xin > -2 * half_space) & (xin < 2 * half_space), (xin >= -half_space) & (xin < half_space))
+                if not ok.all():
+                    raise RangeError(f"PBS input {int(xin[np.flatnonzero(~ok)[0]])} outside the message space")
+                if (xin % scale).any():
+                    raise RangeError("PBS input not a multiple of its scale")
+            m = xin // scale
+            hp = np.left_shift(1, p - 1)
+            hi_wrap = widef & (m >= half_space)       # the other half of the torus: negacyclic wrap-around
+            lo_wrap = widef & (m < -half_space)
+            mm = np.where(hi_wrap, m - 2 * half_space, np.where(lo_wrap, m + 2 * half_space, m))
+            out = self.lut_tab[self.node_lut[nodes], mm + hp].astype(np.int64)
+            out = np.where(hi_wrap | lo_wrap, -out, out)
+            if check and ((out < self.node_lo[nodes]) | (out > self.node_hi[nodes])).any():
+                raise RangeError("look-up output outside its interval")
+            val[n_in + nodes] = out
+
+        def rows(ptr, leaf, coef, const):
+            ln = np.diff(ptr)
+            seg = np.repeat(np.arange(ln.size), ln)
+            return const + np.bincount(seg, weights=coef * val[leaf], minlength=ln.size).astype(np.int64)
+
+        if check and self.claim_const.size:
+            cv = rows(self.claim_ptr, self.claim_leaf, self.claim_coef, self.claim_const)
+            bad = np.flatnonzero((cv < self.claim_lo) | (cv > self.claim_hi))
+            if bad.size:
+                i = int(bad[0])
+                raise RangeError(f"interval claim [{int(self.claim_lo[i])}, {int(self.claim_hi[i])}] violated by value {int(cv[i])}")
+        return [int(v) for v in rows(self.out_ptr, self.out_leaf, self.out_coef, self.out_const)]
+
+
+def estimated_evaluate_ms(widths):
+    """Cost model of one evaluation on one MI355X (measured): a level up to 512 ciphertexts wide runs
+    ceil(width / 256) rounds of the latency kernel (4.4 ms each: one workgroup per ciphertext, 256 CUs), a wider one
+    the throughput kernel (10.8 ms per started 1,024 ciphertexts, 96 PBS per ms once the chip is full)."""
+    w = np.asarray(widths, np.float64)
+    lat = 4.4 * np.ceil(w / 256)
+    tp = np.maximum(10.8 * np.ceil(w / 1024), w / 96.0)
+    return float(np.where(w <= 512, lat, tp).sum())
+
+
+def compile_cached(key_fields, build, cache=True):
+    """key_fields: dict naming the configuration; build(): -> Program (slow path: trace + freeze).
+    Returns (program, info) with info = {"cached": bool, "seconds": load or build time, "path": file}."""
+    t0 = time.time()
+    path = None
+    if cache:
+        key = hashlib.sha256(repr((FORMAT, _tracer_fingerprint(), sorted(key_fields.items()))).encode()).hexdigest()[:24]
+        name = "_".join(f"{k}{v}" for k, v in sorted(key_fields.items()) if not isinstance(v, bool) or v)
+        path = os.path.join(cache_dir(), f"{name}_{key}.npz".replace(" ", ""))
+        if os.path.exists(path):
+            try:
+                prog = Program.load(path)
+                return prog, {"cached": True, "seconds": time.time() - t0, "path": path}
+            except Exception:
+                pass    # unreadable / stale file: rebuild below and overwrite it
+    prog = build()
+    if path is not None:
+        try:
+            prog.save(path)
+        except OSError:
+            path = None     # read-only tree: stay uncached
+    return prog, {"cached": False, "seconds": time.time() - t0, "path": path}

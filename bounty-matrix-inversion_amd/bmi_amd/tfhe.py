@@ -58,6 +58,7 @@ _SIGS = {
     "bmi_blind_rotate_batch": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p],
     "bmi_lincomb_batch": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                           C.c_void_p, C.c_void_p],
+    "bmi_scatter_rows": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p],
     "bmi_pbs_batch_host": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
     "bmi_keyswitch_batch_host": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
     "bmi_blind_rotate_batch_host": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
@@ -367,6 +368,10 @@ class Engine:
     def lincomb(self, d_store, d_row_ptr, d_idx, d_coef, d_const, count, d_out, stream=0):
         self._ck(self.lib.bmi_lincomb_batch(self.h, _ptr(d_store), _ptr(d_row_ptr), _ptr(d_idx), _ptr(d_coef),
                                             _ptr(d_const), count, _ptr(d_out), C.c_void_p(stream)), "bmi_lincomb_batch")
+
+    def scatter_rows(self, d_src, count, d_store, d_rows, stream=0):
+        self._ck(self.lib.bmi_scatter_rows(self.h, _ptr(d_src), count, _ptr(d_store), _ptr(d_rows), C.c_void_p(stream)),
+                 "bmi_scatter_rows")
 
     def reserve(self, max_count):
         self._ck(self.lib.bmi_reserve(self.h, int(max_count)), "bmi_reserve")

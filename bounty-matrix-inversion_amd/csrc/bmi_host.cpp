@@ -146,7 +146,12 @@ int fail(const bmi_ctx *c, int code, const std::string &msg) {
 
 int ensure_small(bmi_ctx *c, size_t count) {
     if (count <= c->small_cap) return 0;
-    if (c->d_small) HIP_OK(c, hipFree(c->d_small));
+    if (c->d_small) {   // queued work may still read the old buffer
+        HIP_OK(c, hipDeviceSynchronize());
+        HIP_OK(c, hipFree(c->d_small));
+        c->d_small = nullptr;
+        c->small_cap = 0;
+    }
     size_t cap = std::max<size_t>(count, 1024);
     HIP_OK(c, hipMalloc(&c->d_small, cap * (c->P.n + 1) * sizeof(u64)));
     c->small_cap = cap;
@@ -820,10 +825,19 @@ int bmi_lincomb_batch(bmi_ctx *c, const uint64_t *d_store, const uint32_t *d_row
                       const int64_t *d_coef, const uint64_t *d_const_body, uint32_t count, uint64_t *d_out,
                       void *stream) {
     if (!c || (count && (!d_store || !d_row_ptr || !d_const_body || !d_out))) return -1;
+    HIP_OK(c, hipSetDevice(c->device));
     int rc = (c->f64() ? bmi49::launch_lincomb : bmi::launch_lincomb)(d_store, d_row_ptr, d_idx, (const i64 *)d_coef,
                                                                       d_const_body, d_out, count, c->big_n + 1,
                                                                       (hipStream_t)stream);
     return rc ? fail(c, -2, std::string("lincomb launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+}
+
+int bmi_scatter_rows(bmi_ctx *c, const uint64_t *d_src, uint32_t count, uint64_t *d_store, const uint32_t *d_rows,
+                     void *stream) {
+    if (!c || (count && (!d_src || !d_store || !d_rows))) return -1;
+    HIP_OK(c, hipSetDevice(c->device));
+    int rc = bmi::launch_scatter_rows(d_src, d_store, d_rows, count, c->big_n + 1, (hipStream_t)stream);
+    return rc ? fail(c, -2, std::string("scatter_rows launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
 }
 
 int bmi_reserve(bmi_ctx *c, uint32_t max_count) {
@@ -835,12 +849,18 @@ int bmi_reserve(bmi_ctx *c, uint32_t max_count) {
         HIP_OK(c, hipMalloc(&c->d_ks_partial, c->ks_partial_bytes));
     }
     if (c->ks_mfma_ok) {
-        // the sums buffer peaks where the K-split is still active (small batches), not at max_count
-        for (uint32_t cnt = 32; cnt < max_count; cnt *= 2) {
-            int rc = ensure_ks_mfma(c, cnt);
-            if (rc) return rc;
+        // the sums buffer peaks where the K-split is still active (small batches), not at max_count, and the slice
+        // count is not monotonic in the batch size: take the largest need over every tile count up to max_count
+        uint32_t worst = max_count;
+        size_t worst_sums = 0;
+        for (uint32_t tiles = 1; tiles <= (max_count + 31) / 32; tiles++) {
+            const uint32_t cnt = std::min(tiles * 32, max_count);
+            const size_t sums = (size_t)ks_mfma_slices(c, cnt) * cnt;
+            if (sums > worst_sums) { worst_sums = sums; worst = cnt; }
         }
-        int rc = ensure_ks_mfma(c, max_count);
+        int rc = ensure_ks_mfma(c, worst);
+        if (rc) return rc;
+        rc = ensure_ks_mfma(c, max_count);
         if (rc) return rc;
     }
     return ensure_small(c, max_count);

@@ -85,6 +85,8 @@ int launch_keyswitch_mfma(const u64 *in, const signed char *limbs, signed char *
                           uint32_t base_log, hipStream_t s);
 int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *idx, const i64 *coef,
                    const u64 *const_body, u64 *out, uint32_t count, uint32_t width, hipStream_t s);
+// store[rows[i]] = src[i] (rows of `width` words); field independent
+int launch_scatter_rows(const u64 *src, u64 *store, const uint32_t *rows, uint32_t count, uint32_t width, hipStream_t s);
 }  // namespace bmi
 
 // The same launchers for the 49-bit field (bmi_kernels_f64.hip): NTT-domain key, twiddles and test polynomials are f64.

@@ -390,4 +390,19 @@ int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *id
     return ksl::launch_lincomb<FieldG>(store, row_ptr, idx, coef, const_body, out, count, width, s);
 }
 
+// store[rows[i]] = src[i] for i < count (rows of `width` words): the executor's level buffer -> recycled store rows
+__global__ void __launch_bounds__(256) k_scatter_rows(const u64 *__restrict__ src, u64 *__restrict__ store,
+                                                      const uint32_t *__restrict__ rows, uint32_t width) {
+    const u64 *s = src + (size_t)blockIdx.x * width;
+    u64 *d = store + (size_t)rows[blockIdx.x] * width;
+    for (uint32_t x = threadIdx.x; x < width; x += 256) d[x] = s[x];
+}
+
+int launch_scatter_rows(const u64 *src, u64 *store, const uint32_t *rows, uint32_t count, uint32_t width, hipStream_t s) {
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(k_scatter_rows, dim3(count), dim3(256), 0, s, src, store, rows, width);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 }  // namespace bmi

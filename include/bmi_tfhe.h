@@ -120,6 +120,11 @@ int bmi_blind_rotate_batch(bmi_ctx *ctx, const uint64_t *d_small, const uint32_t
 int bmi_lincomb_batch(bmi_ctx *ctx, const uint64_t *d_store, const uint32_t *d_row_ptr, const uint32_t *d_idx,
                       const int64_t *d_coef, const uint64_t *d_const_body, uint32_t count, uint64_t *d_out,
                       void *stream);
+/* d_store[d_rows[i]] = d_src[i] for i < count (big-key ciphertext rows).  Lets a scheduler keep a level's outputs
+ * contiguous for the batch call and still place them in recycled rows of its ciphertext store (the reference leaves
+ * value lifetimes to Concrete's runtime inside circuit.run, main.py:81). */
+int bmi_scatter_rows(bmi_ctx *ctx, const uint64_t *d_src, uint32_t count, uint64_t *d_store, const uint32_t *d_rows,
+                     void *stream);
 /* Host-buffer convenience forms (what a ctypes/cgo binding over numpy buffers would call):
  * copy in, run on the context's own stream, copy out, synchronise. */
 int bmi_pbs_batch_host(bmi_ctx *ctx, const uint64_t *in, const uint32_t *lut_ids, uint32_t count, uint64_t *out);

@@ -90,6 +90,10 @@ class _PlainEngine:
             acc[-1] += int(cs[r])
             out[r] = acc
 
+    def scatter_rows(self, src, count, store, rows, stream=0):
+        for r in range(count):
+            store[int(rows[r])] = src[r]
+
     def pbs(self, d_in, ids, count, d_out, stream=0):
         for r in range(count):
             p, table = self.tables[int(ids[r])]
