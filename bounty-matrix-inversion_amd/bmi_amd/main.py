@@ -125,7 +125,8 @@ class EncryptedMatrixInversion:
             self.engine = tfhe.Engine(device=self.device)
         return self.engine
 
-    def keygen(self, seed=0x5EED):
+    def keygen(self, seed=None):
+        """circuit.keygen() (main.py:177).  seed=None: CSPRNG keys; an integer: the test-only deterministic key set."""
         self._engine().keygen(seed)
 
     def _executor(self):

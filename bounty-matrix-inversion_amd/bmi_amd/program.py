@@ -115,6 +115,22 @@ def schedule_levels(n_in, node_ptr, term_leaf, asap, round_=ROUND, wide_round=WI
     return np.asarray(level, np.int32)
 
 
+def prune_nodes(n_in, node_ptr, term_leaf, out_leaf):
+    """live mask of the look-ups an output depends on (Python twin of bmi_circuit_prune)"""
+    nn = node_ptr.size - 1
+    live = [False] * nn
+    for t in out_leaf.tolist():
+        if t >= n_in:
+            live[t - n_in] = True
+    ptr, tl = node_ptr.tolist(), term_leaf.tolist()
+    for i in range(nn - 1, -1, -1):     # creation order is topological: consumers come after producers
+        if live[i]:
+            for t in tl[ptr[i]:ptr[i + 1]]:
+                if t >= n_in:
+                    live[t - n_in] = True
+    return np.asarray(live, bool)
+
+
 class Program:
     ARRAYS = ("in_lo", "in_hi", "node_ptr", "term_leaf", "term_coef", "node_const", "node_lut", "node_level",
               "node_wide", "node_lo", "node_hi", "lut_p", "lut_tab", "out_ptr", "out_leaf", "out_coef", "out_const",
@@ -163,85 +179,82 @@ class Program:
 
     # ---- construction ---------------------------------------------------------------------------------------------
     @classmethod
-    def from_circuit(cls, c: Circuit, meta=None, prune=True):
+    def from_circuit(cls, c: Circuit, meta=None, prune=True, native=True):
+        """Freezes a traced circuit: flatten -> prune -> renumber -> schedule.  native=True runs the two graph passes in
+        the library (bmi_circuit_prune / bmi_circuit_schedule, C++); native=False the Python twins in this module."""
+        from itertools import chain
         n_in, nn = c.n_inputs, len(c.nodes)
         n_leaves = n_in + nn
-        for i, (_, _, _, leaf) in enumerate(c.nodes):
-            if leaf != n_in + i:
-                raise ValueError("circuit leaves are not numbered inputs-then-nodes")
-        live = np.zeros(n_leaves, bool)
-        for terms, _ in c.outputs:
-            for t, _ in terms:
-                live[t] = True
-        if prune:
-            lv = live.tolist()
-            for i in range(nn - 1, -1, -1):     # creation order is topological: consumers come after producers
-                if lv[n_in + i]:
-                    for t, _ in c.nodes[i][0]:
-                        lv[t] = True
-            live = np.asarray(lv, bool)
-            live[:n_in] = True
+        if nn and (c.nodes[0][3] != n_in or c.nodes[-1][3] != n_leaves - 1):
+            raise ValueError("circuit leaves are not numbered inputs-then-nodes")
+
+        def flatten(rows):
+            """rows of (terms, const) -> CSR (ptr, leaf, coef, const)"""
+            lens = np.fromiter((len(r[0]) for r in rows), np.int64, len(rows))
+            flat = np.fromiter(chain.from_iterable(chain.from_iterable(r[0] for r in rows)), np.int64, 2 * int(lens.sum()))
+            const = np.fromiter((r[1] for r in rows), np.int64, len(rows))
+            return np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), flat[0::2].astype(np.int32), flat[1::2].copy(), const
+
+        node_ptr, term_leaf, term_coef, node_const = flatten(c.nodes)
+        node_lut = np.fromiter((r[2] for r in c.nodes), np.int64, nn)
+        out_ptr, out_leaf, out_coef, out_const = flatten(c.outputs)
+        claim_ptr, claim_leaf, claim_coef, claim_const = flatten([cl[0] for cl in c.claims])
+        claim_lo = np.fromiter((cl[1] for cl in c.claims), np.int64, len(c.claims))
+        claim_hi = np.fromiter((cl[2] for cl in c.claims), np.int64, len(c.claims))
+        if not prune:
+            live = np.ones(nn, bool)
+        elif native:
+            from . import tfhe
+            live = tfhe.circuit_prune(n_in, node_ptr, term_leaf, out_leaf)
         else:
-            live[:] = True
-        keep = np.flatnonzero(live[n_in:])
+            live = prune_nodes(n_in, node_ptr, term_leaf, out_leaf)
+        keep = np.flatnonzero(live)
         new_leaf = np.full(n_leaves, -1, np.int64)
         new_leaf[:n_in] = np.arange(n_in)
         new_leaf[n_in + keep] = n_in + np.arange(keep.size)
-        nl = new_leaf.tolist()
-        ptr, tleaf, tcoef, nconst, nlut = [0], [], [], [], []
-        for i in keep.tolist():
-            terms, const, li, _ = c.nodes[i]
-            for t, cf in terms:
-                tleaf.append(nl[t])
-                tcoef.append(cf)
-            ptr.append(len(tleaf))
-            nconst.append(const)
-            nlut.append(li)
+
+        def take_rows(ptr, leaf, coef, rows):
+            """the CSR rows `rows`, leaves renumbered"""
+            lens = np.diff(ptr)[rows]
+            tot = int(lens.sum())
+            off = np.arange(tot) - np.repeat(np.cumsum(lens) - lens, lens) + np.repeat(ptr[:-1][rows], lens)
+            return np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), new_leaf[leaf[off]].astype(np.int32), coef[off]
+
+        k_ptr, k_leaf, k_coef = take_rows(node_ptr, term_leaf, term_coef, keep)
+        o_ptr, o_leaf, o_coef = take_rows(out_ptr, out_leaf, out_coef, np.arange(out_const.size))
+        # a claim about a value nothing depends on goes with it
+        claim_lens = np.diff(claim_ptr)
+        dead_terms = np.bincount(np.repeat(np.arange(claim_const.size), claim_lens),
+                                 weights=(new_leaf[claim_leaf] < 0), minlength=claim_const.size)
+        claim_rows = np.flatnonzero(dead_terms == 0)
+        c_ptr, c_leaf, c_coef = take_rows(claim_ptr, claim_leaf, claim_coef, claim_rows)
+        if native:
+            from . import tfhe
+            node_level = tfhe.circuit_schedule(n_in, k_ptr, k_leaf, ROUND, WIDE_ROUND)
+        else:
+            asap = np.asarray(c.leaf_level, np.int32)[n_in + keep]
+            node_level = schedule_levels(n_in, k_ptr, k_leaf, asap)
         leaf_lo, leaf_hi = np.asarray(c.leaf_lo, np.int64), np.asarray(c.leaf_hi, np.int64)
-        leaf_level = np.asarray(c.leaf_level, np.int32)
         wide = np.zeros(n_leaves, bool)
         if c.wide_leaves:
-            wide[np.fromiter(c.wide_leaves, np.int64)] = True
-        node_ptr = np.asarray(ptr, np.int64)
-        term_leaf = np.asarray(tleaf, np.int32)
-        asap = leaf_level[n_in + keep]
+            wide[np.fromiter(c.wide_leaves, np.int64, len(c.wide_leaves))] = True
         width = 1 << c.msg_bits
         lut_tab = np.zeros((max(len(c.luts), 1), width), np.int16)
         for j, (p, tab) in enumerate(c.luts):
             lut_tab[j, : len(tab)] = tab
-        used_luts = np.unique(np.asarray(nlut, np.int64)) if nlut else np.zeros(0, np.int64)
+        k_lut = node_lut[keep]
+        used_luts = np.unique(k_lut)
         lut_map = np.full(max(len(c.luts), 1), -1, np.int64)
         lut_map[used_luts] = np.arange(used_luts.size)
-
-        def csr(rows, with_bounds=False):
-            rp, lf, cf, cs, lo, hi = [0], [], [], [], [], []
-            for row in rows:
-                (terms, const) = row[0] if with_bounds else row
-                if any(nl[t] < 0 for t, _ in terms):
-                    continue    # a claim about a value nothing depends on
-                for t, k in terms:
-                    lf.append(nl[t])
-                    cf.append(k)
-                rp.append(len(lf))
-                cs.append(const)
-                if with_bounds:
-                    lo.append(row[1])
-                    hi.append(row[2])
-            a = (np.asarray(rp, np.int64), np.asarray(lf, np.int32), np.asarray(cf, np.int64), np.asarray(cs, np.int64))
-            return a + (np.asarray(lo, np.int64), np.asarray(hi, np.int64)) if with_bounds else a
-
-        out_ptr, out_leaf, out_coef, out_const = csr(c.outputs)
-        claim_ptr, claim_leaf, claim_coef, claim_const, claim_lo, claim_hi = csr(c.claims, True)
         arrays = dict(
-            in_lo=leaf_lo[:n_in].copy(), in_hi=leaf_hi[:n_in].copy(), node_ptr=node_ptr, term_leaf=term_leaf,
-            term_coef=np.asarray(tcoef, np.int32), node_const=np.asarray(nconst, np.int64),
-            node_lut=lut_map[np.asarray(nlut, np.int64)].astype(np.int32) if nlut else np.zeros(0, np.int32),
-            node_level=schedule_levels(n_in, node_ptr, term_leaf, asap), node_wide=wide[n_in + keep],
+            in_lo=leaf_lo[:n_in].copy(), in_hi=leaf_hi[:n_in].copy(), node_ptr=k_ptr, term_leaf=k_leaf,
+            term_coef=k_coef.astype(np.int32), node_const=node_const[keep], node_lut=lut_map[k_lut].astype(np.int32),
+            node_level=node_level, node_wide=wide[n_in + keep],
             node_lo=leaf_lo[n_in + keep].astype(np.int16), node_hi=leaf_hi[n_in + keep].astype(np.int16),
             lut_p=np.asarray([c.luts[j][0] for j in used_luts.tolist()], np.int8), lut_tab=lut_tab[used_luts],
-            out_ptr=out_ptr, out_leaf=out_leaf, out_coef=out_coef, out_const=out_const,
-            claim_ptr=claim_ptr, claim_leaf=claim_leaf, claim_coef=claim_coef, claim_const=claim_const,
-            claim_lo=claim_lo, claim_hi=claim_hi)
+            out_ptr=o_ptr, out_leaf=o_leaf, out_coef=o_coef, out_const=out_const,
+            claim_ptr=c_ptr, claim_leaf=c_leaf, claim_coef=c_coef, claim_const=claim_const[claim_rows],
+            claim_lo=claim_lo[claim_rows], claim_hi=claim_hi[claim_rows])
         m = dict(meta or {})
         m.update(traced_pbs=nn, pruned_pbs=int(nn - keep.size), cse_hits=int(c.stats.get("cse_hits", 0)),
                  const_folds=int(c.stats.get("const_folds", 0)))

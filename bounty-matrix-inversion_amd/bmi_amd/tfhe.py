@@ -46,7 +46,8 @@ _SIGS = {
     "bmi_default_params_for": [C.c_uint32, C.POINTER(Params)],
     "bmi_ctx_create": [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)],
     "bmi_get_params": [C.c_void_p, C.POINTER(Params)],
-    "bmi_keygen": [C.c_void_p, C.c_uint64],
+    "bmi_keygen": [C.c_void_p],
+    "bmi_keygen_insecure_deterministic": [C.c_void_p, C.c_uint64],
     "bmi_export_keys": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "bmi_encrypt": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p],
     "bmi_decrypt": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p],
@@ -71,8 +72,37 @@ _SIGS = {
     "bmi_field_to_torus64": [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p],
     "bmi_set_kernel_variant": [C.c_void_p, C.c_int],
     "bmi_set_keyswitch_variant": [C.c_void_p, C.c_int],
+    "bmi_circuit_prune": [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p],
+    "bmi_circuit_schedule": [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                             C.POINTER(C.c_int32)],
     "bmi_key_bytes": [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
 }
+
+
+def circuit_prune(n_in, node_ptr, term_leaf, out_leaf):
+    """live mask of the look-ups an output depends on (bmi_circuit_prune; context-free, CPU)"""
+    node_ptr = np.ascontiguousarray(node_ptr, np.int64)
+    term_leaf = np.ascontiguousarray(term_leaf, np.int32)
+    out_leaf = np.ascontiguousarray(out_leaf, np.int32)
+    live = np.zeros(max(node_ptr.size - 1, 0), np.uint8)
+    rc = load_library().bmi_circuit_prune(int(n_in), live.size, _ptr(node_ptr), _ptr(term_leaf), _ptr(out_leaf),
+                                          out_leaf.size, _ptr(live))
+    if rc != 0:
+        raise BmiError(f"bmi_circuit_prune failed ({rc}): malformed circuit arrays")
+    return live.astype(bool)
+
+
+def circuit_schedule(n_in, node_ptr, term_leaf, round_, wide_round):
+    """width-aware level (1-based) of every look-up (bmi_circuit_schedule; context-free, CPU)"""
+    node_ptr = np.ascontiguousarray(node_ptr, np.int64)
+    term_leaf = np.ascontiguousarray(term_leaf, np.int32)
+    level = np.zeros(max(node_ptr.size - 1, 0), np.int32)
+    depth = C.c_int32(0)
+    rc = load_library().bmi_circuit_schedule(int(n_in), level.size, _ptr(node_ptr), _ptr(term_leaf), int(round_),
+                                             int(wide_round), _ptr(level), C.byref(depth))
+    if rc != 0:
+        raise BmiError(f"bmi_circuit_schedule failed ({rc}): malformed circuit arrays")
+    return level
 
 
 def torus64_to_field(ct, q_bits):
@@ -197,8 +227,14 @@ class Engine:
             raise BmiError(f"{what} failed ({rc}): {self.lib.bmi_last_error(self.h).decode()}")
 
     # ---- keys
-    def keygen(self, seed=0x5EED):
-        self._ck(self.lib.bmi_keygen(self.h, C.c_uint64(seed)), "bmi_keygen")
+    def keygen(self, seed=None):
+        """seed=None: production key generation, all randomness from the library's CSPRNG (ChaCha20 keyed by getrandom).
+        An integer seed selects bmi_keygen_insecure_deterministic: reproducible keys AND reproducible encryptions for
+        the oracle parity tests and for replicating one key set on every rank of a benchmark - not cryptographic."""
+        if seed is None:
+            self._ck(self.lib.bmi_keygen(self.h), "bmi_keygen")
+        else:
+            self._ck(self.lib.bmi_keygen_insecure_deterministic(self.h, C.c_uint64(seed)), "bmi_keygen_insecure_deterministic")
 
     def export_keys(self, secret=True):
         """(sk_small, sk_big, bsk, ksk), standard domain; secret=False returns (None, None, bsk, ksk) and also works on
@@ -230,7 +266,8 @@ class Engine:
         self._ck(self.lib.bmi_import_keys(self.h, _ptr(sk_small), _ptr(sk_big), _ptr(bsk), _ptr(ksk)), "bmi_import_keys")
 
     def keygen_from_secret(self, sk_small, sk_big, seed=0):
-        """evaluation keys for binary secret keys made elsewhere (e.g. by a Concrete client), deterministic in seed"""
+        """evaluation keys for binary secret keys made elsewhere (e.g. by a Concrete client); seed=0: CSPRNG masks and
+        noise, seed != 0: deterministic test vectors (not cryptographic)"""
         sk_small = np.ascontiguousarray(sk_small, dtype=np.uint64)
         sk_big = np.ascontiguousarray(sk_big, dtype=np.uint64)
         if sk_small.size != self.P.n or sk_big.size != self.P.k * self.P.N:

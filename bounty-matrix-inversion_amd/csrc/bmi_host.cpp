@@ -4,6 +4,9 @@
 // batch call needs a HIP device and fails loudly without one.
 #include <hip/hip_runtime.h>
 
+#include <errno.h>
+#include <sys/random.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -74,6 +77,87 @@ struct Stream {
 };
 enum : u64 { S_SK_SMALL = 1, S_SK_BIG, S_BSK_MASK, S_BSK_NOISE, S_KSK_MASK, S_KSK_NOISE, S_ENC_MASK, S_ENC_NOISE };
 
+// --------------------------------------------------------------------------- CSPRNG (production keys and encryptions)
+// ChaCha20 (D. J. Bernstein's original variant: 256-bit key, 64-bit nonce, 64-bit block counter) keyed from the
+// operating system (getrandom).  Secret material (key bits, noise) and public material (masks) use two independent keys,
+// so that the public evaluation-key words say nothing about the stream the secrets came from.  Every (domain, row) pair
+// is its own nonce: rows are sampled in parallel and sequentially within a row.
+struct ChaKey {
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool fill_from_os() {
+        size_t got = 0;
+        unsigned char *p = reinterpret_cast<unsigned char *>(k);
+        while (got < sizeof(k)) {
+            const ssize_t r = getrandom(p + got, sizeof(k) - got, 0);
+            if (r < 0) {
+                if (errno == EINTR) continue;
+                return false;
+            }
+            got += (size_t)r;
+        }
+        return true;
+    }
+};
+inline uint32_t rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+inline void chacha_block(const ChaKey &key, u64 nonce, u64 counter, uint32_t out[16]) {
+    uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3],
+                       key.k[4], key.k[5], key.k[6], key.k[7], (uint32_t)counter, (uint32_t)(counter >> 32),
+                       (uint32_t)nonce, (uint32_t)(nonce >> 32)};
+    uint32_t x[16];
+    for (int i = 0; i < 16; i++) x[i] = in[i];
+#define BMI_QR(a, b, c, d)                  \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16); \
+    x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12); \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);  \
+    x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7)
+    for (int r = 0; r < 10; r++) {
+        BMI_QR(0, 4, 8, 12); BMI_QR(1, 5, 9, 13); BMI_QR(2, 6, 10, 14); BMI_QR(3, 7, 11, 15);
+        BMI_QR(0, 5, 10, 15); BMI_QR(1, 6, 11, 12); BMI_QR(2, 7, 8, 13); BMI_QR(3, 4, 9, 14);
+    }
+#undef BMI_QR
+    for (int i = 0; i < 16; i++) out[i] = x[i] + in[i];
+}
+struct ChaStream {
+    const ChaKey *key;
+    u64 nonce, counter = 0;
+    uint32_t buf[16];
+    int pos = 16;
+    ChaStream(const ChaKey &k, u64 domain, u64 row) : key(&k), nonce((domain << 56) | (row & ((1ULL << 56) - 1))) {}
+    u64 next64() {
+        if (pos > 14) {
+            chacha_block(*key, nonce, counter++, buf);
+            pos = 0;
+        }
+        const u64 v = (u64)buf[pos] | ((u64)buf[pos + 1] << 32);
+        pos += 2;
+        return v;
+    }
+    u64 bit() { return next64() & 1; }
+    u64 uniform(const Fq &f) {   // rejection sampling: exactly uniform on [0, q)
+        for (;;) {
+            const u64 u = f.bits == 64 ? next64() : next64() >> (64 - f.bits);
+            if (u < f.q) return u;
+        }
+    }
+    u64 gauss(const Fq &f, double sigma) {
+        const double u1 = (double)((next64() >> 11) + 1) * (1.0 / 9007199254740992.0);
+        const double u2 = (double)(next64() >> 11) * (1.0 / 9007199254740992.0);
+        const double g = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586476925286766559 * u2);
+        return f.from_i64(std::llround(g * sigma * (f.bits == 64 ? 18446744073709551616.0 : (double)f.q)));
+    }
+};
+// One row's source of masks / noise: the CSPRNG (sequential within the row) or, for the test-only deterministic key
+// generation, the counter-indexed splitmix streams the oracle reproduces bit for bit.
+struct RowRng {
+    const Stream *det;
+    ChaStream cha;
+    bool secure;
+    RowRng(const Stream *d, const ChaKey &k, u64 domain, u64 row, bool sec) : det(d), cha(k, domain, row), secure(sec) {}
+    u64 uniform(u64 idx) { return secure ? cha.uniform(det->f) : det->uniform(idx); }
+    u64 gauss(u64 idx, double sigma) { return secure ? cha.gauss(det->f, sigma) : det->gauss(idx, sigma); }
+    u64 bit(u64 idx) { return secure ? cha.bit() : det->bit(idx); }
+};
+
 thread_local std::string g_create_error;
 
 template <class F>
@@ -99,6 +183,8 @@ struct bmi_ctx {
     bool have_keys = false;
     bool have_secret = false;  // false for a context that imported evaluation keys only (no encrypt / decrypt)
     u64 seed = 0, enc_counter = 0;
+    bool secure_rng = false;       // true: keys / encryptions drawn from the CSPRNG below; false: test-only seeded streams
+    ChaKey rng_secret, rng_public; // independent ChaCha20 keys from getrandom(): secrets + noise / public masks
     std::vector<u64> sk_small, sk_big, bsk_std, ksk;
     void *d_bsk = nullptr, *d_tw = nullptr, *d_luts = nullptr;  // u64 words (Goldilocks) or f64 words (49-bit field)
     double *d_tw_half = nullptr, *d_bsk_lat = nullptr;          // 49-bit field: tables and key copy of the split-transform latency kernel
@@ -362,16 +448,37 @@ int upload_eval_keys(bmi_ctx *c);
 
 namespace {
 int gen_eval_keys(bmi_ctx *c, uint64_t seed);
+// fresh CSPRNG keys for this context (secret-class and public-class streams, never shared between them)
+int rekey_csprng(bmi_ctx *c) {
+    if (!c->rng_secret.fill_from_os() || !c->rng_public.fill_from_os())
+        return fail(c, -2, "getrandom() failed: no entropy source for key generation");
+    c->secure_rng = true;
+    c->enc_counter = 0;   // a new key: the (key, nonce) pairs of the new streams have never been used
+    return 0;
 }
-
-int bmi_keygen(bmi_ctx *c, uint64_t seed) {
-    if (!c) return -1;
+int gen_secret_keys(bmi_ctx *c, uint64_t seed) {
     const uint32_t n = c->P.n, kN = c->P.k * c->N;
     c->sk_small.assign(n, 0);
     c->sk_big.assign(kN, 0);
     Stream s1(seed, S_SK_SMALL, c->f), s2(seed, S_SK_BIG, c->f);
-    for (uint32_t i = 0; i < n; i++) c->sk_small[i] = s1.bit(i);
-    for (uint32_t i = 0; i < kN; i++) c->sk_big[i] = s2.bit(i);
+    RowRng r1(&s1, c->rng_secret, S_SK_SMALL, 0, c->secure_rng), r2(&s2, c->rng_secret, S_SK_BIG, 0, c->secure_rng);
+    for (uint32_t i = 0; i < n; i++) c->sk_small[i] = r1.bit(i);
+    for (uint32_t i = 0; i < kN; i++) c->sk_big[i] = r2.bit(i);
+    return 0;
+}
+}
+
+int bmi_keygen(bmi_ctx *c) {
+    if (!c) return -1;
+    if (int rc = rekey_csprng(c)) return rc;
+    gen_secret_keys(c, 0);
+    return gen_eval_keys(c, 0);
+}
+
+int bmi_keygen_insecure_deterministic(bmi_ctx *c, uint64_t seed) {
+    if (!c) return -1;
+    c->secure_rng = false;
+    gen_secret_keys(c, seed);
     return gen_eval_keys(c, seed);
 }
 
@@ -384,6 +491,11 @@ int bmi_keygen_from_secret(bmi_ctx *c, const uint64_t *sk_small, const uint64_t 
         if (sk_big[i] > 1) return fail(c, -1, "secret keys are binary");
     c->sk_small.assign(sk_small, sk_small + n);
     c->sk_big.assign(sk_big, sk_big + kN);
+    if (seed == 0) {            // production: masks and noise from the CSPRNG
+        if (int rc = rekey_csprng(c)) return rc;
+    } else {
+        c->secure_rng = false;  // test vectors: deterministic in seed
+    }
     return gen_eval_keys(c, seed);
 }
 
@@ -417,11 +529,14 @@ int gen_eval_keys(bmi_ctx *c, uint64_t seed) {
     const bmi_params &P = c->P;
     const uint32_t n = P.n, N = c->N, k = P.k, l = P.bs_levels, lk = P.ks_levels, rows = c->rows;
     c->seed = seed;
-    c->enc_counter = 0;
+    if (!c->secure_rng) c->enc_counter = 0;   // deterministic test keys: encryption i of a key set is reproducible
     // --- bootstrap key: GGSW(s_i) rows, standard domain.  B = sum_j A_j * S_j + E by shifted adds (S binary).
     c->bsk_std.assign((size_t)n * rows * (k + 1) * N, 0);
     {
-        Stream sm(seed, S_BSK_MASK, c->f), se(seed, S_BSK_NOISE, c->f);
+        const Stream sm_det(seed, S_BSK_MASK, c->f), se_det(seed, S_BSK_NOISE, c->f);
+        const Stream *smp = &sm_det, *sep = &se_det;
+        const ChaKey *ksec = &c->rng_secret, *kpub = &c->rng_public;
+        const bool secure = c->secure_rng;
         const Fq f = c->f;
         const u64 *skb = c->sk_big.data();
         const u64 *sks = c->sk_small.data();
@@ -429,6 +544,7 @@ int gen_eval_keys(bmi_ctx *c, uint64_t seed) {
         const double sigma = P.glwe_noise;
         const uint32_t bl = P.bs_base_log;
         parallel_for((size_t)n * rows, [=](size_t ir) {
+            RowRng sm(smp, *kpub, S_BSK_MASK, ir, secure), se(sep, *ksec, S_BSK_NOISE, ir, secure);
             const uint32_t i = (uint32_t)(ir / rows), r = (uint32_t)(ir % rows), comp = r / l, lev = r % l;
             u64 *row = bsk + ir * (k + 1) * N;
             u64 *B = row + (size_t)k * N;
@@ -445,7 +561,10 @@ int gen_eval_keys(bmi_ctx *c, uint64_t seed) {
     // --- keyswitch key
     c->ksk.assign((size_t)k * N * lk * (n + 1), 0);
     {
-        Stream sm(seed, S_KSK_MASK, c->f), se(seed, S_KSK_NOISE, c->f);
+        const Stream sm_det(seed, S_KSK_MASK, c->f), se_det(seed, S_KSK_NOISE, c->f);
+        const Stream *smp = &sm_det, *sep = &se_det;
+        const ChaKey *ksec = &c->rng_secret, *kpub = &c->rng_public;
+        const bool secure = c->secure_rng;
         const Fq f = c->f;
         const u64 *skb = c->sk_big.data();
         const u64 *sks = c->sk_small.data();
@@ -453,6 +572,7 @@ int gen_eval_keys(bmi_ctx *c, uint64_t seed) {
         const double sigma = P.lwe_noise;
         const uint32_t bl = P.ks_base_log;
         parallel_for((size_t)k * N * lk, [=](size_t jr) {
+            RowRng sm(smp, *kpub, S_KSK_MASK, jr, secure), se(sep, *ksec, S_KSK_NOISE, jr, secure);
             const uint32_t j = (uint32_t)(jr / lk), lev = (uint32_t)(jr % lk);
             u64 *row = ksk + jr * (n + 1);
             u64 b = se.gauss(jr, sigma);
@@ -562,8 +682,7 @@ int bmi_import_keys(bmi_ctx *c, const uint64_t *sk_small, const uint64_t *sk_big
         c->sk_small.clear();
         c->sk_big.clear();
     }
-    c->seed = 0x1234567ULL;  // encryption randomness stream of an imported key set (bmi_encrypt is still deterministic)
-    c->enc_counter = 0;
+    if (int rc = rekey_csprng(c)) return rc;   // encryptions under an imported key set draw fresh CSPRNG randomness
     return upload_eval_keys(c);
 }
 
@@ -590,13 +709,17 @@ int bmi_encrypt(bmi_ctx *c, const int64_t *msgs, uint32_t count, uint32_t delta_
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
     if (!c->have_secret) return fail(c, -1, "evaluation-only context: it holds no secret key");
     if (delta_log >= c->f.bits - 1) return fail(c, -1, "delta_log out of range");
-    Stream sm(c->seed, S_ENC_MASK, c->f), se(c->seed, S_ENC_NOISE, c->f);
+    const Stream sm_det(c->seed, S_ENC_MASK, c->f), se_det(c->seed, S_ENC_NOISE, c->f);
+    const Stream *smp = &sm_det, *sep = &se_det;
+    const ChaKey *ksec = &c->rng_secret, *kpub = &c->rng_public;
+    const bool secure = c->secure_rng;
     const Fq f = c->f;
     const uint32_t dim = c->big_n;
-    const u64 first = c->enc_counter;
+    const u64 first = c->enc_counter;   // secure contexts: never reset while the CSPRNG keys live (one nonce per ciphertext)
     const u64 *key = c->sk_big.data();
     const double sigma = c->P.glwe_noise;
     parallel_for(count, [=](size_t i) {
+        RowRng sm(smp, *kpub, S_ENC_MASK, first + i, secure), se(sep, *ksec, S_ENC_NOISE, first + i, secure);
         u64 *ct = ct_out + i * (dim + 1);
         const u64 torus = f.mul(f.from_i64(msgs[i]), (u64)1 << delta_log);
         u64 b = f.add(torus, se.gauss(first + i, sigma));

@@ -63,10 +63,19 @@ void bmi_ctx_destroy(bmi_ctx *ctx);
 const char *bmi_last_error(const bmi_ctx *ctx);
 int bmi_get_params(const bmi_ctx *ctx, bmi_params *out);
 
-/* replaces circuit.keygen() (main.py:177).  Deterministic in `seed` (the reference's analogue is the
- * insecure key cache, qfloat_matrix_inversion.py:997-998).  Generates both secret keys, the bootstrap
- * key (uploaded and transformed to the NTT domain on the GPU) and the keyswitch key. */
-int bmi_keygen(bmi_ctx *ctx, uint64_t seed);
+/* replaces circuit.keygen() (main.py:177).  Generates both secret keys, the bootstrap key (uploaded and transformed
+ * to the NTT domain on the GPU) and the keyswitch key.  All randomness comes from a CSPRNG: ChaCha20 keyed from the
+ * operating system (getrandom), with one key for secret material (key bits, noise) and an independent one for the
+ * public masks, so the evaluation keys reveal nothing about the secret streams.  bmi_encrypt then draws fresh
+ * mask + noise for every ciphertext from the same generators (one nonce per ciphertext, never reused). */
+int bmi_keygen(bmi_ctx *ctx);
+/* TEST ONLY - NOT CRYPTOGRAPHIC.  The same key set, deterministic in `seed`: every word is a counter-indexed
+ * splitmix64 output (an invertible map: public key words reveal the seed and with it the secret keys), and
+ * bmi_encrypt under such a key set is deterministic too (ciphertext i of a key set repeats its mask and noise).  It
+ * exists so that oracle/tfhe_oracle.c can reproduce keys and ciphertexts bit for bit in the parity tests and so that
+ * every rank of a benchmark holds the same keys without an exchange (the reference's analogue: Concrete's
+ * use_insecure_key_cache, qfloat_matrix_inversion.py:997-998).  Never use it for data that matters. */
+int bmi_keygen_insecure_deterministic(bmi_ctx *ctx, uint64_t seed);
 /* Test hook: copies out the secret keys and the standard-domain evaluation keys.
  * Sizes: sk_small[n], sk_big[k*N], bsk[n*(k+1)*l*(k+1)*N], ksk[k*N*ks_levels*(n+1)]; any may be NULL. */
 int bmi_export_keys(const bmi_ctx *ctx, uint64_t *sk_small, uint64_t *sk_big, uint64_t *bsk, uint64_t *ksk);
@@ -77,9 +86,10 @@ int bmi_export_keys(const bmi_ctx *ctx, uint64_t *sk_small, uint64_t *sk_big, ui
  * qfloat_matrix_inversion.py:997-998). */
 int bmi_import_keys(bmi_ctx *ctx, const uint64_t *sk_small, const uint64_t *sk_big, const uint64_t *bsk, const uint64_t *ksk);
 
-/* Evaluation keys for secret keys made elsewhere (binary, sizes as in bmi_export_keys), deterministic in `seed`: the
- * trusted-benchmark half of interoperating with a Concrete client, whose LWE secret keys are binary vectors too
- * (SURVEY.md section 8 f4). */
+/* Evaluation keys for secret keys made elsewhere (binary, sizes as in bmi_export_keys): the trusted-benchmark half of
+ * interoperating with a Concrete client, whose LWE secret keys are binary vectors too.
+ * seed = 0: masks and noise from the CSPRNG (production).  seed != 0: deterministic test vectors, NOT cryptographic
+ * (same caveats as bmi_keygen_insecure_deterministic). */
 int bmi_keygen_from_secret(bmi_ctx *ctx, const uint64_t *sk_small, const uint64_t *sk_big, uint64_t seed);
 /* 2^64-torus interop (context-free, host): ciphertext words as Concrete stores them (u64, the torus scaled by 2^64)
  * to words mod q and back, by the modulus switch round(x * q / 2^64) resp. round(x * 2^64 / q).  A message m * 2^(63-p)
@@ -88,7 +98,9 @@ int bmi_keygen_from_secret(bmi_ctx *ctx, const uint64_t *sk_small, const uint64_
 int bmi_torus64_to_field(uint32_t q_bits, const uint64_t *in, uint64_t words, uint64_t *out);
 int bmi_field_to_torus64(uint32_t q_bits, const uint64_t *in, uint64_t words, uint64_t *out);
 
-/* replaces circuit.encrypt (main.py:76): big-key LWE encryptions of msgs[i] * 2^delta_log. */
+/* replaces circuit.encrypt (main.py:76): big-key LWE encryptions of msgs[i] * 2^delta_log.  Fresh CSPRNG mask and noise
+ * per ciphertext, except under bmi_keygen_insecure_deterministic keys (deterministic, test only).  Key sets loaded
+ * with bmi_import_keys always encrypt from the CSPRNG. */
 int bmi_encrypt(bmi_ctx *ctx, const int64_t *msgs, uint32_t count, uint32_t delta_log, uint64_t *ct_out);
 /* replaces circuit.decrypt (main.py:86): msgs[i] = round(phase / 2^delta_log), signed. */
 int bmi_decrypt(const bmi_ctx *ctx, const uint64_t *ct_in, uint32_t count, uint32_t delta_log, int64_t *msgs);
@@ -149,6 +161,19 @@ int bmi_set_kernel_variant(bmi_ctx *ctx, int variant);
 /* Selects the keyswitch kernel: 0 = auto (int8 matrix-core product when the parameter set allows it),
  * 1 = scalar 96-bit multiply-accumulate kernel. */
 int bmi_set_keyswitch_variant(bmi_ctx *ctx, int variant);
+
+/* ---- compiler passes on a traced circuit in flat (CSR) form; context-free, CPU only -----------------------------
+ * What fhe.Compiler(...).compile does inside Concrete (main.py:53-66) for this path.  A circuit has n_in input leaves
+ * and n_nodes look-ups in creation (= topological) order; look-up i reads the leaves term_leaf[node_ptr[i] ..
+ * node_ptr[i+1]) and produces leaf n_in + i.
+ * bmi_circuit_prune: live_node[i] = 1 iff an output (out_leaf[0 .. n_out_terms)) depends on look-up i.
+ * bmi_circuit_schedule: level (1 .. depth) of every look-up; same depth as the ASAP schedule, but nodes with slack
+ * are moved out of levels that would otherwise need one more kernel round (`round_` ciphertexts per latency-kernel
+ * round up to two rounds, `wide_round` per throughput-kernel round beyond). */
+int bmi_circuit_prune(uint32_t n_in, uint32_t n_nodes, const int64_t *node_ptr, const int32_t *term_leaf,
+                      const int32_t *out_leaf, uint64_t n_out_terms, uint8_t *live_node);
+int bmi_circuit_schedule(uint32_t n_in, uint32_t n_nodes, const int64_t *node_ptr, const int32_t *term_leaf,
+                         uint32_t round_, uint32_t wide_round, int32_t *level_out, int32_t *depth_out);
 
 /* bytes of device memory held by the keys (bootstrap key NTT-domain, keyswitch key) */
 int bmi_key_bytes(const bmi_ctx *ctx, uint64_t *bsk_bytes, uint64_t *ksk_bytes);
