@@ -13,7 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libbmi_tfhe.so")
 Q = 0xFFFFFFFF00000001  # Goldilocks modulus (q_bits = 64)
-MODULUS = {64: 0xFFFFFFFF00000001, 49: 562949952700417}
+TORUS64 = 65                      # bmi_params.q_bits value for q = 2^64 exactly (BMI_Q_TORUS64, Concrete's torus)
+MODULUS = {64: 0xFFFFFFFF00000001, 49: 562949952700417, TORUS64: 1 << 64}
 
 
 class Params(C.Structure):
@@ -170,7 +171,7 @@ def default_params(q_bits=None, **kw):
     lib = load_library()
     rc = lib.bmi_default_params(C.byref(P)) if q_bits is None else lib.bmi_default_params_for(int(q_bits), C.byref(P))
     if rc != 0:
-        raise BmiError("unsupported q_bits")
+        raise BmiError("unsupported q_bits (64, 49 or TORUS64 = 65)")
     for k, v in kw.items():
         setattr(P, k, v)
     return P
@@ -206,10 +207,11 @@ class Engine:
         self._luts = {}
         self.q_bits = self.P.q_bits or 64
         self.modulus = MODULUS[self.q_bits]
+        self.log_q = 49 if self.q_bits == 49 else 64     # bits of the torus messages are scaled on
 
     def delta_log(self, msg_bits=4):
-        """scaling exponent of a signed msg_bits-bit message space: q_bits - 1 - msg_bits (59 / 44 for 4 bits)"""
-        return self.q_bits - 1 - msg_bits
+        """scaling exponent of a signed msg_bits-bit message space: log_q - 1 - msg_bits (59 / 44 for 4 bits)"""
+        return self.log_q - 1 - msg_bits
 
     def close(self):
         if getattr(self, "h", None):

@@ -40,12 +40,14 @@ inline u64 mix64(u64 z) {
 struct Fq {
     u64 q = gl::P;
     uint32_t bits = 64;
-    u64 add(u64 a, u64 b) const { return (u64)(((unsigned __int128)a + b) % q); }
-    u64 sub(u64 a, u64 b) const { return a >= b ? a - b : (u64)((unsigned __int128)a + q - b); }
-    u64 neg(u64 a) const { return a ? q - a : 0; }
-    u64 mul(u64 a, u64 b) const { return (u64)(((unsigned __int128)a * b) % q); }
-    u64 from_i64(long long v) const { return v >= 0 ? (u64)v % q : q - ((u64)(-v) % q); }
-    long long centered(u64 a) const { return a > (q >> 1) ? (long long)(a - q) : (long long)a; }
+    bool torus = false;   // q = 2^64 exactly (q field unused): plain wrap-around arithmetic
+    u64 add(u64 a, u64 b) const { return torus ? a + b : (u64)(((unsigned __int128)a + b) % q); }
+    u64 sub(u64 a, u64 b) const { return torus ? a - b : (a >= b ? a - b : (u64)((unsigned __int128)a + q - b)); }
+    u64 neg(u64 a) const { return torus ? (u64)0 - a : (a ? q - a : 0); }
+    u64 mul(u64 a, u64 b) const { return torus ? a * b : (u64)(((unsigned __int128)a * b) % q); }
+    u64 from_i64(long long v) const { return torus ? (u64)v : (v >= 0 ? (u64)v % q : q - ((u64)(-v) % q)); }
+    long long centered(u64 a) const { return torus ? (long long)a : (a > (q >> 1) ? (long long)(a - q) : (long long)a); }
+    bool canonical(u64 a) const { return torus || a < q; }
     u64 pow(u64 b, u64 e) const {
         u64 r = 1;
         while (e) {
@@ -65,6 +67,7 @@ struct Stream {
     u64 bit(u64 idx) const { return raw(idx) & 1; }
     u64 uniform(u64 idx) const {
         u64 u = raw(idx);
+        if (f.torus) return u;
         return f.bits == 64 ? (u >= f.q ? u - f.q : u) : u % f.q;
     }
     u64 gauss(u64 idx, double sigma) const {  // Box-Muller, rounded to an element of Z_q
@@ -136,7 +139,7 @@ struct ChaStream {
     u64 uniform(const Fq &f) {   // rejection sampling: exactly uniform on [0, q)
         for (;;) {
             const u64 u = f.bits == 64 ? next64() : next64() >> (64 - f.bits);
-            if (u < f.q) return u;
+            if (f.torus || u < f.q) return u;
         }
     }
     u64 gauss(const Fq &f, double sigma) {
@@ -211,9 +214,10 @@ struct bmi_ctx {
     signed char *d_ks_limbs = nullptr, *d_ks_digits = nullptr;
     int *d_ks_sums = nullptr;
     size_t ks_digits_bytes = 0, ks_sums_bytes = 0;
-    uint32_t ks_limbs() const { return f64() ? bmi49::KS_LIMBS : bmi::KS_LIMBS; }
+    uint32_t ks_limbs() const { return f64() ? bmi49::KS_LIMBS : (f.torus ? bmit::KS_LIMBS : bmi::KS_LIMBS); }
     mutable std::string err;
     bool f64() const { return f.bits == 49; }
+    bool t64() const { return f.torus; }
 };
 
 namespace {
@@ -342,6 +346,7 @@ std::vector<u64> build_twiddles_quad(const Fq &f) {
 }
 
 bool params_supported(const bmi_params &P, std::string &why) {
+    if (P.q_bits == BMI_Q_TORUS64 && P.log_N != 10) { why = "the 2^64 torus has a HIP kernel for N = 1024 only"; return false; }
     if (P.log_N != 10 && !((P.log_N == 11 || P.log_N == 12) && P.q_bits == 49)) {
         why = "log_N must be 10 (N = 1024), or 11 / 12 (N = 2048 / 4096) on the 49-bit field";
         return false;
@@ -349,7 +354,10 @@ bool params_supported(const bmi_params &P, std::string &why) {
     if (P.k != 1) { why = "only k = 1 has a HIP kernel in this build"; return false; }
     if (P.bs_levels != 3 || P.bs_base_log != 15) { why = "only (l, Bg) = (3, 2^15) has a HIP kernel in this build"; return false; }
     if (P.n == 0 || P.n > 639) { why = "n must be in [1, 639]"; return false; }
-    if (P.q_bits != 0 && P.q_bits != 64 && P.q_bits != 49) { why = "q_bits must be 64 (2^64-2^32+1) or 49 (2^49-720895)"; return false; }
+    if (P.q_bits != 0 && P.q_bits != 64 && P.q_bits != 49 && P.q_bits != BMI_Q_TORUS64) {
+        why = "q_bits must be 64 (2^64-2^32+1), 49 (2^49-720895) or BMI_Q_TORUS64 (2^64)";
+        return false;
+    }
     const uint32_t qb = P.q_bits == 49 ? 49 : 64;
     if (P.ks_levels * P.ks_base_log >= qb || P.ks_base_log > 7 || P.ks_levels == 0) { why = "unsupported keyswitch decomposition"; return false; }
     return true;
@@ -360,8 +368,8 @@ bool params_supported(const bmi_params &P, std::string &why) {
 extern "C" {
 
 int bmi_default_params_for(uint32_t q_bits, bmi_params *out) {
-    if (!out || (q_bits != 64 && q_bits != 49)) return -1;
-    // same shape for both fields; the 49-bit modulus keeps the absolute bootstrap-key noise above the integer grid
+    if (!out || (q_bits != 64 && q_bits != 49 && q_bits != BMI_Q_TORUS64)) return -1;
+    // same shape for every modulus; the 49-bit modulus keeps the absolute bootstrap-key noise above the integer grid
     *out = bmi_params{630, 10, 1, 3, 15, 8, 4, q_bits, std::ldexp(1.0, -25), std::ldexp(1.0, q_bits == 49 ? -40 : -44)};
     return 0;
 }
@@ -384,6 +392,7 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
     c->P = *params;
     if (c->P.q_bits == 0) c->P.q_bits = 64;
     if (c->P.q_bits == 49) c->f = Fq{f49::Q, 49};
+    if (c->P.q_bits == BMI_Q_TORUS64) c->f = Fq{0, 64, true};
     c->device = device;
     c->N = 1u << params->log_N;
     c->big_n = params->k * c->N;
@@ -397,8 +406,9 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice failed");
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
     {
-        const bool f64 = c->f64();
-        const std::vector<u64> tw = f64 ? build_twiddles(c->f, nttf::PSI_U, nttf::PSI_INV_U, nttf::N_INV_U)
+        const bool f64 = c->f64() || c->t64();   // the torus kernels transform mod the 49-bit prime as well
+        const Fq f49q{f49::Q, 49};
+        const std::vector<u64> tw = f64 ? build_twiddles(f49q, nttf::PSI_U, nttf::PSI_INV_U, nttf::N_INV_U)
                                         : build_twiddles(c->f, nttw::PSI, nttw::PSI_INV, nttw::N_INV);
         const std::vector<double> twd = f64 ? to_centred_doubles(tw) : std::vector<double>();
         const void *src = f64 ? (const void *)twd.data() : (const void *)tw.data();
@@ -595,12 +605,21 @@ int upload_eval_keys(bmi_ctx *c) {
     const uint32_t n = P.n, N = c->N, k = P.k, lk = P.ks_levels;
     // --- upload: bootstrap key -> NTT domain on the GPU; keyswitch key with padded rows
     const size_t bsk_words = c->bsk_std.size();
-    if (!c->d_bsk && !c->wide() && !c->quad()) HIP_OK(c, hipMalloc(&c->d_bsk, bsk_words * 8));
+    if (!c->d_bsk && !c->wide() && !c->quad() && !c->t64()) HIP_OK(c, hipMalloc(&c->d_bsk, bsk_words * 8));
     u64 *d_tmp = nullptr;
     HIP_OK(c, hipMalloc(&d_tmp, bsk_words * sizeof(u64)));
     HIP_OK(c, hipMemcpy(d_tmp, c->bsk_std.data(), bsk_words * sizeof(u64), hipMemcpyHostToDevice));
     int rc = 0;
-    if (c->wide() || c->quad()) {  // N = 2048 / 4096: one key copy, in the slot order of k_blind_rotate_wide49 / quad49
+    if (c->t64()) {  // 2^64 torus: BSK_LIMBS transform-domain limb polynomials per key polynomial
+        if (c->d_bsk) { (void)hipFree(c->d_bsk); c->d_bsk = nullptr; }
+        if (hipMalloc(&c->d_bsk, bsk_words * 8 * bmit::BSK_LIMBS) != hipSuccess) {
+            (void)hipFree(d_tmp);
+            return fail(c, -2, "hipMalloc(torus limb key) failed");
+        }
+        rc = bmit::launch_bsk_to_limbs(d_tmp, (double *)c->d_bsk, (const double *)c->d_tw, (uint32_t)(bsk_words / N),
+                                       bmit::BSK_LIMBS, c->stream);
+        if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_limbs launch failed"); }
+    } else if (c->wide() || c->quad()) {  // N = 2048 / 4096: one key copy, in the slot order of k_blind_rotate_wide49 / quad49
         if (!c->d_bsk_lat && hipMalloc(&c->d_bsk_lat, bsk_words * 8) != hipSuccess) {
             (void)hipFree(d_tmp);
             return fail(c, -2, "hipMalloc(wide key) failed");
@@ -647,7 +666,7 @@ int upload_eval_keys(bmi_ctx *c) {
         const uint32_t cbs = (n + 1 + 31) / 32;
         const size_t bytes = (size_t)cbs * (ksk_rows / 32) * c->ks_limbs() * 1024;
         if (!c->d_ks_limbs) HIP_OK(c, hipMalloc(&c->d_ks_limbs, bytes));
-        rc = (c->f64() ? bmi49::launch_ksk_to_limbs : bmi::launch_ksk_to_limbs)(c->d_ksk, c->d_ks_limbs, (uint32_t)ksk_rows, n,
+        rc = (c->f64() ? bmi49::launch_ksk_to_limbs : (c->t64() ? bmit::launch_ksk_to_limbs : bmi::launch_ksk_to_limbs))(c->d_ksk, c->d_ks_limbs, (uint32_t)ksk_rows, n,
                                                                                 c->ks_stride, c->stream);
         if (rc) return fail(c, -2, "ksk_to_limbs launch failed");
         HIP_OK(c, hipStreamSynchronize(c->stream));
@@ -664,9 +683,9 @@ int bmi_import_keys(bmi_ctx *c, const uint64_t *sk_small, const uint64_t *sk_big
     const bmi_params &P = c->P;
     const size_t bsk_words = (size_t)P.n * c->rows * (P.k + 1) * c->N, ksk_words = (size_t)c->big_n * P.ks_levels * (P.n + 1);
     for (size_t i = 0; i < bsk_words; i++)
-        if (bsk[i] >= c->f.q) return fail(c, -1, "bootstrap key word not reduced mod q");
+        if (!c->f.canonical(bsk[i])) return fail(c, -1, "bootstrap key word not reduced mod q");
     for (size_t i = 0; i < ksk_words; i++)
-        if (ksk[i] >= c->f.q) return fail(c, -1, "keyswitch key word not reduced mod q");
+        if (!c->f.canonical(ksk[i])) return fail(c, -1, "keyswitch key word not reduced mod q");
     c->have_keys = false;
     c->bsk_std.assign(bsk, bsk + bsk_words);
     c->ksk.assign(ksk, ksk + ksk_words);
@@ -699,7 +718,7 @@ int bmi_export_keys(const bmi_ctx *c, uint64_t *sk_small, uint64_t *sk_big, uint
 
 int bmi_key_bytes(const bmi_ctx *c, uint64_t *bsk_bytes, uint64_t *ksk_bytes) {
     if (!c) return -1;
-    if (bsk_bytes) *bsk_bytes = (u64)c->P.n * c->rows * (c->P.k + 1) * c->N * 8;
+    if (bsk_bytes) *bsk_bytes = (u64)c->P.n * c->rows * (c->P.k + 1) * c->N * 8 * (c->t64() ? bmit::BSK_LIMBS : 1);
     if (ksk_bytes) *ksk_bytes = (u64)c->big_n * c->P.ks_levels * (c->P.n + 1) * 8;
     return 0;
 }
@@ -852,7 +871,7 @@ int keyswitch_mfma(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64_t *d
     if (count == 0) return 0;
     int rc = ensure_ks_mfma(c, count);
     if (rc) return rc;
-    rc = (c->f64() ? bmi49::launch_keyswitch_mfma : bmi::launch_keyswitch_mfma)(
+    rc = (c->f64() ? bmi49::launch_keyswitch_mfma : (c->t64() ? bmit::launch_keyswitch_mfma : bmi::launch_keyswitch_mfma))(
         d_in, c->d_ks_limbs, c->d_ks_digits, c->d_ks_sums, d_small, ks_mfma_slices(c, count), count, c->P.n, c->big_n,
         c->P.ks_levels, c->P.ks_base_log, stream);
     return rc ? fail(c, -2, std::string("keyswitch (matrix cores) launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
@@ -882,7 +901,7 @@ int bmi_keyswitch_batch(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64
         HIP_OK(c, hipMalloc(&c->d_ks_partial, cap));
         c->ks_partial_bytes = cap;
     }
-    int rc = (c->f64() ? bmi49::launch_keyswitch : bmi::launch_keyswitch)(
+    int rc = (c->f64() ? bmi49::launch_keyswitch : (c->t64() ? bmit::launch_keyswitch : bmi::launch_keyswitch))(
         d_in, c->d_ksk, c->d_ks_bias, d_small, slices > 1 ? c->d_ks_partial : nullptr, slices, count, c->P.n, c->big_n,
         c->P.ks_levels, c->P.ks_base_log, c->ks_stride, (hipStream_t)stream);
     return rc ? fail(c, -2, std::string("keyswitch launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
@@ -897,6 +916,11 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     // with wave-pair work, the throughput kernel beyond that (49-bit field: the exchange-once form).
     const bool latency = c->variant == 2 || (c->variant == 0 && count <= c->lat_threshold);
     int rc;
+    if (c->t64()) {   // 2^64 torus: one kernel for every batch size
+        rc = bmit::launch_blind_rotate(d_small, d_lut_ids, (const u64 *)c->d_luts, (const double *)c->d_bsk,
+                                       (const double *)c->d_tw, d_out, count, c->P.n, bmit::BSK_LIMBS, (hipStream_t)stream);
+        return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+    }
     if (c->f64()) {
         const double *luts = (const double *)c->d_luts, *bsk = (const double *)c->d_bsk, *tw = (const double *)c->d_tw;
         hipStream_t st = (hipStream_t)stream;
@@ -949,7 +973,7 @@ int bmi_lincomb_batch(bmi_ctx *c, const uint64_t *d_store, const uint32_t *d_row
                       void *stream) {
     if (!c || (count && (!d_store || !d_row_ptr || !d_const_body || !d_out))) return -1;
     HIP_OK(c, hipSetDevice(c->device));
-    int rc = (c->f64() ? bmi49::launch_lincomb : bmi::launch_lincomb)(d_store, d_row_ptr, d_idx, (const i64 *)d_coef,
+    int rc = (c->f64() ? bmi49::launch_lincomb : (c->t64() ? bmit::launch_lincomb : bmi::launch_lincomb))(d_store, d_row_ptr, d_idx, (const i64 *)d_coef,
                                                                       d_const_body, d_out, count, c->big_n + 1,
                                                                       (hipStream_t)stream);
     return rc ? fail(c, -2, std::string("lincomb launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
@@ -1058,6 +1082,7 @@ int bmi_blind_rotate_batch_host(bmi_ctx *c, const uint64_t *small_in, const uint
 int bmi_negacyclic_mul_host(bmi_ctx *c, const uint64_t *a, const uint64_t *b, uint32_t count, uint64_t *out) {
     if (!c || !a || !b || !out) return -1;
     if (c->wide() || c->quad()) return fail(c, -1, "the transform test hook exists for N = 1024 only");
+    if (c->t64()) return fail(c, -1, "no transform exists mod 2^64: the test hook covers the two prime fields");
     HIP_OK(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)count * c->N * 8;
     u64 *da = nullptr, *db = nullptr, *dc = nullptr;

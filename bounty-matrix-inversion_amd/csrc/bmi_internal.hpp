@@ -129,3 +129,25 @@ int launch_keyswitch_mfma(const u64 *in, const signed char *limbs, signed char *
 int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *idx, const i64 *coef,
                    const u64 *const_body, u64 *out, uint32_t count, uint32_t width, hipStream_t s);
 }  // namespace bmi49
+
+// The 2^64 torus (bmi_kernels_t64.hip): ciphertexts, test polynomials and keyswitch key are plain u64 words; the
+// bootstrap key is LIMBS transform-domain f64 limb polynomials per key polynomial ([poly][limb][N]).
+namespace bmit {
+using gl::i64;
+using gl::u64;
+constexpr int BSK_LIMBS = 3;        // balanced 22-bit limbs of a 64-bit key word
+constexpr uint32_t KS_LIMBS = 9;    // balanced base-256 limbs of a keyswitch-key word
+int launch_bsk_to_limbs(const u64 *std_polys, double *limb_polys, const double *g_tw, uint32_t n_polys, int limbs,
+                        hipStream_t s);
+int launch_blind_rotate(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_limbs,
+                        const double *g_tw, u64 *out, uint32_t count, uint32_t n, int limbs, hipStream_t s);
+int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
+                     uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,
+                     hipStream_t s);
+int launch_ksk_to_limbs(const u64 *ksk, signed char *limbs, uint32_t rows, uint32_t n, uint32_t ks_stride, hipStream_t s);
+int launch_keyswitch_mfma(const u64 *in, const signed char *limbs, signed char *digits, int *sums, u64 *out,
+                          uint32_t slices, uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels,
+                          uint32_t base_log, hipStream_t s);
+int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *idx, const i64 *coef,
+                   const u64 *const_body, u64 *out, uint32_t count, uint32_t width, hipStream_t s);
+}  // namespace bmit

@@ -1,0 +1,333 @@
+// HIP kernels (gfx950) for ciphertexts on the 2^64 TORUS (q = 2^64 exactly: the modulus Concrete computes on; SURVEY.md
+// section 7 hard part 1, option A).  No transform exists mod 2^64, so the external product is computed EXACTLY over the
+// integers and only then reduced:
+//
+//   * the six digit polynomials of a CMUX are small (|d| <= 2^14) and are transformed once, mod p = 2^49 - 720895, with
+//     the f64 wave transform of ntt_wave_f64.hpp (the machinery of the 49-bit field kernels);
+//   * every 64-bit bootstrap-key word k (read as a signed integer) is split once, at key upload, into LIMBS balanced
+//     limbs of T64_LIMB_BITS bits, k = sum_j k_j 2^(22 j), and each limb polynomial is stored in the transform domain;
+//   * per limb, the sum over the six GGSW rows of digit x limb is an integer of magnitude
+//     < 6 * 1024 * 2^14 * 2^21 = 2^47.585 < p / 2, so its centred residue mod p IS that integer (exact, no rounding);
+//   * the limb results are recombined with shifts and added to the accumulator mod 2^64.
+//
+// Cost against the 49-bit field kernel: the same 6 forward transforms, LIMBS x the multiply-accumulates, key bytes and
+// inverse transforms.  Structure of k_blind_rotate_t64 = k_blind_rotate_tpx49 (a pair of wavefronts per ciphertext,
+// wavefront c owns INPUT polynomial c, one exchange per inverse transform through the pair's LDS flags), with the three
+// transformed digit polynomials held in registers across the limb loop and the accumulator kept as u64 in LDS.
+//
+// Decomposition (identical to the oracle's 64-bit rule, oracle/tfhe_oracle.c ora_decompose): centred lift = the word as
+// int64, rounded half-up to its top 45 bits, signed digits in [-2^14, 2^14), the top digit absorbing the last carry.
+#include <hip/hip_runtime.h>
+
+#include "bmi_internal.hpp"
+#include "ks_lincomb.hpp"
+#include "ks_mfma.hpp"
+#include "ntt_wave_f64.hpp"
+
+using f49::i64;
+using f49::u64;
+using namespace nttf;
+
+namespace {
+
+constexpr int T64_LIMB_BITS = 22;
+constexpr int T64_CTS = 4;
+constexpr int T64_AT_WORDS = 160;
+constexpr int T64_LDS_WORDS = TW_WORDS + 2 * T64_CTS * (SCRATCH_WORDS + N) + T64_CTS * T64_AT_WORDS + 4 * T64_CTS;
+
+__device__ __forceinline__ uint32_t modswitch_t64(u64 a) {   // round(a * 2N / 2^64) mod 2N, ties up
+    return (uint32_t)(((a >> (63 - (LOG_N + 1))) + 1) >> 1) & (2 * N - 1);
+}
+
+// balanced limb j of a signed 64-bit word: k = sum_j limb_j 2^(22 j), limb_j in [-2^21, 2^21) (the last one takes the rest)
+__host__ __device__ __forceinline__ i64 limb_of(i64 k, int j, int limbs) {
+    constexpr i64 B = (i64)1 << T64_LIMB_BITS, H = B >> 1;
+    for (int t = 0; t < j; t++) {
+        const i64 d = ((k + H) & (B - 1)) - H;
+        k = (k - d) >> T64_LIMB_BITS;
+    }
+    if (j == limbs - 1) return k;
+    return ((k + H) & (B - 1)) - H;
+}
+
+// standard-domain GGSW polynomials (u64 torus words) -> LIMBS transform-domain limb polynomials each, lane layout
+__global__ void __launch_bounds__(256) k_bsk_to_limbs_t64(const u64 *__restrict__ std_polys, double *__restrict__ limb_polys,
+                                                          const double *__restrict__ g_tw, uint32_t n_polys, int limbs) {
+    __shared__ double lds[TW_WORDS + 4 * SCRATCH_WORDS];
+    for (int i = threadIdx.x; i < TW_WORDS; i += blockDim.x) lds[i] = g_tw[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t item = blockIdx.x * 4 + wave;            // (polynomial, limb)
+    if (item >= n_polys * (uint32_t)limbs) return;
+    const uint32_t poly = item / limbs;
+    const int j = (int)(item % limbs);
+    double *scratch = lds + TW_WORDS + wave * SCRATCH_WORDS;
+    double x[16];
+    static_for<0, 16>([&](auto J) { x[J] = (double)limb_of((i64)std_polys[(size_t)poly * N + lane + 64 * J], j, limbs); });
+    forward(x, lane, lds, scratch);
+    static_for<0, 16>([&](auto V) { limb_polys[(size_t)item * N + eval_offset(lane, V)] = f49::red(x[V]); });
+}
+
+__device__ __forceinline__ void pair_post(uint32_t *flag, uint32_t v) {
+    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// one opaque asm block (as C++ control flow the poll loop makes the register allocator spill, see bmi_kernels_f64.hip)
+__device__ __forceinline__ void pair_wait(uint32_t *flag, uint32_t v) {
+    const uint32_t addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)flag;
+    uint32_t tmp;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %0, %1\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u32 vcc, %2, %0\n\t"
+        "s_cbranch_vccnz 2f\n\t"
+        "s_sleep 1\n\t"
+        "s_branch 1b\n"
+        "2:"
+        : "=&v"(tmp)
+        : "v"(addr), "s"(v)
+        : "vcc", "memory");
+}
+__device__ __forceinline__ void pin() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// exact integer |v| < 2^52 held in a double -> two's complement 64-bit word
+__device__ __forceinline__ u64 f64_to_word(double v) {
+    const double hi = __builtin_floor(v * 0x1p-32);
+    const double lo = __builtin_fma(-0x1p32, hi, v);          // in [0, 2^32)
+    return ((u64)(uint32_t)(int32_t)hi << 32) | (u64)(uint32_t)lo;
+}
+// signed integer |t| < 2^52 held in an int64 -> double (exact)
+__device__ __forceinline__ double word_to_f64(i64 t) {
+    return __builtin_fma((double)(int32_t)(t >> 32), 0x1p32, (double)(uint32_t)t);
+}
+
+template <int LIMBS>
+__global__ void __launch_bounds__(128 * T64_CTS)
+    k_blind_rotate_t64(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids, const u64 *__restrict__ luts,
+                       const double *__restrict__ bsk, const double *__restrict__ g_tw, u64 *__restrict__ out,
+                       uint32_t count, uint32_t n) {
+    constexpr int CTS = T64_CTS;
+    extern __shared__ double lds[];
+    double *tiles = lds + TW_WORDS;
+    u64 *accs = reinterpret_cast<u64 *>(tiles + 2 * CTS * SCRATCH_WORDS);
+    double *at_base = reinterpret_cast<double *>(accs + 2 * CTS * N);
+    uint32_t *flags = reinterpret_cast<uint32_t *>(at_base + CTS * T64_AT_WORDS);  // [2 CTS] published, [2 CTS] consumed
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ctl = wave >> 1, c = wave & 1;
+    if (threadIdx.x < 4 * CTS) flags[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < TW_WORDS; i += blockDim.x) lds[i] = g_tw[i];
+    const uint32_t ct_raw = blockIdx.x * CTS + ctl;
+    const bool live = ct_raw < count;
+    const uint32_t ct = live ? ct_raw : count - 1;
+    double *tile = tiles + wave * SCRATCH_WORDS;
+    const double *ptile = tiles + (wave ^ 1) * SCRATCH_WORDS;
+    u64 *accl = accs + wave * N;
+    uint16_t *at = reinterpret_cast<uint16_t *>(at_base + ctl * T64_AT_WORDS);
+    uint32_t *f_pub = flags + wave, *f_pub_partner = flags + (wave ^ 1);
+    uint32_t *f_ack = flags + 2 * CTS + wave, *f_ack_partner = flags + 2 * CTS + (wave ^ 1);
+    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
+    for (uint32_t i = lane + 64 * c; i <= n; i += 128) at[i] = (uint16_t)modswitch_t64(lwe[i]);
+    __syncthreads();
+    {
+        const u64 *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
+        const uint32_t bt = at[n];
+        static_for<0, 16>([&](auto J) {
+            const uint32_t e = (lane + 64 * J + bt) & (2 * N - 1);
+            const u64 v = tv[e & (N - 1)];
+            accl[lane + 64 * J] = c ? ((e & N) ? (u64)0 - v : v) : (u64)0;
+        });
+    }
+
+    uint32_t hand = 0;   // handshake counter of the pair (one per inverse transform)
+    for (uint32_t i = 0; i < n; i++) {
+#if BMI_TPX49_RESYNC
+        if (i % BMI_TPX49_RESYNC == 0) __syncthreads();  // keeps the four pairs on the same key rows (shared through L1)
+#endif
+        const uint32_t a_t = at[i];
+        // this wavefront's three GGSW rows: [row = 3 c + lev][column][limb][N]
+        const double *bsk_c = bsk + ((size_t)i * 12 + c * 6) * LIMBS * N;
+        __builtin_amdgcn_s_setprio(3);
+        wave_sync();
+        double r[16];
+        {
+            u64 vr[16], vs[16];  // all 32 reads in flight before the first use
+            static_for<0, 16>([&](auto J) {
+                vr[J] = accl[(lane + 64 * J + 2 * N - a_t) & (N - 1)];
+                vs[J] = accl[lane + 64 * J];
+            });
+            sched_fence();
+            static_for<0, 16>([&](auto J) {
+                const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
+                const u64 v = (e & N) ? (u64)0 - vr[J] : vr[J];
+                const i64 t = (i64)(v - vs[J]) >> 18;                                   // 46 signed bits
+                r[J] = __builtin_floor(__builtin_fma(word_to_f64(t), 0.5, 0.5));         // round half up to 45 bits
+            });
+        }
+        double X[3][16];   // the three digit polynomials, transform domain, live across the limb loop
+        static_for<0, 3>([&](auto LEV) {
+            constexpr int lev = 2 - LEV;  // least significant digit first
+            pin();
+            __builtin_amdgcn_s_setprio(lev + 1);
+            static_for<0, 16>([&](auto J) {
+                if constexpr (lev == 0) {
+                    X[0][J] = r[J];
+                } else {
+                    const double rn = __builtin_floor(__builtin_fma(r[J], 0x1p-15, 0.5));
+                    X[lev][J] = __builtin_fma(-32768.0, rn, r[J]);                       // digit in [-2^14, 2^14)
+                    r[J] = rn;
+                }
+            });
+            forward(X[lev], lane, lds, tile);
+        });
+        __builtin_amdgcn_s_setprio(0);
+        static_for<0, LIMBS>([&](auto JL) {
+            constexpr int j = JL;
+            // six key rows of this limb, partner's column first (its partial sum is published while the own column is
+            // still being multiplied): rows 0..2 = (lev, column c^1), rows 3..5 = (lev, column c); one row in flight
+            auto row_ptr = [&](int q) {
+                const int lev = q % 3, col = q < 3 ? (c ^ 1) : c;
+                return reinterpret_cast<const double2 *>(bsk_c + ((size_t)(lev * 2 + col) * LIMBS + j) * N);
+            };
+            double2 kb[2][8];
+            static_for<0, 8>([&](auto VP) { kb[0][VP] = row_ptr(0)[VP * 64 + lane]; });
+            double acc[16];
+            hand++;
+            static_for<0, 6>([&](auto Q) {
+                constexpr int q = Q, lev = q % 3, cur = q & 1;
+                if constexpr (q < 5) static_for<0, 8>([&](auto VP) { kb[cur ^ 1][VP] = row_ptr(q + 1)[VP * 64 + lane]; });
+                sched_fence();
+                static_for<0, 8>([&](auto VP) {
+                    const double m0 = f49::mul(X[lev][2 * VP], kb[cur][VP].x), m1 = f49::mul(X[lev][2 * VP + 1], kb[cur][VP].y);
+                    if constexpr (lev == 0) {
+                        acc[2 * VP] = m0;
+                        acc[2 * VP + 1] = m1;
+                    } else {
+                        acc[2 * VP] += m0;
+                        acc[2 * VP + 1] += m1;
+                    }
+                });
+                if constexpr (q == 2) {
+                    // the partner's partial goes through this wavefront's tile (free since the last transform)
+                    wave_sync();
+                    static_for<0, 8>([&](auto VP) {
+                        reinterpret_cast<double2 *>(tile)[VP * 64 + lane] = double2{acc[2 * VP], acc[2 * VP + 1]};
+                    });
+                    pair_post(f_pub, hand);
+                }
+                pin();
+            });
+            pair_wait(f_pub_partner, hand);
+            static_for<0, 8>([&](auto VP) {
+                const double2 p = reinterpret_cast<const double2 *>(ptile)[VP * 64 + lane];
+                acc[2 * VP] = f49::red(acc[2 * VP] + p.x);          // <= 2 * 3 * 1.4p before the reduction
+                acc[2 * VP + 1] = f49::red(acc[2 * VP + 1] + p.y);
+            });
+            pair_post(f_ack, hand);          // release: the reads above have landed
+            pair_wait(f_ack_partner, hand);  // the partner has read this tile: the inverse transform may overwrite it
+            inverse(acc, lane, lds, tile);
+            // the limb's exact integer result (|.| < 2^47.6 < p/2: the centred residue is the integer), shifted into place
+            static_for<0, 16>([&](auto J) {
+                accl[lane + 64 * J] += f64_to_word(f49::red(acc[J])) << (T64_LIMB_BITS * j);
+            });
+            pin();
+        });
+    }
+
+    if (!live) return;
+    wave_sync();
+    u64 *o = out + (size_t)ct * (N + 1);
+    if (c == 0) {
+        static_for<0, 16>([&](auto J) {
+            const uint32_t m = lane + 64 * J;
+            const u64 v = accl[m];
+            if (m == 0) o[0] = v;
+            else o[N - m] = (u64)0 - v;
+        });
+    } else if (lane == 0) {
+        o[N] = accl[0];
+    }
+}
+
+// keyswitch / linear combinations: wrap-around arithmetic, the oracle's 64-bit decomposition rule
+struct FieldT {
+    static __device__ __forceinline__ void digits(u64 a, uint32_t levels, uint32_t base_log, unsigned char *d) {
+        const uint32_t shift = 64 - levels * base_log;
+        const i64 B = (i64)1 << base_log, half = B >> 1;
+        const i64 c = (i64)a;
+        i64 r = (c >> shift) + ((c >> (shift - 1)) & 1);
+        for (int lev = (int)levels - 1; lev >= 1; lev--) {
+            i64 v = r & (B - 1);
+            r >>= base_log;
+            if (v >= half) { v -= B; r += 1; }
+            d[lev] = (unsigned char)(v + half);
+        }
+        d[0] = (unsigned char)(r + half);
+    }
+    static __device__ __forceinline__ i64 centered(u64 a) { return (i64)a; }
+    static __device__ __forceinline__ u64 add(u64 a, u64 b) { return a + b; }
+    static __device__ __forceinline__ u64 sub(u64 a, u64 b) { return a - b; }
+    static __device__ __forceinline__ u64 neg(u64 a) { return (u64)0 - a; }
+    static __device__ __forceinline__ u64 mul_small(i64 cf, u64 v) { return (u64)cf * v; }
+    static __device__ __forceinline__ u64 reduce96(uint32_t, u64 lo) { return lo; }
+    static __device__ __forceinline__ u64 reduce128(u64, u64 lo) { return lo; }
+};
+
+}  // namespace
+
+namespace bmit {
+
+#define BMIT_LAUNCH_CHECK()                     \
+    do {                                        \
+        hipError_t e__ = hipGetLastError();     \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+int launch_bsk_to_limbs(const u64 *std_polys, double *limb_polys, const double *g_tw, uint32_t n_polys, int limbs,
+                        hipStream_t s) {
+    if (limbs != 3) return (int)hipErrorInvalidValue;
+    const uint32_t items = n_polys * (uint32_t)limbs;
+    hipLaunchKernelGGL(k_bsk_to_limbs_t64, dim3((items + 3) / 4), dim3(256), 0, s, std_polys, limb_polys, g_tw, n_polys, limbs);
+    BMIT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_blind_rotate(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_limbs,
+                        const double *g_tw, u64 *out, uint32_t count, uint32_t n, int limbs, hipStream_t s) {
+    if (count == 0) return 0;
+    if (limbs != 3) return (int)hipErrorInvalidValue;
+    static std::atomic<uint64_t> configured{0};
+    const size_t lds = (size_t)T64_LDS_WORDS * sizeof(double);
+    auto kern = k_blind_rotate_t64<3>;
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
+    hipLaunchKernelGGL(kern, dim3((count + T64_CTS - 1) / T64_CTS), dim3(128 * T64_CTS), lds, s, small_cts, lut_ids, luts,
+                       bsk_limbs, g_tw, out, count, n);
+    BMIT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
+                     uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,
+                     hipStream_t s) {
+    return ksl::launch_keyswitch<FieldT>(in, ksk, ks_bias, out, partial, slices, count, n, big_n, levels, base_log,
+                                         ks_stride, s);
+}
+
+int launch_ksk_to_limbs(const u64 *ksk, signed char *limbs, uint32_t rows, uint32_t n, uint32_t ks_stride, hipStream_t s) {
+    return ksm::launch_ksk_to_limbs<FieldT>(ksk, limbs, rows, n, ks_stride, KS_LIMBS, s);
+}
+
+int launch_keyswitch_mfma(const u64 *in, const signed char *limbs, signed char *digits, int *sums, u64 *out,
+                          uint32_t slices, uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels,
+                          uint32_t base_log, hipStream_t s) {
+    return ksm::launch_keyswitch<FieldT, KS_LIMBS>(in, limbs, digits, sums, out, slices, count, n, big_n, levels, base_log, s);
+}
+
+int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *idx, const i64 *coef,
+                   const u64 *const_body, u64 *out, uint32_t count, uint32_t width, hipStream_t s) {
+    return ksl::launch_lincomb<FieldT>(store, row_ptr, idx, coef, const_body, out, count, width, s);
+}
+
+}  // namespace bmit

@@ -18,8 +18,8 @@
  *   - every function returns 0 on success, <0 on error; bmi_last_error() gives the text.
  *   - plain pointers and sizes only.  Pointers named d_* are DEVICE pointers (HIP), all
  *     others are host pointers.  `stream` is a hipStream_t passed as void* (NULL = default stream).
- *   - ciphertext modulus q (bmi_params.q_bits): 2^64 - 2^32 + 1 or 2^49 - 720895; words are canonical (< q) 64-bit
- *     integers at this boundary for both.
+ *   - ciphertext modulus q (bmi_params.q_bits): 2^64 - 2^32 + 1, 2^49 - 720895 or 2^64; words are canonical (< q)
+ *     64-bit integers at this boundary for all three.
  *   - a "big" LWE ciphertext has k*N+1 words (mask, then body); a "small" one n+1 words.
  *   - messages are signed integers m encoded as m * 2^delta_log (mod q); a p-bit signed message space uses
  *     delta_log = q_bits - 1 - p (59 resp. 44 for p = 4).
@@ -37,6 +37,11 @@ extern "C" {
 
 typedef struct bmi_ctx bmi_ctx;
 
+/* bmi_params.q_bits value selecting q = 2^64 EXACTLY - the torus concrete-python computes on: ciphertext and key words
+ * are Concrete's own u64 representation (no modulus-switch hop), the external product is the exact negacyclic product
+ * mod 2^64.  Message scaling as for q_bits = 64 (delta_log = 63 - msg_bits). */
+#define BMI_Q_TORUS64 65u
+
 typedef struct {
     uint32_t n;           /* small LWE dimension (630) */
     uint32_t log_N;       /* log2 polynomial size (10) */
@@ -46,7 +51,9 @@ typedef struct {
     uint32_t ks_levels;   /* keyswitch levels (8) */
     uint32_t ks_base_log; /* keyswitch base log (4) */
     uint32_t q_bits;      /* ciphertext modulus: 64 -> q = 2^64 - 2^32 + 1 (Goldilocks, integer kernels);
-                             49 -> q = 2^49 - 720895 (exact integers carried in f64: ~2x faster kernels); 0 = 64 */
+                             49 -> q = 2^49 - 720895 (exact integers carried in f64: the fastest kernels);
+                             BMI_Q_TORUS64 -> q = 2^64 (Concrete's torus; exact products through limb-split f64
+                             transforms); 0 = 64 */
     double lwe_noise;     /* std-dev / q of keyswitch-key encryptions */
     double glwe_noise;    /* std-dev / q of bootstrap-key rows and fresh big-key encryptions */
 } bmi_params;

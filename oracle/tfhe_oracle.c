@@ -46,6 +46,13 @@ typedef unsigned __int128 u128;
 static u64 Q = GOLD;
 static uint32_t QBITS = 64;
 static u64 GEN = 7; /* generator of Z_q^* */
+/* q_bits = 65 selects q = 2^64 EXACTLY, the torus Concrete computes on (SURVEY.md section 7 hard part 1, option A):
+ * every Z_q operation below is then plain wrap-around u64 arithmetic, decomposition / message scaling use 64 bits
+ * like the Goldilocks set, and the external product is the exact negacyclic product mod 2^64 (computed through
+ * Goldilocks transforms of the two 32-bit halves of the key, see the torus section below; pinned against the
+ * wrap-around schoolbook product). */
+static int TORUS = 0;
+#define Q_TORUS64 65u
 
 /* Must mirror include/bmi_tfhe.h : bmi_params (same field order). */
 typedef struct {
@@ -62,19 +69,21 @@ typedef struct {
 } ora_params;
 
 int ora_set_field(uint32_t q_bits) {
-    if (q_bits == 64) { Q = GOLD; QBITS = 64; GEN = 7; return 0; }
-    if (q_bits == 49) { Q = P49; QBITS = 49; GEN = 5; return 0; }
+    if (q_bits == 64) { Q = GOLD; QBITS = 64; GEN = 7; TORUS = 0; return 0; }
+    if (q_bits == 49) { Q = P49; QBITS = 49; GEN = 5; TORUS = 0; return 0; }
+    if (q_bits == Q_TORUS64) { Q = 0; QBITS = 64; GEN = 0; TORUS = 1; return 0; }
     return -1;
 }
-u64 ora_modulus(void) { return Q; }
+u64 ora_modulus(void) { return Q; } /* 0 stands for 2^64 */
 
 /* ------------------------------------------------------------------ Z_q ---- */
-static inline u64 addq(u64 a, u64 b) { u64 s = a + b; return (s < a || s >= Q) ? s - Q : s; }
-static inline u64 subq(u64 a, u64 b) { return a >= b ? a - b : a + (Q - b); }
-static inline u64 negq(u64 a) { return a ? Q - a : 0; }
+static inline u64 addq(u64 a, u64 b) { if (TORUS) return a + b; u64 s = a + b; return (s < a || s >= Q) ? s - Q : s; }
+static inline u64 subq(u64 a, u64 b) { if (TORUS) return a - b; return a >= b ? a - b : a + (Q - b); }
+static inline u64 negq(u64 a) { if (TORUS) return (u64)0 - a; return a ? Q - a : 0; }
 /* 128-bit product folded with 2^64 = 2^32 - 1 and 2^96 = -1 (mod q); checked against the plain `% Q` form in
  * ora_selftest_mulq (the baseline should not be handicapped by a 128-bit division per multiply). */
 static inline u64 mulq(u64 a, u64 b) {
+    if (TORUS) return a * b;
     if (Q != GOLD) return (u64)(((u128)a * b) % Q);
     u128 p = (u128)a * b;
     u64 lo = (u64)p, hi = (u64)(p >> 64), hh = hi >> 32, hl = hi & 0xFFFFFFFFull;
@@ -97,8 +106,8 @@ int ora_selftest_mulq(u64 seed, uint32_t iters) {
     return 1;
 }
 static u64 powq(u64 b, u64 e) { u64 r = 1; while (e) { if (e & 1) r = mulq(r, b); b = mulq(b, b); e >>= 1; } return r; }
-static inline u64 from_i64(i64 v) { return v >= 0 ? (u64)v % Q : Q - ((u64)(-v) % Q); }
-static inline i64 centered(u64 a) { return a > (Q >> 1) ? (i64)(a - Q) : (i64)a; } /* (-q/2, q/2] */
+static inline u64 from_i64(i64 v) { if (TORUS) return (u64)v; return v >= 0 ? (u64)v % Q : Q - ((u64)(-v) % Q); }
+static inline i64 centered(u64 a) { if (TORUS) return (i64)a; return a > (Q >> 1) ? (i64)(a - Q) : (i64)a; } /* (-q/2, q/2] */
 
 /* ------------------------------------------------------- deterministic RNG -- */
 /* splitmix64 used as a counter-based generator: value = mix(stream_key + idx*GOLDEN). */
@@ -109,7 +118,7 @@ static inline u64 mix64(u64 z) {
 }
 static inline u64 stream_key(u64 seed, u64 stream) { return mix64(seed ^ (stream * 0xD6E8FEB86659FD93ULL)); }
 static inline u64 rnd_u64(u64 key, u64 idx) { return mix64(key + (idx + 1) * 0x9E3779B97F4A7C15ULL); }
-static inline u64 rnd_modq(u64 key, u64 idx) { u64 u = rnd_u64(key, idx); return QBITS == 64 ? (u >= Q ? u - Q : u) : u % Q; }
+static inline u64 rnd_modq(u64 key, u64 idx) { u64 u = rnd_u64(key, idx); if (TORUS) return u; return QBITS == 64 ? (u >= Q ? u - Q : u) : u % Q; }
 static inline u64 rnd_gauss(u64 key, u64 idx, double sigma) { /* element of Z_q */
     double u1 = ((double)((rnd_u64(key, 2 * idx) >> 11) + 1)) * (1.0 / 9007199254740992.0);
     double u2 = ((double)(rnd_u64(key, 2 * idx + 1) >> 11)) * (1.0 / 9007199254740992.0);
@@ -161,6 +170,72 @@ static void ntt_inv(const ntt_tab *t, u64 *a) {
             for (uint32_t j = 0; j < len; j++) { u64 u = x[j], v = y[j]; x[j] = addq(u, v); y[j] = mulq(subq(u, v), w); }
         }
     for (uint32_t i = 0; i < N; i++) a[i] = mulq(a[i], t->inv_N);
+}
+
+/* ---- Goldilocks arithmetic with the modulus fixed (the torus path computes its exact products through it while the
+ * selected "field" is the torus) */
+static inline u64 g_add(u64 a, u64 b) { u64 s = a + b; return (s < a || s >= GOLD) ? s - GOLD : s; }
+static inline u64 g_sub(u64 a, u64 b) { return a >= b ? a - b : a + (GOLD - b); }
+static inline u64 g_mul(u64 a, u64 b) { return (u64)(((u128)a * b) % GOLD); }
+static u64 g_pow(u64 b, u64 e) { u64 r = 1; while (e) { if (e & 1) r = g_mul(r, b); b = g_mul(b, b); e >>= 1; } return r; }
+static inline u64 g_from_i64(i64 v) { return v >= 0 ? (u64)v : GOLD - (u64)(-v); }              /* |v| < 2^63 */
+static inline i64 g_centered(u64 a) { return a > (GOLD >> 1) ? (i64)(a - GOLD) : (i64)a; }
+static ntt_tab *g_ntt_make(uint32_t logN) {
+    ntt_tab *t = (ntt_tab *)malloc(sizeof *t);
+    t->logN = logN; t->N = 1u << logN;
+    u64 psi = g_pow(7, (GOLD - 1) / (2ull * t->N)), ipsi = g_pow(psi, GOLD - 2);
+    t->psi_br = (u64 *)malloc(t->N * sizeof(u64));
+    t->ipsi_br = (u64 *)malloc(t->N * sizeof(u64));
+    for (uint32_t i = 0; i < t->N; i++) { t->psi_br[i] = g_pow(psi, bitrev(i, logN)); t->ipsi_br[i] = g_pow(ipsi, bitrev(i, logN)); }
+    t->inv_N = g_pow(t->N, GOLD - 2);
+    return t;
+}
+static void g_ntt_fwd(const ntt_tab *t, u64 *a) {
+    uint32_t N = t->N;
+    for (uint32_t m = 1, len = N >> 1; m < N; m <<= 1, len >>= 1)
+        for (uint32_t i = 0; i < m; i++) {
+            u64 w = t->psi_br[m + i];
+            u64 *x = a + 2 * i * len, *y = x + len;
+            for (uint32_t j = 0; j < len; j++) { u64 u = x[j], v = g_mul(y[j], w); x[j] = g_add(u, v); y[j] = g_sub(u, v); }
+        }
+}
+static void g_ntt_inv(const ntt_tab *t, u64 *a) {
+    uint32_t N = t->N;
+    for (uint32_t m = N >> 1, len = 1; m >= 1; m >>= 1, len <<= 1)
+        for (uint32_t i = 0; i < m; i++) {
+            u64 w = t->ipsi_br[m + i];
+            u64 *x = a + 2 * i * len, *y = x + len;
+            for (uint32_t j = 0; j < len; j++) { u64 u = x[j], v = y[j]; x[j] = g_add(u, v); y[j] = g_mul(g_sub(u, v), w); }
+        }
+    for (uint32_t i = 0; i < N; i++) a[i] = g_mul(a[i], t->inv_N);
+}
+
+/* c = a * b mod (X^N + 1, 2^64), wrap-around schoolbook: the definition the torus path is held to */
+void ora_torus_negacyclic_schoolbook(uint32_t logN, const u64 *a, const u64 *b, u64 *c) {
+    uint32_t N = 1u << logN;
+    memset(c, 0, N * sizeof(u64));
+    for (uint32_t i = 0; i < N; i++)
+        for (uint32_t j = 0; j < N; j++) {
+            u64 p = a[i] * b[j];
+            uint32_t k = i + j;
+            if (k < N) c[k] += p; else c[k - N] -= p;
+        }
+}
+/* The same product for a SMALL signed first operand (|d_i| <= 2^bound_log, i.e. decomposition digits) through two
+ * Goldilocks transforms of the 32-bit halves of b: each half-product is an integer of magnitude
+ * < N * 2^bound_log * 2^32, which must stay below q/2 (checked), so its centred residue IS the integer. */
+int ora_torus_negacyclic_split(uint32_t logN, const i64 *d, uint32_t bound_log, const u64 *b, u64 *c) {
+    uint32_t N = 1u << logN;
+    if (logN + bound_log + 32 >= 63) return -1;
+    ntt_tab *t = g_ntt_make(logN);
+    u64 *x = (u64 *)malloc(N * 8), *lo = (u64 *)malloc(N * 8), *hi = (u64 *)malloc(N * 8);
+    for (uint32_t i = 0; i < N; i++) { x[i] = g_from_i64(d[i]); lo[i] = b[i] & 0xFFFFFFFFull; hi[i] = b[i] >> 32; }
+    g_ntt_fwd(t, x); g_ntt_fwd(t, lo); g_ntt_fwd(t, hi);
+    for (uint32_t i = 0; i < N; i++) { lo[i] = g_mul(lo[i], x[i]); hi[i] = g_mul(hi[i], x[i]); }
+    g_ntt_inv(t, lo); g_ntt_inv(t, hi);
+    for (uint32_t i = 0; i < N; i++) c[i] = (u64)g_centered(lo[i]) + ((u64)g_centered(hi[i]) << 32);
+    free(x); free(lo); free(hi); ntt_free(t);
+    return 0;
 }
 
 /* c = a * b mod (X^N + 1, q): schoolbook (slow, obviously correct) */
@@ -225,6 +300,7 @@ void ora_decompose(u64 a, uint32_t levels, uint32_t base_log, i64 *digits) {
 
 /* round(a * 2N / q) mod 2N, exact */
 uint32_t ora_modswitch(u64 a, uint32_t log2N) {
+    if (TORUS) return (uint32_t)(((a >> (63 - log2N)) + 1) >> 1) & ((1u << log2N) - 1); /* round(a 2N / 2^64), ties up */
     u128 t = ((u128)a << log2N) + (Q >> 1);
     return (uint32_t)(t / Q) & ((1u << log2N) - 1);
 }
@@ -253,10 +329,10 @@ void ora_keygen(const ora_params *P, u64 seed, u64 *sk_small, u64 *sk_big, u64 *
     for (uint32_t i = 0; i < k * N; i++) sk_big[i] = rnd_u64(k2, i) & 1;
 
     u64 km = stream_key(seed, ST_BSK_MASK), ke = stream_key(seed, ST_BSK_NOISE);
-    ntt_tab *t = ntt_make(P->log_N);
+    ntt_tab *t = TORUS ? NULL : ntt_make(P->log_N);
     u64 *S = (u64 *)malloc((size_t)k * N * 8); /* NTT of the GLWE secret polynomials */
     memcpy(S, sk_big, (size_t)k * N * 8);
-    for (uint32_t j = 0; j < k; j++) ntt_fwd(t, S + (size_t)j * N);
+    for (uint32_t j = 0; j < k && !TORUS; j++) ntt_fwd(t, S + (size_t)j * N);
     uint32_t rows = (k + 1) * l;
 #pragma omp parallel
     {
@@ -269,11 +345,19 @@ void ora_keygen(const ora_params *P, u64 seed, u64 *sk_small, u64 *sk_big, u64 *
             for (uint32_t j = 0; j < k; j++) {
                 u64 *A = row + (size_t)j * N;
                 for (uint32_t x = 0; x < N; x++) A[x] = rnd_modq(km, ((u64)ir * (k + 1) + j) * N + x);
+                if (TORUS) { /* A * S with S binary: shifted adds, wrap-around (no transform exists mod 2^64) */
+                    for (uint32_t sft = 0; sft < N; sft++) {
+                        if (!sk_big[(size_t)j * N + sft]) continue;
+                        for (uint32_t x = 0; x + sft < N; x++) acc[x + sft] += A[x];
+                        for (uint32_t x = N - sft; x < N; x++) acc[x + sft - N] -= A[x];
+                    }
+                    continue;
+                }
                 memcpy(tmp, A, N * 8);
                 ntt_fwd(t, tmp);
                 for (uint32_t x = 0; x < N; x++) acc[x] = addq(acc[x], mulq(tmp[x], S[(size_t)j * N + x]));
             }
-            ntt_inv(t, acc);
+            if (!TORUS) ntt_inv(t, acc);
             u64 *B = row + (size_t)k * N;
             for (uint32_t x = 0; x < N; x++) B[x] = addq(acc[x], rnd_gauss(ke, (u64)ir * N + x, P->glwe_noise));
             if (sk_small[i]) {
@@ -283,7 +367,7 @@ void ora_keygen(const ora_params *P, u64 seed, u64 *sk_small, u64 *sk_big, u64 *
         }
         free(tmp); free(acc);
     }
-    free(S); ntt_free(t);
+    free(S); if (t) ntt_free(t);
 
     u64 kkm = stream_key(seed, ST_KSK_MASK), kke = stream_key(seed, ST_KSK_NOISE);
 #pragma omp parallel for schedule(static)
@@ -306,7 +390,7 @@ void ora_lwe_encrypt(const u64 *key, uint32_t dim, double noise, u64 seed, u64 f
     u64 km = stream_key(seed, ST_ENC_MASK), ke = stream_key(seed, ST_ENC_NOISE);
     for (uint32_t i = 0; i < count; i++) {
         u64 *ct = out + (size_t)i * (dim + 1);
-        u64 b = addq(torus[i] % Q, rnd_gauss(ke, first + i, noise));
+        u64 b = addq(TORUS ? torus[i] : torus[i] % Q, rnd_gauss(ke, first + i, noise));
         for (uint32_t c = 0; c < dim; c++) {
             ct[c] = rnd_modq(km, (first + i) * (u64)(dim + 1) + c);
             if (key[c]) b = addq(b, ct[c]);
@@ -359,9 +443,22 @@ typedef struct {
 ora_ctx *ora_ctx_create(const ora_params *P, const u64 *bsk, const u64 *ksk) {
     ora_set_field(P->q_bits);
     ora_ctx *c = (ora_ctx *)malloc(sizeof *c);
-    c->P = *P; c->t = ntt_make(P->log_N); c->ksk = ksk;
+    c->P = *P; c->ksk = ksk;
     uint32_t N = 1u << P->log_N;
     size_t polys = (size_t)P->n * (P->k + 1) * P->bs_levels * (P->k + 1);
+    if (TORUS) {
+        /* torus: Goldilocks transforms of the low and the high 32-bit half of every key polynomial: [poly][2][N] */
+        c->t = g_ntt_make(P->log_N);
+        c->bsk_ntt = (u64 *)malloc(polys * 2 * N * 8);
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < polys; i++) {
+            u64 *lo = c->bsk_ntt + i * 2 * N, *hi = lo + N;
+            for (uint32_t x = 0; x < N; x++) { lo[x] = bsk[i * N + x] & 0xFFFFFFFFull; hi[x] = bsk[i * N + x] >> 32; }
+            g_ntt_fwd(c->t, lo); g_ntt_fwd(c->t, hi);
+        }
+        return c;
+    }
+    c->t = ntt_make(P->log_N);
     c->bsk_ntt = (u64 *)malloc(polys * N * 8);
     memcpy(c->bsk_ntt, bsk, polys * N * 8);
 #pragma omp parallel for schedule(static)
@@ -387,6 +484,7 @@ void ora_keyswitch(const ora_ctx *c, const u64 *in, u64 *out) {
     }
     for (uint32_t x = 0; x <= n; x++) {
         __int128 a = -acc[x];
+        if (TORUS) { out[x] = (u64)a; continue; }
         __int128 r = a % (__int128)Q; if (r < 0) r += Q;
         out[x] = (u64)r;
     }
@@ -417,6 +515,31 @@ void ora_blind_rotate_extract(const ora_ctx *c, const u64 *lwe, const u64 *tv, u
                 ora_decompose(d[x], l, P->bs_base_log, dig);
                 for (uint32_t lev = 0; lev < l; lev++) dec[((size_t)comp * l + lev) * N + x] = from_i64(dig[lev]);
             }
+        }
+        if (TORUS) {
+            /* exact product mod 2^64: digits (|d| <= 2^(Bg-1)) as Goldilocks elements against both key halves; every
+             * half-sum is an integer below rows * N * 2^(Bg-1) * 2^32 < q/2, so its centred residue is the integer */
+            u64 *res_hi = (u64 *)calloc((size_t)(k + 1) * N, 8);
+            for (uint32_t r = 0; r < rows; r++) {
+                u64 *d = dec + (size_t)r * N;
+                for (uint32_t x = 0; x < N; x++) d[x] = g_from_i64((i64)d[x]);
+                g_ntt_fwd(c->t, d);
+            }
+            memset(res, 0, (size_t)(k + 1) * N * 8);
+            const u64 *g = c->bsk_ntt + (size_t)i * rows * (k + 1) * 2 * N;
+            for (uint32_t r = 0; r < rows; r++)
+                for (uint32_t oc = 0; oc <= k; oc++) {
+                    const u64 *blo = g + ((size_t)r * (k + 1) + oc) * 2 * N, *bhi = blo + N, *d = dec + (size_t)r * N;
+                    u64 *o = res + (size_t)oc * N, *oh = res_hi + (size_t)oc * N;
+                    for (uint32_t x = 0; x < N; x++) { o[x] = g_add(o[x], g_mul(d[x], blo[x])); oh[x] = g_add(oh[x], g_mul(d[x], bhi[x])); }
+                }
+            for (uint32_t oc = 0; oc <= k; oc++) {
+                g_ntt_inv(c->t, res + (size_t)oc * N); g_ntt_inv(c->t, res_hi + (size_t)oc * N);
+                u64 *a = acc + (size_t)oc * N, *o = res + (size_t)oc * N, *oh = res_hi + (size_t)oc * N;
+                for (uint32_t x = 0; x < N; x++) a[x] += (u64)g_centered(o[x]) + ((u64)g_centered(oh[x]) << 32);
+            }
+            free(res_hi);
+            continue;
         }
         for (uint32_t r = 0; r < rows; r++) ntt_fwd(c->t, dec + (size_t)r * N);
         memset(res, 0, (size_t)(k + 1) * N * 8);
@@ -480,7 +603,7 @@ void ora_lincomb(uint32_t width, const u64 *in, const uint32_t *row_ptr, const u
             const u64 *s = in + (size_t)idx[e] * width;
             for (uint32_t x = 0; x < width; x++) o[x] = addq(o[x], mulq(cq, s[x]));
         }
-        o[width - 1] = addq(o[width - 1], const_body[i] % Q);
+        o[width - 1] = addq(o[width - 1], TORUS ? const_body[i] : const_body[i] % Q);
     }
 }
 

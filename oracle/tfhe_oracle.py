@@ -30,7 +30,13 @@ class Params(C.Structure):
 
 GOLD = 0xFFFFFFFF00000001
 P49 = 562949952700417
-MODULUS = {64: GOLD, 49: P49}
+TORUS64 = 65                     # q_bits value selecting q = 2^64 exactly (Concrete's torus)
+MODULUS = {64: GOLD, 49: P49, TORUS64: 1 << 64}
+
+
+def log_q(q_bits):
+    """bits of the torus the messages are scaled on: 49 for the 49-bit prime, 64 for Goldilocks and for 2^64"""
+    return 49 if q_bits == 49 else 64
 
 
 def default_params(**kw):
@@ -100,6 +106,19 @@ def keygen(P, seed):
     return Keys(P, sk_small, sk_big, bsk, ksk)
 
 
+def torus_negacyclic(logN, d, b, schoolbook=False, bound_log=14):
+    """d * b mod (X^N + 1, 2^64); d small signed (decomposition digits).  schoolbook=True: wrap-around definition;
+    otherwise the Goldilocks half-transform route the torus blind rotation uses."""
+    d = np.ascontiguousarray(d, dtype=np.int64)
+    b = u64(b)
+    c = np.zeros(1 << logN, np.uint64)
+    if schoolbook:
+        lib().ora_torus_negacyclic_schoolbook(C.c_uint32(logN), _p(d.view(np.uint64)), _p(b), _p(c))
+    elif lib().ora_torus_negacyclic_split(C.c_uint32(logN), _p(d), C.c_uint32(bound_log), _p(b), _p(c)) != 0:
+        raise ValueError("operand bound too large for the split product")
+    return c
+
+
 def negacyclic(logN, a, b, schoolbook=False):
     a, b = u64(a), u64(b)
     c = np.zeros(1 << logN, np.uint64)
@@ -118,7 +137,7 @@ def modswitch(a, log2N):
 
 
 def modulus():
-    return int(lib().ora_modulus())
+    return int(lib().ora_modulus()) or (1 << 64)      # the library reports 2^64 as 0
 
 
 def encode(msgs, delta_log):

@@ -148,6 +148,22 @@ def test_encrypted_4x4_inverse_matches_reference_golden(eng):
     print(f"encrypted 4x4 (len 40, ints 16): {wall:.1f} s, {emi.circuit.summary()}")
 
 
+@pytest.mark.parametrize("tag", ["baseline_b_n2_len20_ints8", "baseline_b_n3_len30_ints12", "baseline_b_n4_len40_ints16",
+                                 "overflow_digit_3x3", "rand3x3_seed100", "rand3x3_seed101", "rand3x3_seed102"])
+def test_encrypted_inverse_of_further_matrices(eng, tag):
+    """A second matrix for each of BASELINE configs 2-4 and the remaining 3x3 goldens, on ciphertexts (49-bit field)."""
+    if eng.q_bits == 64:
+        pytest.skip("run once, on the faster field")
+    from bmi_amd.main import EncryptedMatrixInversion
+    c = next(x for x in load("inverse.json") if x["tag"] == tag)
+    emi = EncryptedMatrixInversion(c["n"], None, 2, c["len"], c["ints"], False, False, engine=eng)
+    M = np.array(c["M"]).reshape(c["n"], c["n"])
+    q, s = emi.quantize(M)
+    out = emi.decrypt(emi.evaluate(emi.encrypt(q, s)))
+    assert out.tolist() == c["out"]
+    assert emi.dequantize(out).flatten().tolist() == c["float"]
+
+
 def test_encrypted_8x8_inverse_matches_reference_golden(eng):
     """BASELINE config 5 (8x8, len 48, ints 16) on ONE MI355X, every look-up on ciphertexts: 2.58 M PBS over 2,886
     levels; decrypted digits and signs == the reference's plaintext output (tests/golden/inverse.json,
@@ -175,12 +191,12 @@ def test_encrypted_8x8_inverse_matches_reference_golden(eng):
     assert emi.dequantize(out).flatten().tolist() == c["float"]
 
 
-@pytest.mark.parametrize("tag", ["overflow_digit_2x2", "overflow_digit_3x3"])
+@pytest.mark.parametrize("tag", ["overflow_digit_2x2", "overflow_digit_3x3_ints8"])
 def test_encrypted_inverse_with_a_non_binary_leading_digit(eng, tag):
     """An entry beyond 2^ints keeps a leading digit of 2 or 3 (from_float does not reduce it, base_p_arrays.py:42-46;
     SURVEY section 8d asks for such a matrix on ciphertexts): digits and signs == the reference's."""
     from bmi_amd.main import EncryptedMatrixInversion
-    if eng.q_bits == 64 and tag.endswith("3x3"):
+    if eng.q_bits == 64 and "3x3" in tag:
         pytest.skip("the 3x3 case runs once, on the faster field")
     c = next(x for x in load("inverse.json") if x["tag"] == tag)
     assert max(row[0] for row in c["in_arrays"]) >= 2

@@ -235,6 +235,11 @@ def gen_inverse():
     np.random.seed(1234 + 8)
     if os.environ.get("BMI_GOLDEN_8X8", "1") == "1":
         one("baseline_n8_len48_ints16", np.random.randn(8, 8) * 100, 48, 16)
+    # round 2: a 3x3 whose entry really exceeds 2^ints (leading digit 2), and a second matrix per BASELINE config
+    one("overflow_digit_3x3_ints8", np.array([[300.5, 12.25, 3.0], [-7.5, 41.0, -60.0], [5.0, -2.0, 77.0]]), 24, 8)
+    for n, ln, ints in [(2, 20, 8), (3, 30, 12), (4, 40, 16)]:
+        np.random.seed(2234 + n)
+        one(f"baseline_b_n{n}_len{ln}_ints{ints}", np.random.randn(n, n) * 100, ln, ints)
     return cases
 
 
