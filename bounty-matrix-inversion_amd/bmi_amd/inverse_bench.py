@@ -23,8 +23,11 @@ def run(engine, sizes=(2, 3), shard_threshold=1024):
         M = np.random.randn(n, n) * 100
         t0 = time.time()
         emi = EncryptedMatrixInversion(n, None, 2, ln, ints, False, False, engine=engine, shard_threshold=shard_threshold)
-        emi._executor()
-        t_compile = time.time() - t0
+        t_program = time.time() - t0           # trace + prune + schedule (cold) or a load of the cached program
+        t0 = time.time()
+        ex = emi._executor()                   # index arrays -> device, LUT uploads, store allocation
+        t_exec = time.time() - t0
+        t_compile = t_program + t_exec
         q, s = emi.quantize(M)
         t0 = time.time()
         enc = emi.encrypt(q, s)
@@ -41,6 +44,11 @@ def run(engine, sizes=(2, 3), shard_threshold=1024):
         summ = emi.circuit.summary()
         out[f"{n}x{n}"] = {
             "len": ln, "ints": ints, "evaluate_s": round(t_eval, 3), "compile_s": round(t_compile, 3),
+            "compile_cached": bool(emi.compile_info["cached"]), "program_s": round(t_program, 3),
+            "executor_build_s": round(t_exec, 3),
+            "end_to_end_s": round(t_compile + t_enc + t_eval + t_dec, 3),
+            "store_gb": round(ex.store_bytes() / 1e9, 3), "store_rows": int(ex.n_rows),
+            "traced_pbs": summ.get("traced_pbs"), "pruned_pbs": summ.get("pruned_pbs"),
             "encrypt_s": round(t_enc, 3), "decrypt_s": round(t_dec, 3), "pbs": summ["pbs"], "depth": summ["depth"],
             "ms_per_level": round(t_eval / max(summ["depth"], 1) * 1e3, 3),
             "ranks": emi._executor().world, "sharded_levels": emi._executor().sharded_levels,

@@ -618,3 +618,198 @@ int ora_num_threads(void) {
 #endif
     return n;
 }
+
+/* ====================================================================== fast path (49-bit field) ====
+ * The CPU BASELINE of bench.py: the same PBS, same results bit for bit (ora_fast_pbs_batch == ora_pbs_batch, held by
+ * tests/test_oracle_tfhe.py), written the way a competent CPU implementation is: no 128-bit divisions, no allocation per
+ * call, vectorisable loops.  Arithmetic: exact integers mod p = 2^49 - 720895 carried in doubles (products through one
+ * FMA pair, reductions x - p rint(x / p): the representation the GPU kernels use, here in plain radix-2 transforms
+ * that gcc vectorises), keyswitch as exact f64 FMAs on the two 25-bit halves of the key words.
+ * The generic path above stays the definition; this one is only ever compared with it. */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define F_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))   /* picked at load time by the host CPU */
+#else
+#define F_CLONES
+#endif
+#define FP 562949952700417.0
+#define FPINV (1.0 / 562949952700417.0)
+static inline double f_red(double x) { return __builtin_fma(-__builtin_rint(x * FPINV), FP, x); }
+static inline double f_mul(double a, double b) { /* |a| < 2^53, |b| <= p/2: exact product, result |r| <= 0.5p + |a|/8 */
+    double h = a * b, l = __builtin_fma(a, b, -h);
+    return __builtin_fma(-__builtin_rint(h * FPINV), FP, h) + l;
+}
+static inline double f_center(u64 v) { return v > (P49 >> 1) ? -(double)(P49 - v) : (double)v; }
+static inline u64 f_canon(double x) { double r = f_red(x); if (r < 0) r += FP; return (u64)r; }
+
+typedef struct {
+    ora_params P;
+    uint32_t N;
+    double *psi_br, *ipsi_br; /* centred twiddles, bit-reversed order (same tables as ntt_tab) */
+    double inv_N;
+    double *bsk;              /* [n][rows][k+1][N] transform domain, centred */
+    double *ksk_lo, *ksk_hi;  /* [kN*lk][n+1]: word = hi * 2^25 + lo, both exact in f64 */
+} ora_fctx;
+
+F_CLONES static void f_ntt_fwd(const ora_fctx *c, double *a) {
+    uint32_t N = c->N, stage = 0;
+    for (uint32_t m = 1, len = N >> 1; m < N; m <<= 1, len >>= 1, stage++) {
+        for (uint32_t i = 0; i < m; i++) {
+            double w = c->psi_br[m + i];
+            double *x = a + 2 * i * len, *y = x + len;
+            for (uint32_t j = 0; j < len; j++) { double u = x[j], v = f_mul(y[j], w); x[j] = u + v; y[j] = u - v; }
+        }
+        if (stage == 4) for (uint32_t j = 0; j < N; j++) a[j] = f_red(a[j]); /* lazy sums: 0.5p + 5 x 1.4p at most before */
+    }
+}
+F_CLONES static void f_ntt_inv(const ora_fctx *c, double *a) { /* input |.| <= 0.51 p */
+    uint32_t N = c->N;
+    for (uint32_t m = N >> 1, len = 1; m >= 1; m >>= 1, len <<= 1)
+        for (uint32_t i = 0; i < m; i++) {
+            double w = c->ipsi_br[m + i];
+            double *x = a + 2 * i * len, *y = x + len;
+            for (uint32_t j = 0; j < len; j++) { double u = x[j], v = y[j]; x[j] = f_red(u + v); y[j] = f_mul(u - v, w); }
+        }
+    for (uint32_t i = 0; i < N; i++) a[i] = f_mul(a[i], c->inv_N);
+}
+
+ora_fctx *ora_fctx_create(const ora_params *P, const u64 *bsk, const u64 *ksk) {
+    if (P->q_bits != 49) return NULL;
+    ora_set_field(49);
+    ora_fctx *c = (ora_fctx *)calloc(1, sizeof *c);
+    c->P = *P; c->N = 1u << P->log_N;
+    uint32_t N = c->N, n = P->n, k = P->k, lk = P->ks_levels;
+    ntt_tab *t = ntt_make(P->log_N);
+    c->psi_br = (double *)malloc(N * 8); c->ipsi_br = (double *)malloc(N * 8);
+    for (uint32_t i = 0; i < N; i++) { c->psi_br[i] = f_center(t->psi_br[i]); c->ipsi_br[i] = f_center(t->ipsi_br[i]); }
+    c->inv_N = f_center(t->inv_N);
+    size_t polys = (size_t)n * (k + 1) * P->bs_levels * (k + 1);
+    c->bsk = (double *)malloc(polys * N * 8);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < polys; i++) {
+        double *d = c->bsk + i * N;
+        for (uint32_t x = 0; x < N; x++) d[x] = f_center(bsk[i * N + x]);
+        f_ntt_fwd(c, d);
+        for (uint32_t x = 0; x < N; x++) d[x] = f_red(d[x]);
+    }
+    size_t kw = (size_t)k * N * lk * (n + 1);
+    c->ksk_lo = (double *)malloc(kw * 8); c->ksk_hi = (double *)malloc(kw * 8);
+    for (size_t i = 0; i < kw; i++) { c->ksk_lo[i] = (double)(ksk[i] & 0x1FFFFFFull); c->ksk_hi[i] = (double)(ksk[i] >> 25); }
+    ntt_free(t);
+    return c;
+}
+void ora_fctx_destroy(ora_fctx *c) { if (!c) return; free(c->psi_br); free(c->ipsi_br); free(c->bsk); free(c->ksk_lo); free(c->ksk_hi); free(c); }
+
+/* per-thread scratch of the fast path */
+typedef struct { double *acc, *dec, *res, *ks_lo, *ks_hi; u64 *small; } f_scratch;
+static void f_scratch_make(const ora_fctx *c, f_scratch *s) {
+    uint32_t N = c->N, k = c->P.k, rows = (k + 1) * c->P.bs_levels, n = c->P.n;
+    s->acc = (double *)malloc((size_t)(k + 1) * N * 8); s->dec = (double *)malloc((size_t)rows * N * 8);
+    s->res = (double *)malloc((size_t)(k + 1) * N * 8);
+    s->ks_lo = (double *)malloc((n + 1) * 8); s->ks_hi = (double *)malloc((n + 1) * 8); s->small = (u64 *)malloc((n + 1) * 8);
+}
+static void f_scratch_free(f_scratch *s) { free(s->acc); free(s->dec); free(s->res); free(s->ks_lo); free(s->ks_hi); free(s->small); }
+
+F_CLONES static void f_keyswitch(const ora_fctx *c, const u64 *in, f_scratch *s, u64 *out) {
+    const ora_params *P = &c->P;
+    uint32_t n = P->n, kN = P->k << P->log_N, lk = P->ks_levels;
+    i64 dig[64];
+    double *alo = s->ks_lo, *ahi = s->ks_hi;
+    for (uint32_t x = 0; x <= n; x++) alo[x] = ahi[x] = 0.0;
+    /* |digit| <= 2^(Bks-1) <= 64, halves < 2^25, kN*lk <= 2^15 rows: every partial sum stays below 2^46, exact in f64 */
+    for (uint32_t j = 0; j < kN; j++) {
+        ora_decompose(in[j], lk, P->ks_base_log, dig);
+        for (uint32_t lev = 0; lev < lk; lev++) {
+            if (!dig[lev]) continue;
+            const double d = (double)dig[lev];
+            const double *rlo = c->ksk_lo + ((size_t)j * lk + lev) * (n + 1), *rhi = c->ksk_hi + ((size_t)j * lk + lev) * (n + 1);
+            for (uint32_t x = 0; x <= n; x++) { alo[x] = __builtin_fma(d, rlo[x], alo[x]); ahi[x] = __builtin_fma(d, rhi[x], ahi[x]); }
+        }
+    }
+    for (uint32_t x = 0; x <= n; x++) {
+        /* -(hi * 2^25 + lo) mod p: hi < 2^46 -> hi * 2^25 through the exact product */
+        double v = f_mul(-ahi[x], 33554432.0) - alo[x];
+        out[x] = f_canon(v);
+    }
+    out[n] = addq(out[n], in[kN]);
+}
+
+F_CLONES static void f_blind_rotate_extract(const ora_fctx *c, const u64 *lwe, const u64 *tv, f_scratch *s, u64 *out) {
+    const ora_params *P = &c->P;
+    uint32_t n = P->n, N = c->N, k = P->k, l = P->bs_levels, rows = (k + 1) * l, log2N = P->log_N + 1;
+    const uint32_t shift = 49 - l * P->bs_base_log;
+    const double sc = 1.0 / (double)((u64)1 << shift), B = (double)((u64)1 << P->bs_base_log), Binv = 1.0 / B;
+    double *acc = s->acc, *dec = s->dec, *res = s->res;
+    uint32_t bt = ora_modswitch(lwe[n], log2N);
+    for (uint32_t x = 0; x < (k + 1) * N; x++) acc[x] = 0.0;
+    for (uint32_t j = 0; j < N; j++) { /* X^(-bt) * tv */
+        uint32_t pos = (j + 2 * N - bt) & (2 * N - 1);
+        double v = f_center(tv[j]);
+        if (pos < N) acc[(size_t)k * N + pos] = v; else acc[(size_t)k * N + pos - N] = -v;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t at = ora_modswitch(lwe[i], log2N);
+        if (at == 0) continue;
+        for (uint32_t comp = 0; comp <= k; comp++) {
+            const double *a = acc + (size_t)comp * N;
+            double *d0 = dec + (size_t)comp * l * N;
+            /* rot = X^at * a as two contiguous runs (no per-element branch), then (rot - a) centred, rounded (half to
+             * even) to its top l * Bg bits and peeled into signed digits: all three loops vectorise */
+            double *rot = res;   /* scratch: res is rewritten below */
+            {
+                const uint32_t b = at & (N - 1);
+                const double sg = at < N ? 1.0 : -1.0;
+                for (uint32_t x = 0; x < b; x++) rot[x] = -sg * a[x + N - b];
+                for (uint32_t x = b; x < N; x++) rot[x] = sg * a[x - b];
+            }
+            for (uint32_t x = 0; x < N; x++) d0[x] = __builtin_rint(f_red(rot[x] - a[x]) * sc);
+            for (int lev = (int)l - 1; lev >= 1; lev--) {
+                double *dl_ = d0 + (size_t)lev * N;
+                for (uint32_t x = 0; x < N; x++) {
+                    double r = d0[x], rn = __builtin_rint(r * Binv);
+                    dl_[x] = __builtin_fma(-B, rn, r);
+                    d0[x] = rn;
+                }
+            }
+        }
+        for (uint32_t r = 0; r < rows; r++) {
+            double *d = dec + (size_t)r * N;
+            f_ntt_fwd(c, d);
+            for (uint32_t x = 0; x < N; x++) d[x] = f_red(d[x]);
+        }
+        const double *g = c->bsk + (size_t)i * rows * (k + 1) * N;
+        for (uint32_t oc = 0; oc <= k; oc++) {
+            double *o = res + (size_t)oc * N;
+            for (uint32_t x = 0; x < N; x++) o[x] = 0.0;
+            for (uint32_t r = 0; r < rows; r++) { /* lazy: rows * 0.57p stays far below 2^53 for rows <= 12 */
+                const double *b = g + ((size_t)r * (k + 1) + oc) * N, *d = dec + (size_t)r * N;
+                for (uint32_t x = 0; x < N; x++) o[x] += f_mul(d[x], b[x]);
+            }
+            for (uint32_t x = 0; x < N; x++) o[x] = f_red(o[x]);
+            f_ntt_inv(c, o);
+            double *a = acc + (size_t)oc * N;
+            for (uint32_t x = 0; x < N; x++) a[x] = f_red(a[x] + o[x]);
+        }
+    }
+    for (uint32_t j = 0; j < k; j++) {
+        const double *A = acc + (size_t)j * N;
+        out[(size_t)j * N] = f_canon(A[0]);
+        for (uint32_t x = 1; x < N; x++) out[(size_t)j * N + x] = f_canon(-A[N - x]);
+    }
+    out[(size_t)k * N] = f_canon(acc[(size_t)k * N]);
+}
+
+/* same contract as ora_pbs_batch (ks_out optional) */
+void ora_fast_pbs_batch(const ora_fctx *c, const u64 *in, const u64 *tvs, const uint32_t *tv_ids, uint32_t count, u64 *out, u64 *ks_out) {
+    uint32_t n = c->P.n, N = c->N, big = c->P.k * N + 1;
+#pragma omp parallel
+    {
+        f_scratch s; f_scratch_make(c, &s);
+#pragma omp for schedule(dynamic, 1)
+        for (uint32_t i = 0; i < count; i++) {
+            f_keyswitch(c, in + (size_t)i * big, &s, s.small);
+            if (ks_out) memcpy(ks_out + (size_t)i * (n + 1), s.small, (n + 1) * 8);
+            f_blind_rotate_extract(c, s.small, tvs + (size_t)tv_ids[i] * N, &s, out + (size_t)i * big);
+        }
+        f_scratch_free(&s);
+    }
+}

@@ -74,6 +74,7 @@ def lib():
             build()
         _lib = C.CDLL(SO)
         _lib.ora_ctx_create.restype = C.c_void_p
+        _lib.ora_fctx_create.restype = C.c_void_p
         _lib.ora_modswitch.restype = C.c_uint32
         _lib.ora_num_threads.restype = C.c_int
         _lib.ora_modulus.restype = C.c_uint64
@@ -218,6 +219,40 @@ class Ctx:
         ks = np.zeros((cts.shape[0], self.P.n + 1), np.uint64) if want_ks else None
         lib().ora_pbs_batch(self.h, _p(cts), _p(tvs), _p(ids), C.c_uint32(cts.shape[0]), _p(out),
                             _p(ks) if want_ks else None)
+        return (out, ks) if want_ks else out
+
+
+class FastCtx:
+    """The CPU baseline of bench.py (49-bit field only): same PBS, same bits as Ctx.pbs, written for speed (f64 exact
+    arithmetic, vectorisable loops, no allocation per call).  tests/test_oracle_tfhe.py holds it to Ctx.pbs."""
+
+    def __init__(self, P, bsk, ksk):
+        self.P = P
+        bsk, ksk = u64(bsk), u64(ksk)
+        h = lib().ora_fctx_create(C.byref(P), _p(bsk), _p(ksk))
+        if not h:
+            raise ValueError("the fast path exists for q_bits = 49 only")
+        self.h = C.c_void_p(h)
+
+    def close(self):
+        if self.h:
+            lib().ora_fctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def pbs(self, cts, tvs, tv_ids, want_ks=False):
+        cts = u64(cts).reshape(-1, self.P.big)
+        tvs = u64(tvs).reshape(-1, self.P.N)
+        ids = np.ascontiguousarray(tv_ids, dtype=np.uint32)
+        out = np.zeros_like(cts)
+        ks = np.zeros((cts.shape[0], self.P.n + 1), np.uint64) if want_ks else None
+        lib().ora_fast_pbs_batch(self.h, _p(cts), _p(tvs), _p(ids), C.c_uint32(cts.shape[0]), _p(out),
+                                 _p(ks) if want_ks else None)
         return (out, ks) if want_ks else out
 
 
