@@ -733,12 +733,15 @@ F_CLONES static void f_keyswitch(const ora_fctx *c, const u64 *in, f_scratch *s,
     out[n] = addq(out[n], in[kN]);
 }
 
-F_CLONES static void f_blind_rotate_extract(const ora_fctx *c, const u64 *lwe, const u64 *tv, f_scratch *s, u64 *out) {
+/* blind rotation of one ciphertext in three pieces (accumulator set-up, one CMUX, sample extraction) so that a thread
+ * can walk a GROUP of ciphertexts through the key in step: every key row is then used F_GROUP times while it is in cache */
+static void f_br_init(const ora_fctx *c, const u64 *lwe, const u64 *tv, f_scratch *s) {
     const ora_params *P = &c->P;
     uint32_t n = P->n, N = c->N, k = P->k, l = P->bs_levels, rows = (k + 1) * l, log2N = P->log_N + 1;
     const uint32_t shift = 49 - l * P->bs_base_log;
     const double sc = 1.0 / (double)((u64)1 << shift), B = (double)((u64)1 << P->bs_base_log), Binv = 1.0 / B;
     double *acc = s->acc, *dec = s->dec, *res = s->res;
+    (void)n; (void)rows; (void)log2N; (void)sc; (void)B; (void)Binv; (void)dec; (void)res; (void)shift;
     uint32_t bt = ora_modswitch(lwe[n], log2N);
     for (uint32_t x = 0; x < (k + 1) * N; x++) acc[x] = 0.0;
     for (uint32_t j = 0; j < N; j++) { /* X^(-bt) * tv */
@@ -746,9 +749,16 @@ F_CLONES static void f_blind_rotate_extract(const ora_fctx *c, const u64 *lwe, c
         double v = f_center(tv[j]);
         if (pos < N) acc[(size_t)k * N + pos] = v; else acc[(size_t)k * N + pos - N] = -v;
     }
-    for (uint32_t i = 0; i < n; i++) {
+}
+F_CLONES static void f_br_step(const ora_fctx *c, const u64 *lwe, uint32_t i, f_scratch *s) {
+    const ora_params *P = &c->P;
+    uint32_t n = P->n, N = c->N, k = P->k, l = P->bs_levels, rows = (k + 1) * l, log2N = P->log_N + 1;
+    const uint32_t shift = 49 - l * P->bs_base_log;
+    const double sc = 1.0 / (double)((u64)1 << shift), B = (double)((u64)1 << P->bs_base_log), Binv = 1.0 / B;
+    double *acc = s->acc, *dec = s->dec, *res = s->res;
+    (void)n; (void)rows; (void)log2N; (void)sc; (void)B; (void)Binv; (void)dec; (void)res; (void)shift;
         uint32_t at = ora_modswitch(lwe[i], log2N);
-        if (at == 0) continue;
+        if (at == 0) return;
         for (uint32_t comp = 0; comp <= k; comp++) {
             const double *a = acc + (size_t)comp * N;
             double *d0 = dec + (size_t)comp * l * N;
@@ -789,7 +799,14 @@ F_CLONES static void f_blind_rotate_extract(const ora_fctx *c, const u64 *lwe, c
             double *a = acc + (size_t)oc * N;
             for (uint32_t x = 0; x < N; x++) a[x] = f_red(a[x] + o[x]);
         }
-    }
+}
+static void f_br_extract(const ora_fctx *c, f_scratch *s, u64 *out) {
+    const ora_params *P = &c->P;
+    uint32_t n = P->n, N = c->N, k = P->k, l = P->bs_levels, rows = (k + 1) * l, log2N = P->log_N + 1;
+    const uint32_t shift = 49 - l * P->bs_base_log;
+    const double sc = 1.0 / (double)((u64)1 << shift), B = (double)((u64)1 << P->bs_base_log), Binv = 1.0 / B;
+    double *acc = s->acc, *dec = s->dec, *res = s->res;
+    (void)n; (void)rows; (void)log2N; (void)sc; (void)B; (void)Binv; (void)dec; (void)res; (void)shift;
     for (uint32_t j = 0; j < k; j++) {
         const double *A = acc + (size_t)j * N;
         out[(size_t)j * N] = f_canon(A[0]);
@@ -797,19 +814,27 @@ F_CLONES static void f_blind_rotate_extract(const ora_fctx *c, const u64 *lwe, c
     }
     out[(size_t)k * N] = f_canon(acc[(size_t)k * N]);
 }
-
 /* same contract as ora_pbs_batch (ks_out optional) */
+#define F_GROUP 8
 void ora_fast_pbs_batch(const ora_fctx *c, const u64 *in, const u64 *tvs, const uint32_t *tv_ids, uint32_t count, u64 *out, u64 *ks_out) {
     uint32_t n = c->P.n, N = c->N, big = c->P.k * N + 1;
+    uint32_t groups = (count + F_GROUP - 1) / F_GROUP;
 #pragma omp parallel
     {
-        f_scratch s; f_scratch_make(c, &s);
+        f_scratch s[F_GROUP];
+        for (int g = 0; g < F_GROUP; g++) f_scratch_make(c, &s[g]);
 #pragma omp for schedule(dynamic, 1)
-        for (uint32_t i = 0; i < count; i++) {
-            f_keyswitch(c, in + (size_t)i * big, &s, s.small);
-            if (ks_out) memcpy(ks_out + (size_t)i * (n + 1), s.small, (n + 1) * 8);
-            f_blind_rotate_extract(c, s.small, tvs + (size_t)tv_ids[i] * N, &s, out + (size_t)i * big);
+        for (uint32_t gi = 0; gi < groups; gi++) {
+            const uint32_t first = gi * F_GROUP, m = count - first < F_GROUP ? count - first : F_GROUP;
+            for (uint32_t g = 0; g < m; g++) {
+                f_keyswitch(c, in + (size_t)(first + g) * big, &s[g], s[g].small);
+                if (ks_out) memcpy(ks_out + (size_t)(first + g) * (n + 1), s[g].small, (n + 1) * 8);
+                f_br_init(c, s[g].small, tvs + (size_t)tv_ids[first + g] * N, &s[g]);
+            }
+            for (uint32_t i = 0; i < n; i++)
+                for (uint32_t g = 0; g < m; g++) f_br_step(c, s[g].small, i, &s[g]);
+            for (uint32_t g = 0; g < m; g++) f_br_extract(c, &s[g], out + (size_t)(first + g) * big);
         }
-        f_scratch_free(&s);
+        for (int g = 0; g < F_GROUP; g++) f_scratch_free(&s[g]);
     }
 }

@@ -230,3 +230,85 @@ def test_pbs_known_answer_digests():
     assert h(ctx.keyswitch(ct)) == case["keyswitched"]
     assert h(ctx.pbs(ct, tv[None, :], np.zeros(len(kat["msgs"]), np.uint32))) == case["bootstrapped"]
     ctx.close()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# The 2^64 torus (q_bits = 65, Concrete's modulus): wrap-around arithmetic, exact external products through Goldilocks
+# transforms of the key's 32-bit halves - pinned to the wrap-around schoolbook product.
+@pytest.fixture
+def torus():
+    to.set_field(to.TORUS64)
+    yield 1 << 64
+    to.set_field(64)
+
+
+def rand_u64(n):
+    return RNG.integers(0, 2**63, n, dtype=np.uint64) * np.uint64(2) + RNG.integers(0, 2, n, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("logN", [2, 5, 8, 10])
+def test_torus_split_product_matches_wraparound_schoolbook(torus, logN):
+    N = 1 << logN
+    d = RNG.integers(-(1 << 14), (1 << 14) + 1, N)            # decomposition digits, both extremes reachable
+    d[0], d[-1] = -(1 << 14), 1 << 14
+    b = rand_u64(N)
+    b[:3] = [0, (1 << 64) - 1, 1 << 63]
+    assert np.array_equal(to.torus_negacyclic(logN, d, b), to.torus_negacyclic(logN, d, b, schoolbook=True))
+    e1 = np.zeros(N, np.int64); e1[N - 1] = 1
+    e2 = np.zeros(N, np.uint64); e2[1] = 5
+    c = to.torus_negacyclic(logN, e1, e2)
+    assert int(c[0]) == (1 << 64) - 5 and not c[1:].any()      # X^(N-1) * 5X = -5
+    with pytest.raises(ValueError):
+        to.torus_negacyclic(10, d[:1024] if N >= 1024 else np.zeros(1024, np.int64), np.zeros(1024, np.uint64), bound_log=30)
+
+
+def test_torus_modswitch_decompose_and_wraparound(torus):
+    for a in list(rand_u64(200)) + [0, (1 << 64) - 1, 1 << 63, (1 << 63) - 1, 1 << 52, (1 << 52) - 1]:
+        for lg in (5, 11):
+            assert to.modswitch(a, lg) == ((int(a) * (1 << lg) + (1 << 63)) >> 64) % (1 << lg)
+        d = to.decompose(a, 3, 15)
+        assert all(-(1 << 14) <= int(x) < (1 << 14) for x in d[1:]) and abs(int(d[0])) <= 1 << 14
+        c = int(a) - (1 << 64) if int(a) >> 63 else int(a)
+        rec = sum(int(d[i]) << (64 - 15 * (i + 1)) for i in range(3))
+        assert abs(rec - c) <= 1 << 18 and rec % (1 << 19) == 0
+    assert to.modulus() == 1 << 64 and list(to.encode([-1, 8], 59)) == [(1 << 64) - (1 << 59), 1 << 62]
+
+
+@pytest.mark.parametrize("p", [1, 4])
+def test_torus_pbs_evaluates_every_lut_entry(torus, p):
+    P = to.default_params(n=16, log_N=8, q_bits=to.TORUS64, lwe_noise=2.0 ** -40, glwe_noise=2.0 ** -50)
+    K = to.keygen(P, 31 + p)
+    ctx = to.Ctx(P, K.bsk, K.ksk)
+    M = 1 << p
+    msgs = np.arange(-M // 2, M // 2)
+    table = np.array([(3 * m * m + m + 1) % M - M // 2 for m in msgs], dtype=np.int64)
+    dl = 63 - p
+    tv = to.make_test_vector(P.log_N, p, table, dl)
+    ct = to.lwe_encrypt(K.sk_big, P.glwe_noise, 7, 0, to.encode(msgs, dl))
+    assert list(to.decode(to.lwe_phase(K.sk_big, ct), dl)) == list(msgs)
+    out = ctx.pbs(ct, tv, np.zeros(M, np.uint32))
+    assert list(to.decode(to.lwe_phase(K.sk_big, out), dl)) == list(table)
+    ctx.close()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# The fast path (bench.py's CPU baseline): bit for bit the generic path.
+def test_fast_path_equals_generic_path(field49):
+    for kw in (dict(n=24, log_N=10), dict(n=12, log_N=10, ks_levels=5, ks_base_log=6)):
+        P = to.default_params(q_bits=49, **kw)
+        K = to.keygen(P, 77)
+        slow, fast = to.Ctx(P, K.bsk, K.ksk), to.FastCtx(P, K.bsk, K.ksk)
+        dl = 44
+        tvs = np.stack([to.make_test_vector(10, 4, np.arange(-8, 8), dl), to.make_test_vector(10, 4, RNG.integers(-8, 8, 16), dl)])
+        msgs = RNG.integers(-8, 8, 19)                      # two full groups of 8 and a ragged one
+        ct = to.lwe_encrypt(K.sk_big, P.glwe_noise, 77, 0, to.encode(msgs, dl))
+        ct[3, :1024] = rand_q49(1024, field49)              # arbitrary masks, extreme words
+        ct[4, :1024] = field49 - 1
+        ct[5, :] = 0
+        ids = (np.arange(19) % 2).astype(np.uint32)
+        a, ka = slow.pbs(ct, tvs, ids, want_ks=True)
+        b, kb = fast.pbs(ct, tvs, ids, want_ks=True)
+        assert np.array_equal(ka, kb) and np.array_equal(a, b)
+        slow.close(); fast.close()
+    with pytest.raises(ValueError):
+        to.FastCtx(to.default_params(q_bits=64, n=4), np.zeros((4, 6, 2, 1024), np.uint64), np.zeros((1024, 8, 5), np.uint64))

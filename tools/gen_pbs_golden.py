@@ -16,11 +16,11 @@ SEED = 0xC0FFEE
 MSGS = [-8, -3, 0, 5, 7]
 TABLE = [3, -8, 7, 0, -1, 5, -6, 2, 1, -4, 6, -7, 4, -2, -5, -3]
 out = {"seed": SEED, "msgs": MSGS, "table": TABLE, "cases": []}
-for q_bits, log_N in ((49, 10), (64, 10), (49, 11)):
+for q_bits, log_N in ((49, 10), (64, 10), (49, 11), (to.TORUS64, 10)):
     to.set_field(q_bits)
     P = to.default_params(q_bits=q_bits, log_N=log_N)
     K = to.keygen(P, SEED)
-    dl = q_bits - 1 - 4
+    dl = to.log_q(q_bits) - 1 - 4
     ctx = to.Ctx(P, K.bsk, K.ksk)
     ct = to.lwe_encrypt(K.sk_big, P.glwe_noise, SEED, 0, to.encode(MSGS, dl))
     tv = to.make_test_vector(log_N, 4, np.array(TABLE), dl)
