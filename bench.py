@@ -199,6 +199,18 @@ def main():
              65: "ciphertexts mod 2^64 (Concrete's torus); exact external products: digit transforms mod 2^49-720895 in f64 "
                  "against three 22-bit limbs of every key word, recombined mod 2^64; keyswitch: int8 matrix cores"}
     DTYPE = {64: "u64", 49: "f64", 65: "u64/f64"}
+    # output noise of the timed batch against the analytic CGGI variance (tests/test_gpu_parity.py holds it to +-15 %)
+    def output_noise(e, outputs, expected):
+        Pp, Qm, dlx = e.P, e.modulus, e.delta_log()
+        err = np.array([((int(x) - (int(m) << dlx)) + Qm // 2) % Qm - Qm // 2 for x, m in zip(e.phase(outputs), expected)],
+                       dtype=np.float64) / float(Qm)
+        Bg = 2.0 ** Pp.bs_base_log
+        analytic = Pp.n * (Pp.bs_levels * (Pp.k + 1) * Pp.N * (Bg * Bg + 2) / 12.0 * Pp.glwe_noise ** 2
+                           + (1 + Pp.k * Pp.N / 2.0) / (12.0 * Bg ** (2 * Pp.bs_levels)))
+        return {"samples": int(err.size), "log2_std_measured": float(0.5 * np.log2(np.var(err))),
+                "log2_std_cggi_formula": float(0.5 * np.log2(analytic)), "variance_ratio": float(np.var(err) / analytic),
+                "log2_max_abs": float(np.log2(np.abs(err).max())), "log2_half_box": -5.0}
+
     total_pbs = B * world * args.steps
     value = total_pbs / elapsed
     achieved_gbs = BSK_BYTES_PER_PBS * B / (br_ms * 1e-3) / 1e9
@@ -223,6 +235,7 @@ def main():
                    "arithmetic": ARITH[eng.q_bits],
                    "keys": "bmi_keygen_insecure_deterministic(0x5EED): one key set replicated on every rank without an exchange",
                    "batch_per_gpu": B, "pbs_per_gpu_per_s": value / world, "verified_decrypt": verified,
+                   "output_noise": output_noise(eng, out, want) if rank == 0 else None,
                    "derived_reference_pbs_per_s_64core_cpu": "35-69 (derived, BASELINE.md §1)"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
@@ -302,7 +315,9 @@ def main():
                 kms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
                 ok2 = bool(np.array_equal(e2.decrypt(d_out2.cpu().numpy().view(np.uint64), dl2), want))
                 gbs = BSK_BYTES_PER_PBS * B / (kms * 1e-3) / 1e9
+                out2 = d_out2.cpu().numpy().view(np.uint64)
                 return {"q_bits": qb, "pbs_per_s": B / dt, "ms_per_step": dt * 1e3, "verified_decrypt": ok2,
+                        "output_noise": output_noise(e2, out2, want),
                         "kernel": KERNEL[qb], "kernel_ms": kms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gbs / HBM_PEAK_GBS, "arithmetic": ARITH[qb]}
             finally:

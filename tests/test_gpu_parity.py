@@ -273,6 +273,49 @@ def test_pbs_device_pointers_and_noise_budget(eng, ora):
     assert np.max(np.abs(err)) < 2.0 ** (dl - 9)  # half a box is 2^(dl-1)
 
 
+def cggi_output_variance(P, log_q):
+    """Analytic variance (relative to q^2) of the phase error after one blind rotation, binary keys (CGGI):
+    n CMUXes, each adding  l (k+1) N (Bg^2 + 2) / 12 * sigma_bsk^2  (digits uniform in [-Bg/2, Bg/2) against fresh key noise)
+    +  (1 + k N / 2) / (12 Bg^(2l))  (the rounding of the decomposition, carried by the binary GLWE key)."""
+    N, k, l, Bg = P.N, P.k, P.bs_levels, 2.0 ** P.bs_base_log
+    key = l * (k + 1) * N * (Bg * Bg + 2) / 12.0 * P.glwe_noise ** 2
+    rnd = (1 + k * N / 2.0) * (1.0 / (12.0 * Bg ** (2 * l)) - 1.0 / (12.0 * 4.0 ** log_q))
+    return P.n * (key + rnd)
+
+
+def test_pbs_output_noise_matches_the_cggi_formula(eng):
+    """the output noise of one PBS, measured over 4,096 bootstraps per modulus, against the analytic
+    CGGI variance for (n 630, N 1024, k 1, l 3, Bg 2^15).  Exact arithmetic adds no error of its own, so the measured
+    variance must sit AT the formula (within sampling + the formula's uniform-digit idealisation) on all three
+    moduli - in particular the 49-bit field is not noisier than its parameters say (its key noise is 2^-40 by choice,
+    the 64-bit moduli use 2^-44).  Also: mean error ~ 0, worst sample far inside half a box (2^-5 of the torus)."""
+    import torch
+    rng = np.random.default_rng(33)
+    B = 4096
+    dl = eng.delta_log()
+    msgs = rng.integers(-8, 8, B)
+    table = rng.integers(-8, 8, 16)
+    lid = eng.lut_register(table, 4, dl)
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(eng.encrypt(msgs, dl).view(np.int64)).to(dev)
+    d_ids = torch.full((B,), lid, dtype=torch.int32, device=dev)
+    d_out = torch.empty_like(d_in)
+    eng.pbs(d_in, d_ids, B, d_out, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy().view(np.uint64)
+    want = table[msgs + 8]
+    assert np.array_equal(eng.decrypt(out, dl), want)
+    Q = eng.modulus
+    err = np.array([((int(x) - (int(m) << dl)) + Q // 2) % Q - Q // 2 for x, m in zip(eng.phase(out), want)], dtype=np.float64) / float(Q)
+    measured, analytic = float(np.var(err)), cggi_output_variance(eng.P, eng.log_q)
+    ratio = measured / analytic
+    print(f"q_bits {eng.q_bits}: log2 std measured {0.5 * np.log2(measured):.2f}, CGGI {0.5 * np.log2(analytic):.2f}, "
+          f"variance ratio {ratio:.3f}, max |err| 2^{np.log2(np.abs(err).max()):.2f}")
+    assert 0.85 < ratio < 1.15, ratio                     # 4,096 samples: the variance estimate itself is +-2.2 % (1 sigma)
+    assert abs(err.mean()) < 4 * np.sqrt(measured / B)
+    assert np.abs(err).max() < 2.0 ** -9                  # half a box is 2^-5
+
+
 @pytest.mark.parametrize("q_bits,kw", [(64, dict(n=97, ks_levels=5, ks_base_log=6)), (49, dict(n=97, ks_levels=5, ks_base_log=6)),
                                        (49, dict(n=639, ks_levels=4, ks_base_log=7))],
                          ids=["goldilocks64-n97", "p49-n97", "p49-n639-max"])
