@@ -45,6 +45,7 @@ _U64P = C.POINTER(C.c_uint64)
 _SIGS = {
     "bmi_default_params": [C.POINTER(Params)],
     "bmi_default_params_for": [C.c_uint32, C.POINTER(Params)],
+    "bmi_preset_params": [C.c_char_p, C.POINTER(Params)],
     "bmi_ctx_create": [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)],
     "bmi_get_params": [C.c_void_p, C.POINTER(Params)],
     "bmi_keygen": [C.c_void_p],
@@ -172,6 +173,17 @@ def default_params(q_bits=None, **kw):
     rc = lib.bmi_default_params(C.byref(P)) if q_bits is None else lib.bmi_default_params_for(int(q_bits), C.byref(P))
     if rc != 0:
         raise BmiError("unsupported q_bits (64, 49 or TORUS64 = 65)")
+    for k, v in kw.items():
+        setattr(P, k, v)
+    return P
+
+
+def preset_params(name, **kw):
+    """named parameter set of the library: "north_star", "north_star_torus64", "north_star_goldilocks", "secure128"
+    (n 742, N 2048: the 128-bit-secure set, include/bmi_tfhe.h)"""
+    P = Params()
+    if load_library().bmi_preset_params(name.encode(), C.byref(P)) != 0:
+        raise BmiError(f"unknown parameter preset {name!r}")
     for k, v in kw.items():
         setattr(P, k, v)
     return P

@@ -353,7 +353,7 @@ bool params_supported(const bmi_params &P, std::string &why) {
     }
     if (P.k != 1) { why = "only k = 1 has a HIP kernel in this build"; return false; }
     if (P.bs_levels != 3 || P.bs_base_log != 15) { why = "only (l, Bg) = (3, 2^15) has a HIP kernel in this build"; return false; }
-    if (P.n == 0 || P.n > 639) { why = "n must be in [1, 639]"; return false; }
+    if (P.n == 0 || P.n > BMI_MAX_LWE_N) { why = "n must be in [1, 1024]"; return false; }
     if (P.q_bits != 0 && P.q_bits != 64 && P.q_bits != 49 && P.q_bits != BMI_Q_TORUS64) {
         why = "q_bits must be 64 (2^64-2^32+1), 49 (2^49-720895) or BMI_Q_TORUS64 (2^64)";
         return false;
@@ -375,6 +375,22 @@ int bmi_default_params_for(uint32_t q_bits, bmi_params *out) {
 }
 
 int bmi_default_params(bmi_params *out) { return bmi_default_params_for(BMI_DEFAULT_Q_BITS, out); }
+
+int bmi_preset_params(const char *name, bmi_params *out) {
+    if (!name || !out) return -1;
+    const std::string s(name);
+    if (s == "north_star") return bmi_default_params_for(49, out);
+    if (s == "north_star_torus64") return bmi_default_params_for(BMI_Q_TORUS64, out);
+    if (s == "north_star_goldilocks") return bmi_default_params_for(64, out);
+    if (s == "secure128") {
+        // n = 742 with LWE noise 7.07e-6 (2^-17.11) and a GLWE of size k N = 2048: the two security-relevant pairs of
+        // TFHE-rs' published 128-bit set PARAM_MESSAGE_2_CARRY_2_KS_PBS (see bmi_tfhe.h); the GLWE noise is kept at
+        // 2^-44 >= that set's 2.94e-16, so the GLWE side is at least as hard.  Keyswitch 5 levels x 3 bits as in that set.
+        *out = bmi_params{742, 11, 1, 3, 15, 5, 3, 49, 7.069849454709433e-6, std::ldexp(1.0, -44)};
+        return 0;
+    }
+    return -1;
+}
 
 const char *bmi_last_error(const bmi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -883,6 +899,8 @@ int bmi_keyswitch_batch(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
     HIP_OK(c, hipSetDevice(c->device));
     if (c->ks_variant == 0 && c->ks_mfma_ok && count >= BMI_KS_MFMA_MIN) return keyswitch_mfma(c, d_in, count, d_small, (hipStream_t)stream);
+    if (c->P.n + 1 > 3 * 256)   // ks_lincomb.hpp: KS_COLS x KS_THREADS output columns per workgroup
+        return fail(c, -1, "the scalar keyswitch kernel takes n <= 767; this parameter set needs the matrix-core form");
     // Scalar form.  The row walk (k*N*levels rows) of one workgroup is the latency of a small batch, so it is split over
     // `slices` workgroups per tile of 8 ciphertexts (partial 128-bit sums + a reduce kernel) until the launch
     // has ~1024 workgroups; large batches fill the chip with one slice.

@@ -39,6 +39,11 @@
 // mask the ids they are handed with it, so that a wrong id in a device-resident id array reads a wrong (possibly
 // unregistered) table instead of faulting; the host-buffer entry points refuse unknown ids outright.
 #define BMI_LUT_CAP 1024
+// Largest small-LWE dimension n the blind-rotation kernels take: every kernel stages the n + 1 mod-switched words of a
+// ciphertext in LDS as uint16 (BMI_AT_WORDS 8-byte words per ciphertext).
+#define BMI_MAX_LWE_N 1024
+constexpr int BMI_AT_WORDS = 264;   // 1,056 uint16 slots >= BMI_MAX_LWE_N + 1
+constexpr int BMI_LDS_WORDS_MAX = 160 * 1024 / 8;   // 160 KB of LDS per workgroup on gfx950
 #ifndef BMI_KS_MFMA_MIN
 #define BMI_KS_MFMA_MIN 1  // smallest batch that takes the matrix-core keyswitch (0.05 ms against 0.14 ms scalar even at one ciphertext)
 #endif

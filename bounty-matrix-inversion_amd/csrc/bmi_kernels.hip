@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(128 * CTS, 2)
     k_blind_rotate_tp(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
                       const u64 *__restrict__ luts, const u64 *__restrict__ bsk, const u64 *__restrict__ g_tw,
                       u64 *__restrict__ out, uint32_t count, uint32_t n) {
-    constexpr int AT_WORDS = 160;  // 640 x uint16 per ciphertext
+    constexpr int AT_WORDS = BMI_AT_WORDS;
     __shared__ u64 lds[TW_WORDS + 2 * CTS * SCRATCH_WORDS + CTS * AT_WORDS];
     stage_twiddles(lds, g_tw);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -207,7 +207,8 @@ __global__ void __launch_bounds__(128 * CTS, 2)
 //   phase C  waves 0,1: inverse transform of one output polynomial each, accumulated into the LDS accumulator.
 // LDS: twiddles | acc[2][1024] | 6 tiles | Y[2][1024] | mod-switched mask.  ~101 KB -> one workgroup per CU.
 constexpr int LAT_THREADS = 512;
-constexpr int LAT_LDS_WORDS = TW_WORDS + 2 * N + 6 * SCRATCH_WORDS + 2 * N + 160;
+constexpr int LAT_LDS_WORDS = TW_WORDS + 2 * N + 6 * SCRATCH_WORDS + 2 * N + BMI_AT_WORDS;
+static_assert(LAT_LDS_WORDS <= BMI_LDS_WORDS_MAX, "LAT_LDS_WORDS exceeds the 160 KB of LDS");
 
 __global__ void __launch_bounds__(LAT_THREADS)
     k_blind_rotate_lat(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,

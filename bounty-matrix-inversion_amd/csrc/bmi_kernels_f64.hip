@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
     k_blind_rotate_tp49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
                         const double *__restrict__ luts, const double *__restrict__ bsk, const double *__restrict__ g_tw,
                         u64 *__restrict__ out, uint32_t count, uint32_t n) {
-    constexpr int AT_WORDS = 160;
+    constexpr int AT_WORDS = BMI_AT_WORDS;
     __shared__ double lds[TW_WORDS + 2 * CTS * SCRATCH_WORDS + CTS * AT_WORDS];
     stage_twiddles(lds, g_tw);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -214,8 +214,9 @@ __global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
 // the CU (8 wavefronts share one copy of the twiddle tables, which leaves LDS room for the accumulators: the
 // accumulator lives in LDS between iterations, not in registers).
 constexpr int TPX_CTS = 4;
-constexpr int TPX_AT_WORDS = 160;
+constexpr int TPX_AT_WORDS = BMI_AT_WORDS;
 constexpr int TPX_LDS_WORDS = TW_WORDS + 2 * TPX_CTS * (SCRATCH_WORDS + N) + TPX_CTS * TPX_AT_WORDS + 4 * TPX_CTS;
+static_assert(TPX_LDS_WORDS <= BMI_LDS_WORDS_MAX, "TPX_LDS_WORDS exceeds the 160 KB of LDS");
 
 __device__ __forceinline__ void pair_post(uint32_t *flag, uint32_t v) {
     __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -412,7 +413,8 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
 }
 
 constexpr int LAT_THREADS = 512;
-constexpr int LAT_LDS_WORDS = TW_WORDS + 2 * N + 6 * SCRATCH_WORDS + 2 * N + 160;
+constexpr int LAT_LDS_WORDS = TW_WORDS + 2 * N + 6 * SCRATCH_WORDS + 2 * N + BMI_AT_WORDS;
+static_assert(LAT_LDS_WORDS <= BMI_LDS_WORDS_MAX, "LAT_LDS_WORDS exceeds the 160 KB of LDS");
 
 __global__ void __launch_bounds__(LAT_THREADS)
     k_blind_rotate_lat49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
@@ -521,7 +523,8 @@ __global__ void __launch_bounds__(LAT_THREADS)
 //   C  wavefronts 0..3   = (o, parity): inverse half transform, accumulator update
 // The accumulator is kept de-interleaved in LDS (acc[c][parity][512]) so that every access of a wavefront is contiguous.
 constexpr int L2_THREADS = 1024;
-constexpr int L2_LDS_WORDS = ntth::HT_WORDS + 2 * N + 12 * ntth::HSCRATCH + 2 * N + 160;
+constexpr int L2_LDS_WORDS = ntth::HT_WORDS + 2 * N + 12 * ntth::HSCRATCH + 2 * N + BMI_AT_WORDS;
+static_assert(L2_LDS_WORDS <= BMI_LDS_WORDS_MAX, "L2_LDS_WORDS exceeds the 160 KB of LDS");
 
 __global__ void __launch_bounds__(256) k_bsk_to_lat49(const u64 *__restrict__ std_polys, double *__restrict__ lat_polys,
                                                       const double *__restrict__ g_tw_h, uint32_t n_polys) {
@@ -683,7 +686,8 @@ __global__ void __launch_bounds__(L2_THREADS)
 constexpr int W_N = 2 * N;                 // 2048
 constexpr int W_THREADS = 512;
 constexpr int W_T = TW_WORDS;              // T table [reg][lane] (1024 words), then T^-1 (1024 words)
-constexpr int W_LDS_WORDS = TW_WORDS + 2 * N + 2 * W_N + 8 * SCRATCH_WORDS + 264;
+constexpr int W_LDS_WORDS = TW_WORDS + 2 * N + 2 * W_N + 8 * SCRATCH_WORDS + BMI_AT_WORDS;
+static_assert(W_LDS_WORDS <= BMI_LDS_WORDS_MAX, "W_LDS_WORDS exceeds the 160 KB of LDS");
 
 // Issue priority of a wavefront (0..3).  Tasks that share a SIMD start at 3 and step down as they advance: the one that
 // is ahead yields issue slots to the others, so they finish together instead of the last one running its tail alone
@@ -904,7 +908,8 @@ __global__ void __launch_bounds__(W_THREADS)
 // through the tile region to eight inverse part-transform tasks.  The key copy is in slot order, scaled by 1/4.
 constexpr int Q_N = 4 * N;                 // 4096
 constexpr int Q_THREADS = 512;
-constexpr int Q_LDS_WORDS = TW_WORDS + 2 * Q_N + 8 * SCRATCH_WORDS + 264;
+constexpr int Q_LDS_WORDS = TW_WORDS + 2 * Q_N + 8 * SCRATCH_WORDS + BMI_AT_WORDS;
+static_assert(Q_LDS_WORDS <= BMI_LDS_WORDS_MAX, "Q_LDS_WORDS exceeds the 160 KB of LDS");
 constexpr double I4 = f49::centred_c(f49::powmod_c(f49::GEN, (f49::Q - 1) / 4));          // psi_8192^2048
 constexpr double I4_INV = f49::centred_c(f49::powmod_c(f49::GEN, 3 * ((f49::Q - 1) / 4)));  // -i
 static_assert(f49::mulmod_c(f49::powmod_c(f49::GEN, (f49::Q - 1) / 4), f49::powmod_c(f49::GEN, (f49::Q - 1) / 4)) == f49::Q - 1, "i^2 = -1");

@@ -32,8 +32,9 @@ namespace {
 
 constexpr int T64_LIMB_BITS = 22;
 constexpr int T64_CTS = 4;
-constexpr int T64_AT_WORDS = 160;
+constexpr int T64_AT_WORDS = BMI_AT_WORDS;
 constexpr int T64_LDS_WORDS = TW_WORDS + 2 * T64_CTS * (SCRATCH_WORDS + N) + T64_CTS * T64_AT_WORDS + 4 * T64_CTS;
+static_assert(T64_LDS_WORDS <= BMI_LDS_WORDS_MAX, "T64_LDS_WORDS exceeds the 160 KB of LDS");
 
 __device__ __forceinline__ uint32_t modswitch_t64(u64 a) {   // round(a * 2N / 2^64) mod 2N, ties up
     return (uint32_t)(((a >> (63 - (LOG_N + 1))) + 1) >> 1) & (2 * N - 1);

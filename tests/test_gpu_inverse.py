@@ -319,6 +319,23 @@ def test_encrypted_2x2_inverse_on_the_N2048_parameter_set():
         e.close()
 
 
+def test_encrypted_2x2_inverse_under_the_secure128_preset():
+    """The whole stack under 128-bit-secure parameters (n 742, N 2048, LWE noise 2^-17.1): digits equal the reference's."""
+    from bmi_amd import tfhe
+    from bmi_amd.main import EncryptedMatrixInversion
+    c = next(x for x in load("inverse.json") if x["tag"] == "baseline_b_n2_len20_ints8")
+    e = tfhe.Engine(tfhe.preset_params("secure128"))
+    try:
+        e.keygen()                                   # CSPRNG keys
+        emi = EncryptedMatrixInversion(2, None, 2, c["len"], c["ints"], False, False, engine=e)
+        M = np.array(c["M"]).reshape(2, 2)
+        q, s = emi.quantize(M)
+        out = emi.decrypt(emi.evaluate(emi.encrypt(q, s)))
+        assert out.tolist() == c["out"]
+    finally:
+        e.close()
+
+
 def test_six_bit_circuit_on_the_N4096_parameter_set():
     """Circuit(msg_bits=6) through the executor on the N = 4096 set: a 64-entry look-up, an 8 x 8 packed bivariate one
     and a 7-bit odd one on ciphertexts, against the plaintext simulation."""

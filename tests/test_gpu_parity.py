@@ -46,9 +46,11 @@ def ora(eng):
 
 
 @pytest.fixture(autouse=True)
-def _select_oracle_field(eng):
-    from oracle import tfhe_oracle as to
-    to.set_field(eng.q_bits)
+def _select_oracle_field(request):
+    """tests that take the engine fixture run the oracle on its modulus (the others select their own)"""
+    if "eng" in request.fixturenames:
+        from oracle import tfhe_oracle as to
+        to.set_field(request.getfixturevalue("eng").q_bits)
     yield
 
 
@@ -314,6 +316,54 @@ def test_pbs_output_noise_matches_the_cggi_formula(eng):
     assert 0.85 < ratio < 1.15, ratio                     # 4,096 samples: the variance estimate itself is +-2.2 % (1 sigma)
     assert abs(err.mean()) < 4 * np.sqrt(measured / B)
     assert np.abs(err).max() < 2.0 ** -9                  # half a box is 2^-5
+
+
+def test_secure128_preset_bit_exact_noise_and_margin():
+    """The 128-bit-secure preset (n 742, N 2048, LWE noise 2^-17.1; include/bmi_tfhe.h): keys, keyswitch, blind
+    rotation and PBS bit-exact against the oracle at these parameters; every 4-bit message through a random table;
+    keyswitch noise at its analytic value; the look-up margin it leaves (mod-switch + keyswitch noise vs half a box)."""
+    from bmi_amd import tfhe
+    from oracle import tfhe_oracle as to
+    P = tfhe.preset_params("secure128")
+    assert (P.n, P.N, P.k, P.bs_levels, P.q_bits, P.ks_levels, P.ks_base_log) == (742, 2048, 1, 3, 49, 5, 3) and abs(np.log2(P.lwe_noise) + 17.11) < 0.01
+    e = tfhe.Engine(P)
+    try:
+        e.keygen(SEED + 5)
+        to.set_field(49)
+        OP = to.Params(**{f: getattr(P, f) for f, _ in tfhe.Params._fields_})
+        sk_small, sk_big, bsk, ksk = e.export_keys()
+        K = to.keygen(OP, SEED + 5)
+        assert np.array_equal(K.bsk, bsk) and np.array_equal(K.ksk, ksk) and np.array_equal(K.sk_small, sk_small)
+        ctx = to.Ctx(OP, bsk, ksk)
+        rng = np.random.default_rng(41)
+        dl = e.delta_log()
+        table = rng.integers(-8, 8, 16)
+        lid = e.lut_register(table, 4, dl)
+        msgs = np.concatenate([np.arange(-8, 8)] * 32)                    # 512 ciphertexts, every message 32 times
+        ct = e.encrypt(msgs, dl)
+        small = e.keyswitch_host(ct)
+        assert np.array_equal(small[:40], ctx.keyswitch(ct[:40]))
+        out = e.pbs_host(ct, np.full(msgs.size, lid, np.uint32))
+        pick = rng.choice(msgs.size, 6, replace=False)
+        assert np.array_equal(out[pick], ctx.pbs(ct[pick], e.lut_get(lid)[None, :], np.zeros(6, np.uint32)))
+        assert np.array_equal(e.decrypt(out, dl), table[msgs + 8])
+        # keyswitch noise: phase error of the small ciphertexts, relative to q
+        Q = e.modulus
+        ph = to.lwe_phase(sk_small, small)
+        err = np.array([((int(x) - (int(m) << dl)) + Q // 2) % Q - Q // 2 for x, m in zip(ph, msgs)], dtype=np.float64) / Q
+        B = 2.0 ** P.ks_base_log
+        kN = P.k * P.N
+        analytic = kN * P.ks_levels * (B * B + 2) / 12.0 * P.lwe_noise ** 2 + kN / 2.0 / (12.0 * B ** (2 * P.ks_levels))
+        ratio = float(np.var(err)) / analytic
+        # what reaches the blind rotation, in units of the 2N positions of the circle: keyswitch noise + mod-switch rounding
+        sigma_pos = np.sqrt(np.var(err) * (2 * P.N) ** 2 + (P.n / 2.0 + 1) / 12.0)
+        margin = (2 * P.N / 32.0) / sigma_pos                                # half a 4-bit box in sigmas
+        print(f"secure128: keyswitch log2 std {0.5 * np.log2(np.var(err)):.2f} (analytic {0.5 * np.log2(analytic):.2f}, ratio "
+              f"{ratio:.3f}); positions sigma {sigma_pos:.2f} of {2 * P.N}; 4-bit look-up margin {margin:.1f} sigma")
+        assert 0.75 < ratio < 1.3 and margin > 12.0
+        ctx.close()
+    finally:
+        e.close()
 
 
 @pytest.mark.parametrize("q_bits,kw", [(64, dict(n=97, ks_levels=5, ks_base_log=6)), (49, dict(n=97, ks_levels=5, ks_base_log=6)),
