@@ -64,6 +64,33 @@ def base_p_to_float(arr, p):
 
 
 # ------------------------------------------------------------------------------------ helpers
+def _find_circuit(*xs):
+    for x in xs:
+        if isinstance(x, Lin):
+            return x.c
+        if isinstance(x, (list, tuple, np.ndarray)):
+            c = _find_circuit(*x)
+            if c is not None:
+                return c
+    return None
+
+
+def reference_signature(fn):
+    """Lets a digit-array primitive be called exactly like its namesake in the reference's base_p_arrays.py
+    (operands first: `base_p_subtraction(a, b, p, overflow)`), the circuit being found from the encrypted operands, as
+    well as with the circuit as a leading argument (how the QFloat layer of this package calls it)."""
+    import functools
+    from .circuit import Circuit as _Circuit
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        if args and (args[0] is None or isinstance(args[0], _Circuit)):
+            return fn(*args, **kw)
+        args = tuple(list(a) if isinstance(a, np.ndarray) else a for a in args)
+        return fn(_find_circuit(*args), *args, **kw)
+    return wrapper
+
+
 def lo_of(x):
     return x.lo if isinstance(x, Lin) else int(x)
 
@@ -266,6 +293,7 @@ def _lookahead_bits(c, S, span, bits):
     return bits
 
 
+@reference_signature
 def base_p_subtraction(c, a, b, p, overflow=False):
     """reference base_p_arrays.py:108-139: a - b with borrows, right-aligned, and (overflow=True) the flag a < b
     as defined there for unequal sizes.  Same integers as the reference's sequential borrow chain, computed
@@ -320,6 +348,7 @@ def base_p_subtraction(c, a, b, p, overflow=False):
     return out, bits[-1]
 
 
+@reference_signature
 def base_p_division(c, dividend, divisor, p):
     """reference base_p_arrays.py:173-203: restoring long division, MSD first; quotient has dividend.size digits.
 
@@ -421,6 +450,7 @@ def _division_radix(c, dividend, divisor, kbits):
     return quo
 
 
+@reference_signature
 def is_greater_or_equal(c, a, b):
     """reference base_p_arrays.py:245-260: 1 - (borrow out of a - b), by borrow look-ahead (log depth)."""
     m = min(len(a), len(b))
@@ -458,6 +488,7 @@ def is_greater_or_equal(c, a, b):
     return 1 - lut2(c, sig[1], sig[0], lambda h, l: int(_comb(h, l) == -1))
 
 
+@reference_signature
 def is_equal(c, a, b):
     """reference base_p_arrays.py:276-280: all digits equal (an AND tree instead of a wide sum)."""
     ne = [lut(c, x - y, lambda v: int(v != 0)) for x, y in zip(a, b)]
@@ -636,3 +667,43 @@ def carry_propagate_signed(c, digits, p):
             d = d.assume(min(vals), max(vals))
         out[L - 1 - i] = d
     return out
+
+
+# ------------------------------------------------------------------------------- tensorised twins
+# The reference's multi_* functions (base_p_arrays.py:142-170, 206-242, 263-273) apply the same primitive to every row
+# of a 2-D array so that Concrete sees one wide tensor operation.  Here every look-up of every row is an independent
+# node of the circuit and the level scheduler batches them whatever the call structure, so the twins are row maps:
+# same signatures, same results, and the same PBS levels as a "tensorised" formulation would produce.
+def _rows(x):
+    return [list(r) for r in x]
+
+
+def multi_base_p_subtraction(a_arrays, b_arrays, p, overflow=False):
+    res = [base_p_subtraction(a, b, p, overflow) for a, b in zip(_rows(a_arrays), _rows(b_arrays))]
+    if not overflow:
+        return res
+    return [d for d, _ in res], [lt for _, lt in res]
+
+
+def multi_base_p_division(dividends, divisors, p):
+    return [base_p_division(a, b, p) for a, b in zip(_rows(dividends), _rows(divisors))]
+
+
+def multi_is_greater_or_equal(a_arrays, b_arrays):
+    return [is_greater_or_equal(a, b) for a, b in zip(_rows(a_arrays), _rows(b_arrays))]
+
+
+def insert_array_at_index(a, B, i, j):
+    """a into row i of B from column j on, clipped on both sides (reference :326-338); B is a list of rows (or a 2-D array)"""
+    a = list(a)
+    if j < 0:
+        a, j = a[-j:], 0
+    n = min(len(B[i]) - j, len(a))
+    for t in range(max(n, 0)):
+        B[i][j + t] = a[t]
+
+
+def insert_array_at_index_3D(A, B, i, j):
+    """the same for every matrix of a stack: rows of A into B[m][i] (reference :341-354)"""
+    for m, a in enumerate(A):
+        insert_array_at_index(a, B[m], i, j)

@@ -420,7 +420,15 @@ class QFloat:
             self._is_base_tidy = False
             self.base_tidy()
         elif isinstance(other, Lin):
-            raise NotImplementedError("QFloat *= encrypted integer is not on the inverse's path")
+            # an encrypted integer (a Tracer in the reference, qfloat.py:858-865): sign and magnitude are one look-up
+            # each, every digit x magnitude one packed product, then the carries
+            c = other.c
+            s = c.lut(other, lambda v: (v > 0) - (v < 0))
+            mag = c.lut(other, abs)
+            self._array = [_mul(x, mag) for x in self._array]
+            self._sign = _mul(self._sign, s)
+            self._is_base_tidy = False
+            self.base_tidy()
         elif isinstance(other, SignedBinary):
             self._sign = _mul(self._sign, other.value)
         else:

@@ -611,3 +611,77 @@ def test_store_rows_are_recycled_only_after_the_last_consumer():
             owner[r] = n_in + int(i)
         pos += w
     assert len({int(row[o]) for o in outs}) == len(outs)
+
+
+def test_imul_by_an_integer_plain_and_encrypted_matches_reference_golden():
+    """QFloat *= k (reference qfloat.py:858-865): k a plain int, and k an ENCRYPTED integer in [-7, 7] (a Tracer there);
+    digits and sign equal the reference's on every golden case."""
+    cases = load("qfloat_ops.json")["imul_int"]
+    assert len(cases) == 40
+    # one circuit per format: the QFloat and the integer are both encrypted inputs
+    circuits = {}
+    for g in cases:
+        q = QFloat.from_float(g["f"], g["len"], g["ints"], 2)
+        assert [int(x) for x in q.array] == g["q"]["array"]
+        q *= g["k"]
+        assert [int(x) for x in q.array] == g["out"]["array"] and int(q.sign) == g["out"]["sign"], g
+        key = (g["len"], g["ints"])
+        if key not in circuits:
+            c = Circuit()
+            eq, _ = enc_q(c, g["q"], top=1)
+            k = c.input(-7, 7)
+            eq *= k
+            c.set_outputs(list(eq.array) + [eq.sign])
+            circuits[key] = c
+        c = circuits[key]
+        out = c.simulate(g["q"]["array"] + [g["q"]["sign"], g["k"]])
+        assert out[:-1] == g["out"]["array"], g
+        if any(g["out"]["array"]):                     # the reference leaves the sign of a zero product as it falls
+            assert out[-1] == g["out"]["sign"], g
+    assert all(c.stats["pbs"] > 0 for c in circuits.values())
+
+
+def test_digit_array_primitives_take_the_reference_signatures():
+    """base_p_arrays called exactly like the reference's (operands first, no circuit argument), plain and encrypted, and
+    the tensorised twins multi_* / insert_array_at_index (reference base_p_arrays.py:108-280, 326-354) on the goldens."""
+    from bmi_amd import base_p_arrays as bpa
+    g = load("base_p_arrays.json")
+    subs = [c for c in g if c["op"] == "sub" and c["p"] == 2]
+    assert subs
+    for c in subs:
+        a, b = np.array(c["a"]), np.array(c["b"])
+        d, lt = bpa.base_p_subtraction(a, b, 2, True)                       # reference call form, numpy operands
+        assert [int(x) for x in d] == c["diff"] and int(lt) == c["lt"]
+        assert [int(x) for x in bpa.base_p_subtraction(None, list(a), list(b), 2)] == c["diff_noov"]
+    same = [c for c in subs if len(c["a"]) == len(c["b"])]
+    same = [c for c in same if len(c["a"]) == len(same[0]["a"])]
+    assert same
+    D, LT = bpa.multi_base_p_subtraction(np.array([c["a"] for c in same]), np.array([c["b"] for c in same]), 2, True)
+    assert [[int(x) for x in r] for r in D] == [c["diff"] for c in same] and [int(x) for x in LT] == [c["lt"] for c in same]
+    assert [int(x) for x in bpa.multi_is_greater_or_equal([c["a"] for c in same], [c["b"] for c in same])] == [1 - c["lt"] for c in same]
+    # encrypted operands, reference call form: the circuit is found from the operands
+    c0 = same[0]
+    circ = Circuit()
+    ea = [circ.input(0, 1) for _ in c0["a"]]
+    eb = [circ.input(0, 1) for _ in c0["b"]]
+    d, lt = bpa.base_p_subtraction(ea, eb, 2, True)
+    ge = bpa.is_greater_or_equal(ea, eb)
+    circ.set_outputs(list(d) + [lt, ge])
+    out = circ.simulate(c0["a"] + c0["b"])
+    assert out[:-2] == c0["diff"] and out[-2] == c0["lt"]
+    # division twin
+    divs = [c for c in g if c["op"] == "div" and c["p"] == 2][:3]
+    for c in divs:
+        assert [int(x) for x in bpa.base_p_division(np.array(c["a"]), np.array(c["b"]), 2)] == c["q"]
+    if divs:
+        same_d = [c for c in divs if len(c["a"]) == len(divs[0]["a"]) and len(c["b"]) == len(divs[0]["b"])]
+        Q = bpa.multi_base_p_division([c["a"] for c in same_d], [c["b"] for c in same_d], 2)
+        assert [[int(x) for x in r] for r in Q] == [c["q"] for c in same_d]
+    # insertion helpers: clipping on both sides
+    B = [[0] * 5 for _ in range(2)]
+    bpa.insert_array_at_index([1, 2, 3], B, 0, 3)
+    bpa.insert_array_at_index([1, 2, 3], B, 1, -1)
+    assert B == [[0, 0, 0, 1, 2], [2, 3, 0, 0, 0]]
+    S = [[[0] * 4 for _ in range(2)] for _ in range(2)]
+    bpa.insert_array_at_index_3D([[7, 8], [9, 1]], S, 1, 3)
+    assert S[0][1] == [0, 0, 0, 7] and S[1][1] == [0, 0, 0, 9] and S[0][0] == [0] * 4

@@ -178,7 +178,14 @@ def gen_qfloat_ops(rng):
         q2 = QFloat.from_float(f2, 25, 0, 2)
         fm.append({"f1": f1, "f2": f2, "q1": qf_dump(q1), "q2": qf_dump(q2),
                    "out": qf_dump(QFloat.from_mul(q1, q2, 18, 1))})
-    return {"pairs": cases, "tidy": tid, "from_mul_mixed": fm}
+    # QFloat *= integer (qfloat.py:858-865; on a Tracer the integer is encrypted): no further rng draws above this line change
+    im = []
+    for f, ln, ints in [(13.75, 16, 8), (-7.3125, 18, 9), (0.40625, 14, 6), (101.0, 20, 10), (-0.0, 12, 6)]:
+        for kk in (-7, -3, -1, 0, 1, 2, 5, 7):
+            q = QFloat.from_float(f, ln, ints, 2)
+            q *= kk
+            im.append({"f": f, "len": ln, "ints": ints, "k": kk, "q": qf_dump(QFloat.from_float(f, ln, ints, 2)), "out": qf_dump(q)})
+    return {"pairs": cases, "tidy": tid, "from_mul_mixed": fm, "imul_int": im}
 
 
 # ------------------------------------------------------------------------ inverse
