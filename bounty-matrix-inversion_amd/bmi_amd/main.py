@@ -27,7 +27,15 @@ def estimated_evaluate_ms(circuit):
     return _estimate_widths(widths)
 
 
-def trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base=2, true_division=False, tensorize=False, division_bits=None):
+def message_bits_for(qfloat_base):
+    """Message bits of the look-ups a configuration needs: 4 for base 2 (every site restructured to fit, DESIGN.md §5);
+    other bases keep the reference's digit sums, whose leading-digit sums span up to 39 values (base 3): 5 bits with the
+    odd-function look-ups, i.e. the N = 2048 parameter sets (what Concrete solves by choosing wider parameters itself)."""
+    return 4 if qfloat_base == 2 else 5
+
+
+def trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base=2, true_division=False, tensorize=False, division_bits=None,
+                  msg_bits=None):
     """Builds the PBS circuit of qfloat_matrix_inverse (the analogue of fhe.Compiler(...).compile, main.py:53-66).
     Inputs are declared in the order: all n^2 * len digits (row-major), then the n^2 signs.
     Digit intervals: leading digit [0, 2*base - 1] (from_float does not reduce it), others
@@ -42,7 +50,7 @@ def trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base=2, true_division=False
         cands = (2, 3) if (n <= 3 and qfloat_base == 2) else (2,)
         best = None
         for bits in cands:
-            cir = trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize, bits)
+            cir = trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize, bits, msg_bits)
             est = estimated_evaluate_ms(cir) if len(cands) > 1 else 0.0
             if best is None or est < best[0]:
                 best = (est, cir)
@@ -50,13 +58,14 @@ def trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base=2, true_division=False
     saved = bpa.DIVISION_BITS
     bpa.DIVISION_BITS = int(division_bits)
     try:
-        return _trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize)
+        return _trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize,
+                              msg_bits or message_bits_for(qfloat_base))
     finally:
         bpa.DIVISION_BITS = saved
 
 
-def _trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize):
-    c = Circuit()
+def _trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize, msg_bits=MSG_BITS):
+    c = Circuit(msg_bits=msg_bits)
     top = 2 * qfloat_base - 1
     arrays = [[c.input(0, top if j == 0 else qfloat_base - 1) for j in range(qfloat_len)] for _ in range(n * n)]
     signs = [c.input(-1, 1) for _ in range(n * n)]
@@ -73,7 +82,8 @@ def compile_inverse(n, qfloat_len, qfloat_ints, qfloat_base=2, true_division=Fal
     later start.  The analogue of fhe.Compiler(...).compile (main.py:53-66), whose seconds the reference pays on
     every run.  Returns (program, info); info = {"cached", "seconds", "path"}."""
     key = dict(kind="inverse", n=int(n), len=int(qfloat_len), ints=int(qfloat_ints), base=int(qfloat_base),
-               truediv=bool(true_division), tensorize=bool(tensorize), divbits=division_bits or 0, msg=MSG_BITS)
+               truediv=bool(true_division), tensorize=bool(tensorize), divbits=division_bits or 0,
+               msg=message_bits_for(qfloat_base))
 
     def build():
         from . import base_p_arrays as bpa
@@ -112,6 +122,7 @@ class EncryptedMatrixInversion:
         self.program, self.compile_info = compile_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division,
                                                           tensorize, cache=cache)
         self.circuit = self.program      # what the reference calls the compiled circuit
+        self.msg_bits = self.program.msg_bits
         self.trace_seconds = time.time() - t0
         self.engine = engine
         self.device = device
@@ -122,7 +133,12 @@ class EncryptedMatrixInversion:
     def _engine(self):
         if self.engine is None:
             from . import tfhe  # raises BmiError when libbmi_tfhe.so or the GPU is missing: no CPU fallback
-            self.engine = tfhe.Engine(device=self.device)
+            # 4-bit look-ups: the north-star set (N = 1024); 5-bit ones (bases other than 2): N = 2048, same margin
+            params = None if self.msg_bits <= 4 else tfhe.default_params(q_bits=49, log_N=self.msg_bits + 6)
+            self.engine = tfhe.Engine(params, device=self.device)
+        if self.engine.P.N < (1 << (self.msg_bits + 6)):
+            raise ValueError(f"{self.msg_bits}-bit look-ups need a parameter set with N >= {1 << (self.msg_bits + 6)} "
+                             f"(this engine has N = {self.engine.P.N})")
         return self.engine
 
     def keygen(self, seed=None):
@@ -155,14 +171,14 @@ class EncryptedMatrixInversion:
 
     def encrypt(self, quantized_matrix: np.ndarray, qfloats_signs: np.ndarray) -> np.ndarray:
         flat = self._flat_inputs(quantized_matrix, qfloats_signs)
-        return self._engine().encrypt(flat, self._engine().delta_log(MSG_BITS))
+        return self._engine().encrypt(flat, self._engine().delta_log(self.msg_bits))
 
     def evaluate(self, encrypted_quantized_matrix: np.ndarray) -> np.ndarray:
         return self._executor().run(encrypted_quantized_matrix)
 
     def decrypt(self, encrypted_quantized_inverted_matrix: np.ndarray) -> np.ndarray:
         n2 = self.shape[0] * self.shape[1]
-        m = self._engine().decrypt(encrypted_quantized_inverted_matrix, self._engine().delta_log(MSG_BITS))
+        m = self._engine().decrypt(encrypted_quantized_inverted_matrix, self._engine().delta_log(self.msg_bits))
         return m.reshape(n2, self.qfloat_len + 1)
 
     def dequantize(self, quantized_inverted_matrix: np.ndarray) -> np.ndarray:

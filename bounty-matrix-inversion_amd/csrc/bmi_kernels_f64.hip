@@ -1105,7 +1105,7 @@ struct Field49 {
         i64 r = f49::rne_shift(f49::centered(a), f49::QBITS - levels * base_log);
         for (int lev = (int)levels - 1; lev >= 1; lev--) {
             const i64 rn = f49::rne_shift(r, base_log);
-            d[lev] = (unsigned char)(r - (rn << base_log) + half);
+            d[lev] = (unsigned char)(r - (i64)((u64)rn << base_log) + half);
             r = rn;
         }
         d[0] = (unsigned char)(r + half);

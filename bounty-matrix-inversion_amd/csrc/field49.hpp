@@ -51,7 +51,7 @@ F49_HD u64 from_i64(i64 v) { return v >= 0 ? (u64)v % Q : Q - ((u64)(-v) % Q); }
 F49_HD i64 centered(u64 a) { return a > (Q >> 1) ? (i64)a - (i64)Q : (i64)a; }
 // round-half-to-even of x / 2^k
 F49_HD i64 rne_shift(i64 x, uint32_t k) {
-    const i64 q = x >> k, rem = x - (q << k), half = (i64)1 << (k - 1);
+    const i64 q = x >> k, rem = x - (i64)((u64)q << k), half = (i64)1 << (k - 1);
     return (rem > half || (rem == half && (q & 1))) ? q + 1 : q;
 }
 F49_HD uint32_t modswitch(u64 a, uint32_t log2N) {

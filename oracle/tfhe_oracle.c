@@ -268,7 +268,7 @@ void ora_negacyclic_ntt(uint32_t logN, const u64 *a, const u64 *b, u64 *c) {
  * centred lift rounded to a multiple of 2^(64 - levels*base_log), exactly (no wrap). */
 /* round-half-to-even of x / 2^k (what v_rndne_f64 computes on the GPU) */
 static inline i64 rne_shift(i64 x, uint32_t k) {
-    i64 q = x >> k, rem = x - (q << k), half = (i64)1 << (k - 1);
+    i64 q = x >> k, rem = x - (i64)((u64)q << k), half = (i64)1 << (k - 1);   /* shifts of negative values through u64: defined */
     if (rem > half || (rem == half && (q & 1))) q++;
     return q;
 }
@@ -281,7 +281,7 @@ void ora_decompose(u64 a, uint32_t levels, uint32_t base_log, i64 *digits) {
         i64 r = rne_shift(c, shift);
         for (int lev = (int)levels - 1; lev >= 1; lev--) {
             i64 rn = rne_shift(r, base_log);
-            digits[lev] = r - (rn << base_log);
+            digits[lev] = r - (i64)((u64)rn << base_log);
             r = rn;
         }
         digits[0] = r;

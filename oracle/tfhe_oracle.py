@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "_build", "libtfhe_oracle.so")
+# BMI_ORACLE_SO selects another build of the same sources (the AddressSanitizer / UBSan one: `make -C oracle asan`, run
+# with LD_PRELOAD of libasan; profiles/r02_oracle_asan.txt)
+SO = os.environ.get("BMI_ORACLE_SO") or os.path.join(HERE, "_build", "libtfhe_oracle.so")
 Q = 0xFFFFFFFF00000001
 
 

@@ -336,6 +336,34 @@ def test_encrypted_2x2_inverse_under_the_secure128_preset():
         e.close()
 
 
+def test_encrypted_base3_inverse_matches_reference_golden():
+    """qfloat_base = 3 on ciphertexts (reference main.py:25, generic-p carries qfloat.py:607-626): the base-3 digit sums
+    need 5-bit look-ups, so the wrapper picks the N = 2048 parameter set by itself; digits == the reference's."""
+    from bmi_amd.main import EncryptedMatrixInversion
+    c = next(x for x in load("inverse.json") if x["tag"] == "uniform_3x3_base3")
+    emi = EncryptedMatrixInversion(3, None, 3, c["len"], c["ints"], False, False)
+    try:
+        assert emi.msg_bits == 5
+        emi.keygen(0x5EED)
+        assert emi.engine.P.N == 2048
+        M = np.array(c["M"]).reshape(3, 3)
+        q, s = emi.quantize(M)
+        assert q.tolist() == c["in_arrays"]
+        out = emi.decrypt(emi.evaluate(emi.encrypt(q, s)))
+        assert out.tolist() == c["out"]
+        assert emi.dequantize(out).flatten().tolist() == c["float"]
+        # the north-star set (N = 1024) cannot carry 5-bit look-ups: refused loudly, never silently wrong
+        from bmi_amd import tfhe
+        small = tfhe.Engine()
+        try:
+            with pytest.raises(ValueError):
+                EncryptedMatrixInversion(3, None, 3, c["len"], c["ints"], False, False, engine=small).keygen(1)
+        finally:
+            small.close()
+    finally:
+        emi.engine.close()
+
+
 def test_six_bit_circuit_on_the_N4096_parameter_set():
     """Circuit(msg_bits=6) through the executor on the N = 4096 set: a 64-entry look-up, an 8 x 8 packed bivariate one
     and a 7-bit odd one on ciphertexts, against the plaintext simulation."""

@@ -363,7 +363,7 @@ def test_circuit_guards():
     assert c3.stats["pbs"] == 1 and c3.stats["cse_hits"] == 1 and isinstance(p, Lin) and q.terms == p.terms
 
 
-CASES = [c for c in load("inverse.json") if c["base"] == 2]     # every BASELINE config incl. 8x8 (len 48, ints 16)
+CASES = load("inverse.json")     # every golden: all BASELINE configs incl. 8x8 (len 48, ints 16), base 3 (5-bit look-ups)
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["tag"])

@@ -1,7 +1,9 @@
 """Tracer-compatible stand-in for `concrete.fhe` that runs the reference's UNMODIFIED base_p_arrays.py / qfloat.py on
-this repo's circuit IR (bmi_amd.circuit), i.e. on MI355X ciphertexts.  Development tooling: it needs /root/reference at
-run time, so it lives under tools/ and is used to produce data fixtures (traced circuits + expected outputs), never
-imported by the product or on the GPU box.
+this repo's circuit IR (bmi_amd.circuit), i.e. on MI355X ciphertexts.  Development tooling, never imported by the
+product: to trace the REFERENCE's functions it needs /root/reference (build container only; that is how the fixtures
+under tests/golden/ref_*.json* were made), while the shim itself is this repo's own code and one GPU test
+(tests/test_gpu_inverse.py::test_shim_compiler_surface_runs_on_the_gpu) imports it on the GPU box with a purpose-written
+function, to exercise its `ENCSHIM_BACKEND=gpu` Circuit (encrypt / run / decrypt through the engine).
 
 How it works (the reference is data-oblivious, so its sequence of operations is the same on every input):
   1. MEASURE: the function runs on an inputset; every encrypted scalar carries the vector of its sample values, and
