@@ -218,8 +218,8 @@ def main():
     tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))
-            if tj.get("batch") == B and tj.get("kernel") == KERNEL[eng.q_bits]:
+            tj = json.load(open(tpath)).get("kernels", {}).get(KERNEL[eng.q_bits], {})
+            if tj.get("batch") == B:
                 traffic = tj.get("bytes_per_launch")
                 valu_busy = tj.get("valu_busy_frac")
         except Exception:

@@ -3,8 +3,8 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/final
-python bench.py --inverse-sizes 2,3,4 > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
-python bench.py --q-bits 64 --no-cpu-baseline --inverse-sizes 2 > gpurun_out/final/bench_q64.json 2> gpurun_out/final/bench_q64.err
+python bench.py --inverse-sizes ${BMI_INV_SIZES:-2,3,4} > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
+python bench.py --q-bits 65 --no-cpu-baseline --inverse-sizes 2 > gpurun_out/final/bench_torus64.json 2> gpurun_out/final/bench_torus64.err
 tail -c 3000 gpurun_out/final/bench_default.json
 B=8192
 rm -rf gpurun_out/final/prof

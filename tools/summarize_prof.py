@@ -42,8 +42,17 @@ for p in ("fetch", "write", "sq"):
                 per[(k, row["Counter_Name"])][row["Dispatch_Id"]] += float(row["Counter_Value"])
     for (k, c), d in per.items():
         counters[k][c] = sum(d.values()) / len(d)
-h = counters[hot]
-if "FETCH_SIZE" in h and "WRITE_SIZE" in h:
+traffic = {}
+tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+if os.path.exists(tpath):
+    try:
+        old = json.load(open(tpath))
+        traffic = old.get("kernels", {}) if "kernels" in old else {}
+    except Exception:
+        traffic = {}
+for hot in kernels:
+  h = counters[hot]
+  if "FETCH_SIZE" in h and "WRITE_SIZE" in h:
     # MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64-byte units as 32 -> x2
     h["hbm_bytes_per_launch_corrected"] = (2 * h["FETCH_SIZE"] + h["WRITE_SIZE"]) * 1024
     extra = {}
@@ -53,9 +62,10 @@ if "FETCH_SIZE" in h and "WRITE_SIZE" in h:
         wps = 2.0
         extra = {"valu_busy_frac": wps * h["SQ_ACTIVE_INST_VALU"] / h["SQ_WAVE_CYCLES"], "waves_per_simd": wps,
                  "valu_formula": "waves_per_simd * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES"}
-    json.dump({"batch": batch, "bytes_per_launch": h["hbm_bytes_per_launch_corrected"], "kernel": hot,
-               "source": f"profiles/{tag}_pmc_B{batch}.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", **extra},
-              open(os.path.join(REPO, "profiles", "hbm_traffic.json"), "w"), indent=1)
+    traffic[hot] = {"batch": batch, "bytes_per_launch": h["hbm_bytes_per_launch_corrected"], "kernel": hot,
+                    "source": f"profiles/{tag}_pmc_B{batch}.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", **extra}
+json.dump({"kernels": traffic}, open(tpath, "w"), indent=1)
+h = counters[kernels[0]]
 json.dump({"tag": tag, "batch": batch, "kernel_trace_avg_ns": avg_ns, "counters_avg_per_launch": counters,
            "note": "rocprofv3 --kernel-trace --stats pass and three separate --pmc passes of `python3 bench.py --batch "
                    f"{batch} --no-cpu-baseline --no-inverse` (tools/gpu_final.sh); FETCH_SIZE/WRITE_SIZE in KiB; FETCH doubled per MI355X_MICROARCH.md"},
