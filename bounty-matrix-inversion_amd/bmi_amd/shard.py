@@ -1,6 +1,8 @@
 """Batch sharding across the GPUs of one node.  Every PBS of a batch is independent, keys are
-replicated on every GPU by seeded keygen, so rank r simply owns a contiguous index range: no data-path
-collective, no RCCL traffic.  torch.distributed is used only for the timing barrier / MAX reduction."""
+replicated on every GPU by seeded keygen, so rank r simply owns a contiguous index range.  For PBS batches (bench.py)
+that is all: no data-path collective, no RCCL traffic; torch.distributed only carries the timing barrier / MAX
+reduction.  The encrypted inverse (executor.py) uses the same ranges per level and adds ONE all-gather per split level -
+the path's only exchange step."""
 from __future__ import annotations
 
 
