@@ -352,7 +352,15 @@ bool params_supported(const bmi_params &P, std::string &why) {
         return false;
     }
     if (P.k != 1) { why = "only k = 1 has a HIP kernel in this build"; return false; }
-    if (P.bs_levels != 3 || P.bs_base_log != 15) { why = "only (l, Bg) = (3, 2^15) has a HIP kernel in this build"; return false; }
+    const bool lb_default = P.bs_levels == 3 && P.bs_base_log == 15;
+    const bool lb_f64 = lb_default || (P.bs_levels == 2 && P.bs_base_log == 15) || (P.bs_levels == 1 && P.bs_base_log == 23);
+    // (2, 2^15) and (1, 2^23): the templated 49-bit kernels (N = 1024 wave-pair / latency kernels, N = 2048), and (2, 2^15) on the torus
+    const bool ok_lb = lb_default || (P.q_bits == 49 && P.log_N <= 11 && lb_f64) ||
+                       (P.q_bits == BMI_Q_TORUS64 && P.bs_levels == 2 && P.bs_base_log == 15);
+    if (!ok_lb) {
+        why = "(l, Bg) must be (3, 2^15); the 49-bit field at N <= 2048 also takes (2, 2^15) and (1, 2^23), the 2^64 torus (2, 2^15)";
+        return false;
+    }
     if (P.n == 0 || P.n > BMI_MAX_LWE_N) { why = "n must be in [1, 1024]"; return false; }
     if (P.q_bits != 0 && P.q_bits != 64 && P.q_bits != 49 && P.q_bits != BMI_Q_TORUS64) {
         why = "q_bits must be 64 (2^64-2^32+1), 49 (2^49-720895) or BMI_Q_TORUS64 (2^64)";
@@ -936,32 +944,39 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     int rc;
     if (c->t64()) {   // 2^64 torus: one kernel for every batch size
         rc = bmit::launch_blind_rotate(d_small, d_lut_ids, (const u64 *)c->d_luts, (const double *)c->d_bsk,
-                                       (const double *)c->d_tw, d_out, count, c->P.n, bmit::BSK_LIMBS, (hipStream_t)stream);
+                                       (const double *)c->d_tw, d_out, count, c->P.n, bmit::BSK_LIMBS, c->P.bs_levels, c->P.bs_base_log,
+                                       (hipStream_t)stream);
         return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
     }
     if (c->f64()) {
         const double *luts = (const double *)c->d_luts, *bsk = (const double *)c->d_bsk, *tw = (const double *)c->d_tw;
         hipStream_t st = (hipStream_t)stream;
         if (c->wide() || c->quad()) {   // N = 2048 / 4096: one kernel for every batch size
-            rc = (c->quad() ? bmi49::launch_blind_rotate_quad : bmi49::launch_blind_rotate_wide)(d_small, d_lut_ids, luts, c->d_bsk_lat, tw, c->d_tw_wide, d_out, count, c->P.n, st);
+            rc = c->quad() ? bmi49::launch_blind_rotate_quad(d_small, d_lut_ids, luts, c->d_bsk_lat, tw, c->d_tw_wide, d_out, count, c->P.n, st)
+                           : bmi49::launch_blind_rotate_wide(d_small, d_lut_ids, luts, c->d_bsk_lat, tw, c->d_tw_wide, d_out, count, c->P.n,
+                                                             c->P.bs_levels, c->P.bs_base_log, st);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }
         // auto mode falls back from the kernels that need > 64 KB of LDS per workgroup to their predecessors (still on
         // the GPU) if the device refuses the configuration; a pinned variant reports the error instead
-        if (c->variant == 4 || (latency && c->no_big_lds)) {
+        const bool lb3 = c->P.bs_levels == 3 && c->P.bs_base_log == 15;   // variants 1 and 4 exist for (3, 2^15) only
+        if (!lb3 && (c->variant == 1 || c->variant == 4))
+            return fail(c, -1, "kernel variants 1 and 4 exist for (l, Bg) = (3, 2^15) only");
+        const uint32_t lv = c->P.bs_levels, bl = c->P.bs_base_log;
+        if (c->variant == 4 || (latency && c->no_big_lds && lb3)) {
             rc = bmi49::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, st);
         } else if (latency) {
-            rc = bmi49::launch_blind_rotate_lat2(d_small, d_lut_ids, luts, c->d_bsk_lat, c->d_tw_half, d_out, count, c->P.n, st);
-            if (rc && c->variant == 0) {
+            rc = bmi49::launch_blind_rotate_lat2(d_small, d_lut_ids, luts, c->d_bsk_lat, c->d_tw_half, d_out, count, c->P.n, lv, bl, st);
+            if (rc && c->variant == 0 && lb3) {
                 (void)hipGetLastError();
                 c->no_big_lds = true;
                 rc = bmi49::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, st);
             }
-        } else if (c->variant == 1 || c->no_big_lds) {
+        } else if (c->variant == 1 || (c->no_big_lds && lb3)) {
             rc = bmi49::launch_blind_rotate_tp(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, st);
         } else {
-            rc = bmi49::launch_blind_rotate_tpx(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, st);
-            if (rc && c->variant == 0) {
+            rc = bmi49::launch_blind_rotate_tpx(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, lv, bl, st);
+            if (rc && c->variant == 0 && lb3) {
                 (void)hipGetLastError();
                 c->no_big_lds = true;
                 rc = bmi49::launch_blind_rotate_tp(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, st);

@@ -112,13 +112,17 @@ int launch_bsk_to_wide(const u64 *std_polys, double *wide_polys, const double *g
                        uint32_t n_polys, hipStream_t s);
 int launch_blind_rotate_wide(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk_wide,
                              const double *g_tw, const double *g_tw_wide, u64 *out, uint32_t count, uint32_t n,
-                             hipStream_t s);
+                             uint32_t levels, uint32_t base_log, hipStream_t s);
 // latency kernel, two wavefronts per transform (ntt_half_f64.hpp): own key copy in slot order, own twiddle tables
 int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, hipStream_t s);
+// (levels, base log) of the bootstrap decomposition: (3, 15), (2, 15) and (1, 23) are instantiated in the three kernels
+// below; the other 49-bit kernels (variants 1 and 4, N = 4096) and the Goldilocks ones take (3, 15) only
 int launch_blind_rotate_lat2(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk_lat,
-                             const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, hipStream_t s);
+                             const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, uint32_t levels, uint32_t base_log,
+                             hipStream_t s);
 int launch_blind_rotate_tpx(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
-                            const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s);
+                            const double *g_tw, u64 *out, uint32_t count, uint32_t n, uint32_t levels, uint32_t base_log,
+                            hipStream_t s);
 int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
                             const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s);
 int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
@@ -145,7 +149,8 @@ constexpr uint32_t KS_LIMBS = 9;    // balanced base-256 limbs of a keyswitch-ke
 int launch_bsk_to_limbs(const u64 *std_polys, double *limb_polys, const double *g_tw, uint32_t n_polys, int limbs,
                         hipStream_t s);
 int launch_blind_rotate(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_limbs,
-                        const double *g_tw, u64 *out, uint32_t count, uint32_t n, int limbs, hipStream_t s);
+                        const double *g_tw, u64 *out, uint32_t count, uint32_t n, int limbs, uint32_t levels,
+                        uint32_t base_log, hipStream_t s);   // (levels, base log) = (3, 15) or (2, 15)
 int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
                      uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,
                      hipStream_t s);

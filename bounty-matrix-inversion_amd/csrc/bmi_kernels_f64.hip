@@ -71,6 +71,32 @@ __device__ __forceinline__ double digit_of(double r, int lev) {
     return r2;
 }
 
+// The same for any (levels L, base 2^BG) with L * BG <= 48: SC rounds a centred coefficient to its top L * BG bits.
+template <int L, int BG>
+struct Dec {
+    static constexpr double SC = 1.0 / (double)(1ull << (49 - L * BG));
+    static constexpr double B = (double)(1ull << BG);
+    static constexpr double BINV = 1.0 / (double)(1ull << BG);
+    static_assert(L >= 1 && L <= 3 && L * BG <= 48, "decomposition must fit the 49-bit field");
+    // digit `lev` (0 = most significant) of the rounded value r, round-half-even steps
+    static __device__ __forceinline__ double digit(double r, int lev) {
+#pragma unroll
+        for (int t = L - 1; t > 0; t--) {
+            const double rn = __builtin_rint(r * BINV);
+            if (t == lev) return __builtin_fma(-B, rn, r);
+            r = rn;
+        }
+        return r;
+    }
+    // peels the least significant remaining digit off r
+    static __device__ __forceinline__ double peel(double &r) {
+        const double rn = __builtin_rint(r * BINV);
+        const double d = __builtin_fma(-B, rn, r);
+        r = rn;
+        return d;
+    }
+};
+
 // Phase timing (debug build only: make prof): wall-clock cycles per phase of one wavefront, see tools/phase_prof.py
 #ifdef BMI_PHASE_PROF
 __device__ unsigned long long g_phase[128];
@@ -252,7 +278,7 @@ __device__ __forceinline__ void pin() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int PF>
+template <int PF, int L = 3, int BG = 15>
 __global__ void __launch_bounds__(128 * TPX_CTS)
     k_blind_rotate_tpx49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
                          const double *__restrict__ luts, const double *__restrict__ bsk,
@@ -294,7 +320,7 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
         if (i % BMI_TPX49_RESYNC == 0) __syncthreads();  // keeps the four pairs on the same key rows (shared through L1)
 #endif
         const uint32_t a_t = at[i];
-        const double *bsk_c = bsk + ((size_t)i * 12 + c * 6) * N;  // this wavefront's three GGSW rows (two columns each)
+        const double *bsk_c = bsk + ((size_t)i * 4 * L + c * 2 * L) * N;  // this wavefront's L GGSW rows (two columns each)
 #if BMI_TPX49_PRIO == 1
         __builtin_amdgcn_s_setprio(1);
 #elif BMI_TPX49_PRIO == 2 || BMI_TPX49_PRIO == 4
@@ -314,12 +340,12 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
             static_for<0, 16>([&](auto J) {
                 const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
                 const double v = (e & N) ? -vr[J] : vr[J];
-                r[J] = __builtin_rint(f49::red(v - vs[J]) * 0x1p-4);
+                r[J] = __builtin_rint(f49::red(v - vs[J]) * Dec<L, BG>::SC);
             });
         }
         double am[16], ao[16];  // partial sums: own component, partner's component
-        static_for<0, 3>([&](auto LEV) {
-            constexpr int lev = 2 - LEV;  // least significant digit first
+        static_for<0, L>([&](auto LEV) {
+            constexpr int lev = L - 1 - LEV;  // least significant digit first
             const double2 *row_m = reinterpret_cast<const double2 *>(bsk_c + (size_t)(lev * 2 + c) * N);
             const double2 *row_o = reinterpret_cast<const double2 *>(bsk_c + (size_t)(lev * 2 + (c ^ 1)) * N);
             double2 bm[8], bo[8];
@@ -335,7 +361,7 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
             if constexpr (PM == 0) load_m();
             if constexpr (PO == 0) load_o();
             double x[16];
-            static_for<0, 16>([&](auto J) { x[J] = lev == 0 ? r[J] : peel_digit(r[J]); });
+            static_for<0, 16>([&](auto J) { x[J] = lev == 0 ? r[J] : Dec<L, BG>::peel(r[J]); });
             forward(
                 x, lane, lds, tile,
                 [&]() {
@@ -351,7 +377,7 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
             if constexpr (PO == 3) load_o();
             static_for<0, 8>([&](auto VP) {
                 const double m0 = f49::mul(x[2 * VP], bm[VP].x), m1 = f49::mul(x[2 * VP + 1], bm[VP].y);
-                if constexpr (lev == 2) {
+                if constexpr (lev == L - 1) {
                     am[2 * VP] = m0;
                     am[2 * VP + 1] = m1;
                 } else {
@@ -361,7 +387,7 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
             });
             static_for<0, 8>([&](auto VP) {
                 const double o0 = f49::mul(x[2 * VP], bo[VP].x), o1 = f49::mul(x[2 * VP + 1], bo[VP].y);
-                if constexpr (lev == 2) {
+                if constexpr (lev == L - 1) {
                     ao[2 * VP] = o0;
                     ao[2 * VP + 1] = o1;
                 } else {
@@ -523,7 +549,7 @@ __global__ void __launch_bounds__(LAT_THREADS)
 //   C  wavefronts 0..3   = (o, parity): inverse half transform, accumulator update
 // The accumulator is kept de-interleaved in LDS (acc[c][parity][512]) so that every access of a wavefront is contiguous.
 constexpr int L2_THREADS = 1024;
-constexpr int L2_LDS_WORDS = ntth::HT_WORDS + 2 * N + 12 * ntth::HSCRATCH + 2 * N + BMI_AT_WORDS;
+constexpr int L2_LDS_WORDS = ntth::HT_WORDS + 2 * N + 12 * ntth::HSCRATCH + 2 * N + BMI_AT_WORDS;   // 12 = 4 x (L = 3) tiles
 static_assert(L2_LDS_WORDS <= BMI_LDS_WORDS_MAX, "L2_LDS_WORDS exceeds the 160 KB of LDS");
 
 __global__ void __launch_bounds__(256) k_bsk_to_lat49(const u64 *__restrict__ std_polys, double *__restrict__ lat_polys,
@@ -556,6 +582,7 @@ __global__ void __launch_bounds__(256) k_bsk_to_lat49(const u64 *__restrict__ st
     }
 }
 
+template <int L = 3, int BG = 15>
 __global__ void __launch_bounds__(L2_THREADS)
     k_blind_rotate_lat2_49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
                            const double *__restrict__ luts, const double *__restrict__ bsk_lat,
@@ -587,17 +614,17 @@ __global__ void __launch_bounds__(L2_THREADS)
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t a_t = at[i];
         if (a_t == 0) continue;  // uniform over the workgroup
-        const double *bi = bsk_lat + (size_t)i * 12 * N;
+        const double *bi = bsk_lat + (size_t)i * 4 * L * N;
         PH_MARK(7);
-        double b[6][2];
+        double b[2 * L][2];
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
+        for (int r = 0; r < 2 * L; r++) {
             b[r][0] = bi[(size_t)(r * 2 + mo) * N + mp];
             b[r][1] = bi[(size_t)(r * 2 + mo) * N + ntth::HALF + mp];
         }
-        if (wave < 12) {
+        if (wave < 4 * L) {
             // (tasks -> SIMDs so that no SIMD gets three of the heavier odd halves: measured 4 % slower)
-            const int c = wave / 6, lev = (wave % 6) >> 1, h = wave & 1;
+            const int c = wave / (2 * L), lev = (wave % (2 * L)) >> 1, h = wave & 1;
             const int pz = wave >> 1;
             const double *ac = acc + c * N;
             double x[8];
@@ -610,7 +637,7 @@ __global__ void __launch_bounds__(L2_THREADS)
                 const uint32_t n2 = e & (N - 1);
                 double v = ac[(n2 & 1) * ntth::HALF + (n2 >> 1)];
                 v = (e & N) ? -v : v;
-                x[J] = digit_of(__builtin_rint(f49::red(v - ac[h * ntth::HALF + m]) * 0x1p-4), lev);
+                x[J] = Dec<L, BG>::digit(__builtin_rint(f49::red(v - ac[h * ntth::HALF + m]) * Dec<L, BG>::SC), lev);
             });
             double *tile = tiles + (2 * pz + h) * ntth::HSCRATCH;
             if (h) ntth::forward_half<true>(x, lane, lds, tile);
@@ -625,9 +652,9 @@ __global__ void __launch_bounds__(L2_THREADS)
         __syncthreads();
         PH_MARK(1);
         {
-            double ylo = 0.0, yhi = 0.0;  // lazy sums of six products (<= 10.2 q)
+            double ylo = 0.0, yhi = 0.0;  // lazy sums of 2 L <= six products (<= 10.2 q)
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
+            for (int r = 0; r < 2 * L; r++) {
                 const double e = tiles[(2 * r) * ntth::HSCRATCH + mp], od = tiles[(2 * r + 1) * ntth::HSCRATCH + mp];
                 ylo += f49::mul(e + od, b[r][0]);
                 yhi += f49::mul(e - od, b[r][1]);
@@ -741,6 +768,7 @@ __global__ void __launch_bounds__(128) k_bsk_to_wide49(const u64 *__restrict__ s
     }
 }
 
+template <int L = 3, int BG = 15>
 __global__ void __launch_bounds__(W_THREADS)
     k_blind_rotate_wide49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
                           const double *__restrict__ luts, const double *__restrict__ bsk_wide,
@@ -773,7 +801,7 @@ __global__ void __launch_bounds__(W_THREADS)
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t a_t = at[i];
         if (a_t == 0) continue;  // uniform over the workgroup
-        const double *bi = bsk_wide + (size_t)i * 12 * W_N;
+        const double *bi = bsk_wide + (size_t)i * 4 * L * W_N;
         PH_MARK(7);
         double ylo[4], yhi[4];
 #pragma unroll
@@ -805,7 +833,7 @@ __global__ void __launch_bounds__(W_THREADS)
             if (wave < 2 * NR) {
                 load_rows(IC0(), std::integral_constant<int, S1>());
                 pin();
-                const int row = R0 + (wave >> 1), c = row / 3, lev = row % 3, h = wave & 1;
+                const int row = R0 + (wave >> 1), c = row / L, lev = row % L, h = wave & 1;
                 const double *ac = acc + c * W_N;
                 double x[16];
                 prio<3>();
@@ -815,7 +843,7 @@ __global__ void __launch_bounds__(W_THREADS)
                     const uint32_t n2 = e & (W_N - 1);
                     double v = ac[(n2 & 1) * N + (n2 >> 1)];
                     v = (e & W_N) ? -v : v;
-                    x[J] = digit_of(__builtin_rint(f49::red(v - ac[h * N + m]) * 0x1p-4), lev);
+                    x[J] = Dec<L, BG>::digit(__builtin_rint(f49::red(v - ac[h * N + m]) * Dec<L, BG>::SC), lev);
                 });
                 pin();
                 load_rows(std::integral_constant<int, S1>(), std::integral_constant<int, S2>());
@@ -855,8 +883,13 @@ __global__ void __launch_bounds__(W_THREADS)
             __syncthreads();   // the tiles are rewritten by the next round / the sums below
             PH_MARK(3);
         };
-        round(std::integral_constant<int, 0>(), std::integral_constant<int, 4>());
-        round(std::integral_constant<int, 4>(), std::integral_constant<int, 2>());
+        // 2 L GGSW rows: rounds of at most four (eight half-transform tasks, one per wavefront)
+        if constexpr (L == 3) {
+            round(std::integral_constant<int, 0>(), std::integral_constant<int, 4>());
+            round(std::integral_constant<int, 4>(), std::integral_constant<int, 2>());
+        } else {
+            round(std::integral_constant<int, 0>(), std::integral_constant<int, 2 * L>());
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int idx = tid + W_THREADS * q, o = idx >> 10, p = idx & (N - 1);
@@ -1162,17 +1195,39 @@ int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const 
 }
 
 
+// (levels, base log) pairs the templated kernels are instantiated for
+#define BMI49_FOR_LB(levels, base_log, F)                            \
+    do {                                                             \
+        if ((levels) == 3 && (base_log) == 15) return F<3, 15>::go;  \
+        if ((levels) == 2 && (base_log) == 15) return F<2, 15>::go;  \
+        if ((levels) == 1 && (base_log) == 23) return F<1, 23>::go;  \
+        return nullptr;                                              \
+    } while (0)
+
+template <int L, int BG>
+struct LaunchTpx {
+    static int go(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk, const double *g_tw,
+                  u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+        static std::atomic<uint64_t> configured{0};
+        const size_t lds = (size_t)TPX_LDS_WORDS * sizeof(double);
+        auto kern = k_blind_rotate_tpx49<BMI_TPX49_PF, L, BG>;
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
+        hipLaunchKernelGGL(kern, dim3((count + TPX_CTS - 1) / TPX_CTS), dim3(128 * TPX_CTS), lds, s, small_cts, lut_ids, luts,
+                           bsk, g_tw, out, count, n);
+        BMI49_LAUNCH_CHECK();
+        return 0;
+    }
+};
+typedef int (*launch9_t)(const u64 *, const uint32_t *, const double *, const double *, const double *, u64 *, uint32_t, uint32_t,
+                         hipStream_t);
+static launch9_t pick_tpx(uint32_t levels, uint32_t base_log) { BMI49_FOR_LB(levels, base_log, LaunchTpx); }
+
 int launch_blind_rotate_tpx(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
-                            const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+                            const double *g_tw, u64 *out, uint32_t count, uint32_t n, uint32_t levels, uint32_t base_log,
+                            hipStream_t s) {
     if (count == 0) return 0;
-    static std::atomic<uint64_t> configured{0};
-    const size_t lds = (size_t)TPX_LDS_WORDS * sizeof(double);
-    auto kern = k_blind_rotate_tpx49<BMI_TPX49_PF>;
-    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
-    hipLaunchKernelGGL(kern, dim3((count + TPX_CTS - 1) / TPX_CTS), dim3(128 * TPX_CTS), lds, s, small_cts, lut_ids, luts,
-                       bsk, g_tw, out, count, n);
-    BMI49_LAUNCH_CHECK();
-    return 0;
+    launch9_t f = pick_tpx(levels, base_log);
+    return f ? f(small_cts, lut_ids, luts, bsk, g_tw, out, count, n, s) : (int)hipErrorInvalidValue;
 }
 
 
@@ -1204,17 +1259,30 @@ int launch_bsk_to_wide(const u64 *std_polys, double *wide_polys, const double *g
     return 0;
 }
 
+template <int L, int BG>
+struct LaunchWide {
+    static int go(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk_wide, const double *g_tw,
+                  const double *g_tw_wide, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+        static std::atomic<uint64_t> configured{0};
+        const size_t lds = (size_t)W_LDS_WORDS * sizeof(double);
+        auto kern = k_blind_rotate_wide49<L, BG>;
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
+        hipLaunchKernelGGL(kern, dim3(count), dim3(W_THREADS), lds, s, small_cts, lut_ids, luts, bsk_wide, g_tw, g_tw_wide, out,
+                           count, n);
+        BMI49_LAUNCH_CHECK();
+        return 0;
+    }
+};
+typedef int (*launch10_t)(const u64 *, const uint32_t *, const double *, const double *, const double *, const double *, u64 *,
+                          uint32_t, uint32_t, hipStream_t);
+static launch10_t pick_wide(uint32_t levels, uint32_t base_log) { BMI49_FOR_LB(levels, base_log, LaunchWide); }
+
 int launch_blind_rotate_wide(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk_wide,
                              const double *g_tw, const double *g_tw_wide, u64 *out, uint32_t count, uint32_t n,
-                             hipStream_t s) {
+                             uint32_t levels, uint32_t base_log, hipStream_t s) {
     if (count == 0) return 0;
-    static std::atomic<uint64_t> configured{0};
-    const size_t lds = (size_t)W_LDS_WORDS * sizeof(double);
-    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k_blind_rotate_wide49), lds, configured)) return rc;
-    hipLaunchKernelGGL(k_blind_rotate_wide49, dim3(count), dim3(W_THREADS), lds, s, small_cts, lut_ids, luts, bsk_wide, g_tw,
-                       g_tw_wide, out, count, n);
-    BMI49_LAUNCH_CHECK();
-    return 0;
+    launch10_t f = pick_wide(levels, base_log);
+    return f ? f(small_cts, lut_ids, luts, bsk_wide, g_tw, g_tw_wide, out, count, n, s) : (int)hipErrorInvalidValue;
 }
 
 int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, hipStream_t s) {
@@ -1223,16 +1291,27 @@ int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_t
     return 0;
 }
 
+template <int L, int BG>
+struct LaunchLat2 {
+    static int go(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk_lat, const double *g_tw_h,
+                  u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+        static std::atomic<uint64_t> configured{0};
+        const size_t lds = (size_t)L2_LDS_WORDS * sizeof(double);
+        auto kern = k_blind_rotate_lat2_49<L, BG>;
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
+        hipLaunchKernelGGL(kern, dim3(count), dim3(L2_THREADS), lds, s, small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n);
+        BMI49_LAUNCH_CHECK();
+        return 0;
+    }
+};
+static launch9_t pick_lat2(uint32_t levels, uint32_t base_log) { BMI49_FOR_LB(levels, base_log, LaunchLat2); }
+
 int launch_blind_rotate_lat2(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk_lat,
-                             const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+                             const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, uint32_t levels, uint32_t base_log,
+                             hipStream_t s) {
     if (count == 0) return 0;
-    static std::atomic<uint64_t> configured{0};
-    const size_t lds = (size_t)L2_LDS_WORDS * sizeof(double);
-    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(k_blind_rotate_lat2_49), lds, configured)) return rc;
-    hipLaunchKernelGGL(k_blind_rotate_lat2_49, dim3(count), dim3(L2_THREADS), lds, s, small_cts, lut_ids, luts, bsk_lat,
-                       g_tw_h, out, count, n);
-    BMI49_LAUNCH_CHECK();
-    return 0;
+    launch9_t f = pick_lat2(levels, base_log);
+    return f ? f(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s) : (int)hipErrorInvalidValue;
 }
 
 int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,

@@ -30,6 +30,15 @@ using namespace nttf;
 
 namespace {
 
+#ifndef BMI_T64_DB
+#define BMI_T64_DB 0      // key rows: 1 = one row requested ahead of the one being multiplied (12 spilled registers), 0 = request, then multiply (no spills); measured equal (156.5 vs 156.7 ms): the kernel is VALU-issue bound
+#endif
+#ifndef BMI_T64_RESYNC
+#define BMI_T64_RESYNC BMI_TPX49_RESYNC   // workgroup barrier every so many CMUXes (keeps the four pairs on the same key rows)
+#endif
+#ifndef BMI_T64_PRIO
+#define BMI_T64_PRIO 1    // 1 = issue priority steps down through the forward transforms (3, 2, 1), 0 in the limb loop; 0 = none
+#endif
 constexpr int T64_LIMB_BITS = 22;
 constexpr int T64_CTS = 4;
 constexpr int T64_AT_WORDS = BMI_AT_WORDS;
@@ -105,12 +114,15 @@ __device__ __forceinline__ double word_to_f64(i64 t) {
     return __builtin_fma((double)(int32_t)(t >> 32), 0x1p32, (double)(uint32_t)t);
 }
 
-template <int LIMBS>
+template <int LIMBS, int L = 3, int BG = 15>
 __global__ void __launch_bounds__(128 * T64_CTS)
     k_blind_rotate_t64(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids, const u64 *__restrict__ luts,
                        const double *__restrict__ bsk, const double *__restrict__ g_tw, u64 *__restrict__ out,
                        uint32_t count, uint32_t n) {
     constexpr int CTS = T64_CTS;
+    // exactness of a limb's sum: 2 L N terms of |digit| <= 2^(BG-1) times |limb| <= 2^(T64_LIMB_BITS-1) must stay below p/2
+    static_assert(2.0 * L * N * (double)(1ull << (BG - 1)) * (double)(1ull << (T64_LIMB_BITS - 1)) < f49::P / 2, "limb sums must stay below p/2");
+    static_assert(LIMBS * T64_LIMB_BITS >= 64 && L * BG < 63, "limbs must cover the 64-bit word");
     extern __shared__ double lds[];
     double *tiles = lds + TW_WORDS;
     u64 *accs = reinterpret_cast<u64 *>(tiles + 2 * CTS * SCRATCH_WORDS);
@@ -144,13 +156,15 @@ __global__ void __launch_bounds__(128 * T64_CTS)
 
     uint32_t hand = 0;   // handshake counter of the pair (one per inverse transform)
     for (uint32_t i = 0; i < n; i++) {
-#if BMI_TPX49_RESYNC
-        if (i % BMI_TPX49_RESYNC == 0) __syncthreads();  // keeps the four pairs on the same key rows (shared through L1)
+#if BMI_T64_RESYNC
+        if (i % BMI_T64_RESYNC == 0) __syncthreads();  // keeps the four pairs on the same key rows (shared through L1)
 #endif
         const uint32_t a_t = at[i];
         // this wavefront's three GGSW rows: [row = 3 c + lev][column][limb][N]
-        const double *bsk_c = bsk + ((size_t)i * 12 + c * 6) * LIMBS * N;
+        const double *bsk_c = bsk + ((size_t)i * 4 * L + c * 2 * L) * LIMBS * N;
+#if BMI_T64_PRIO
         __builtin_amdgcn_s_setprio(3);
+#endif
         wave_sync();
         double r[16];
         {
@@ -163,42 +177,50 @@ __global__ void __launch_bounds__(128 * T64_CTS)
             static_for<0, 16>([&](auto J) {
                 const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
                 const u64 v = (e & N) ? (u64)0 - vr[J] : vr[J];
-                const i64 t = (i64)(v - vs[J]) >> 18;                                   // 46 signed bits
-                r[J] = __builtin_floor(__builtin_fma(word_to_f64(t), 0.5, 0.5));         // round half up to 45 bits
+                const i64 t = (i64)(v - vs[J]) >> (64 - L * BG - 1);                    // L BG + 1 signed bits
+                r[J] = __builtin_floor(__builtin_fma(word_to_f64(t), 0.5, 0.5));         // round half up to L BG bits
             });
         }
-        double X[3][16];   // the three digit polynomials, transform domain, live across the limb loop
-        static_for<0, 3>([&](auto LEV) {
-            constexpr int lev = 2 - LEV;  // least significant digit first
+        double X[L][16];   // the L digit polynomials, transform domain, live across the limb loop
+        static_for<0, L>([&](auto LEV) {
+            constexpr int lev = L - 1 - LEV;  // least significant digit first
             pin();
+#if BMI_T64_PRIO
             __builtin_amdgcn_s_setprio(lev + 1);
+#endif
             static_for<0, 16>([&](auto J) {
                 if constexpr (lev == 0) {
                     X[0][J] = r[J];
                 } else {
-                    const double rn = __builtin_floor(__builtin_fma(r[J], 0x1p-15, 0.5));
-                    X[lev][J] = __builtin_fma(-32768.0, rn, r[J]);                       // digit in [-2^14, 2^14)
+                    const double rn = __builtin_floor(__builtin_fma(r[J], 1.0 / (double)(1ull << BG), 0.5));
+                    X[lev][J] = __builtin_fma(-(double)(1ull << BG), rn, r[J]);          // digit in [-2^(BG-1), 2^(BG-1))
                     r[J] = rn;
                 }
             });
             forward(X[lev], lane, lds, tile);
         });
+#if BMI_T64_PRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
         static_for<0, LIMBS>([&](auto JL) {
             constexpr int j = JL;
-            // six key rows of this limb, partner's column first (its partial sum is published while the own column is
-            // still being multiplied): rows 0..2 = (lev, column c^1), rows 3..5 = (lev, column c); one row in flight
+            // 2 L key rows of this limb, partner's column first (its partial sum is published while the own column is
+            // still being multiplied): rows 0..L-1 = (lev, column c^1), rows L..2L-1 = (lev, column c)
             auto row_ptr = [&](int q) {
-                const int lev = q % 3, col = q < 3 ? (c ^ 1) : c;
+                const int lev = q % L, col = q < L ? (c ^ 1) : c;
                 return reinterpret_cast<const double2 *>(bsk_c + ((size_t)(lev * 2 + col) * LIMBS + j) * N);
             };
-            double2 kb[2][8];
-            static_for<0, 8>([&](auto VP) { kb[0][VP] = row_ptr(0)[VP * 64 + lane]; });
+            double2 kb[BMI_T64_DB ? 2 : 1][8];
+            if constexpr (BMI_T64_DB) static_for<0, 8>([&](auto VP) { kb[0][VP] = row_ptr(0)[VP * 64 + lane]; });
             double acc[16];
             hand++;
-            static_for<0, 6>([&](auto Q) {
-                constexpr int q = Q, lev = q % 3, cur = q & 1;
-                if constexpr (q < 5) static_for<0, 8>([&](auto VP) { kb[cur ^ 1][VP] = row_ptr(q + 1)[VP * 64 + lane]; });
+            static_for<0, 2 * L>([&](auto Q) {
+                constexpr int q = Q, lev = q % L, cur = BMI_T64_DB ? (q & 1) : 0;
+                if constexpr (BMI_T64_DB) {
+                    if constexpr (q < 2 * L - 1) static_for<0, 8>([&](auto VP) { kb[cur ^ 1][VP] = row_ptr(q + 1)[VP * 64 + lane]; });
+                } else {
+                    static_for<0, 8>([&](auto VP) { kb[0][VP] = row_ptr(q)[VP * 64 + lane]; });
+                }
                 sched_fence();
                 static_for<0, 8>([&](auto VP) {
                     const double m0 = f49::mul(X[lev][2 * VP], kb[cur][VP].x), m1 = f49::mul(X[lev][2 * VP + 1], kb[cur][VP].y);
@@ -210,7 +232,7 @@ __global__ void __launch_bounds__(128 * T64_CTS)
                         acc[2 * VP + 1] += m1;
                     }
                 });
-                if constexpr (q == 2) {
+                if constexpr (q == L - 1) {
                     // the partner's partial goes through this wavefront's tile (free since the last transform)
                     wave_sync();
                     static_for<0, 8>([&](auto VP) {
@@ -295,18 +317,27 @@ int launch_bsk_to_limbs(const u64 *std_polys, double *limb_polys, const double *
     return 0;
 }
 
-int launch_blind_rotate(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_limbs,
-                        const double *g_tw, u64 *out, uint32_t count, uint32_t n, int limbs, hipStream_t s) {
-    if (count == 0) return 0;
-    if (limbs != 3) return (int)hipErrorInvalidValue;
+template <int L>
+static int launch_t64(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_limbs,
+                      const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
     static std::atomic<uint64_t> configured{0};
     const size_t lds = (size_t)T64_LDS_WORDS * sizeof(double);
-    auto kern = k_blind_rotate_t64<3>;
+    auto kern = k_blind_rotate_t64<3, L, 15>;
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
     hipLaunchKernelGGL(kern, dim3((count + T64_CTS - 1) / T64_CTS), dim3(128 * T64_CTS), lds, s, small_cts, lut_ids, luts,
                        bsk_limbs, g_tw, out, count, n);
     BMIT_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_blind_rotate(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_limbs,
+                        const double *g_tw, u64 *out, uint32_t count, uint32_t n, int limbs, uint32_t levels,
+                        uint32_t base_log, hipStream_t s) {
+    if (count == 0) return 0;
+    if (limbs != 3 || base_log != 15) return (int)hipErrorInvalidValue;
+    if (levels == 3) return launch_t64<3>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
+    if (levels == 2) return launch_t64<2>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
+    return (int)hipErrorInvalidValue;
 }
 
 int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,

@@ -367,19 +367,27 @@ def test_secure128_preset_bit_exact_noise_and_margin():
 
 
 @pytest.mark.parametrize("q_bits,kw", [(64, dict(n=97, ks_levels=5, ks_base_log=6)), (49, dict(n=97, ks_levels=5, ks_base_log=6)),
-                                       (49, dict(n=639, ks_levels=4, ks_base_log=7))],
-                         ids=["goldilocks64-n97", "p49-n97", "p49-n639-max"])
+                                       (49, dict(n=639, ks_levels=4, ks_base_log=7)),
+                                       (49, dict(n=1024, ks_levels=8, ks_base_log=4)),
+                                       (49, dict(n=211, bs_levels=2, bs_base_log=15)),
+                                       (49, dict(n=211, bs_levels=1, bs_base_log=23)),
+                                       (65, dict(n=211, bs_levels=2, bs_base_log=15)),
+                                       (65, dict(n=1024))],
+                         ids=["goldilocks64-n97", "p49-n97", "p49-n639", "p49-n1024-max", "p49-l2", "p49-l1-Bg23", "torus64-l2",
+                              "torus64-n1024-max"])
 def test_other_parameter_shape_bit_exact(q_bits, kw):
     """n = 97 (98 output columns: a ragged column block in the matrix-core keyswitch) with a 5 x 6-bit keyswitch
-    decomposition, and the largest supported n = 639 (640 columns exactly) with 4 x 7-bit digits (|d| <= 64, the
-    int8 limit of the matrix-core form): keyswitch (both kernels), every blind-rotation kernel and the fused PBS
-    against the oracle; an empty batch is a no-op on every entry point."""
+    decomposition, n = 639 (640 columns exactly) with 4 x 7-bit digits (|d| <= 64, the int8 limit of the matrix-core
+    form), the largest n = 1024, and the other bootstrap decompositions (l, Bg) = (2, 2^15) and (1, 2^23) on the 49-bit
+    field and (2, 2^15) on the 2^64 torus: keyswitch (both kernels), every blind-rotation kernel and the fused PBS
+    against the oracle, every 4-bit message through a random table; an empty batch is a no-op on every entry point."""
     from bmi_amd import tfhe
     from oracle import tfhe_oracle as to
     e = tfhe.Engine(tfhe.default_params(q_bits=q_bits, **kw))
     try:
         e.keygen(SEED + 1)
         sk_small, sk_big, bsk, ksk = e.export_keys()
+        to.set_field(q_bits)
         P = to.default_params(q_bits=q_bits, **kw)
         ctx = to.Ctx(P, bsk, ksk)
         rng = np.random.default_rng(16)
@@ -390,16 +398,31 @@ def test_other_parameter_shape_bit_exact(q_bits, kw):
         want_small = ctx.keyswitch(ct)
         assert np.array_equal(e.keyswitch_host(ct), want_small)
         e.set_keyswitch_variant(1)
-        assert np.array_equal(e.keyswitch_host(ct), want_small)
+        if e.P.n + 1 > 768:     # the scalar keyswitch kernel stops at n = 767: refused, not wrong
+            with pytest.raises(tfhe.BmiError):
+                e.keyswitch_host(ct)
+        else:
+            assert np.array_equal(e.keyswitch_host(ct), want_small)
         e.set_keyswitch_variant(0)
+        table = rng.integers(-8, 8, 16)
+        every = np.arange(-8, 8)
+        assert np.array_equal(e.decrypt(e.pbs_host(e.encrypt(every, dl), np.full(16, e.lut_register(table, 4, dl), np.uint32)), dl),
+                              table[every + 8])
         lid = e.lut_register(rng.integers(-8, 8, 16), 4, dl)
         tv = e.lut_get(lid)[None, :]
         ids = np.full(5, lid, np.uint32)
         want = ctx.blind_rotate(want_small[:5], tv, np.zeros(5, np.uint32))
+        default_lb = (e.P.bs_levels, e.P.bs_base_log) == (3, 15)
         for variant in (0, 1, 2, 3, 4):
             e.set_kernel_variant(variant)
+            if variant in (1, 4) and not default_lb and q_bits == 49:       # those two kernels exist for (3, 2^15) only
+                with pytest.raises(tfhe.BmiError):
+                    e.blind_rotate_host(want_small[:5], ids)
+                continue
             assert np.array_equal(e.blind_rotate_host(want_small[:5], ids), want), variant
         e.set_kernel_variant(0)
+        if e.P.n + 1 > 768:     # the scalar keyswitch kernel stops at n = 767: refused, not wrong
+            pass
         assert np.array_equal(e.pbs_host(ct[:5], ids), want)
         empty = np.zeros((0, e.P.big), np.uint64)
         assert e.pbs_host(empty, np.zeros(0, np.uint32)).shape == (0, e.P.big)

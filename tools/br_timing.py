@@ -13,10 +13,11 @@ def main():
     batches = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,64,4096").split(",")]
     variants = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1").split(",")]
     qb = int(sys.argv[3]) if len(sys.argv) > 3 else None
-    eng = tfhe.Engine(tfhe.default_params(q_bits=qb)); eng.keygen(0x5EED)
+    kw = {k[4:].lower(): int(v) for k, v in os.environ.items() if k.startswith("BMIP_")}   # e.g. BMIP_BS_LEVELS=2
+    eng = tfhe.Engine(tfhe.default_params(q_bits=qb, **kw)); eng.keygen(0x5EED)
     DL = eng.delta_log()
     sk_small, sk_big, bsk, ksk = eng.export_keys()
-    octx = to.Ctx(to.default_params(q_bits=eng.q_bits), bsk, ksk)
+    octx = to.Ctx(to.default_params(q_bits=eng.q_bits, **kw), bsk, ksk)
     lid = eng.lut_register(np.random.default_rng(9).integers(-8, 8, 16), 4, DL)
     tv = eng.lut_get(lid)[None, :]
     dev = torch.device("cuda:0")
@@ -55,6 +56,6 @@ def main():
             ks_scalar = e0.elapsed_time(e1) / reps
             ks_ok = ks_ok and np.array_equal(d_ks.cpu().numpy().view(np.uint64), small)
             eng.set_keyswitch_variant(0)
-            print(json.dumps({"B": B, "variant": v, "br_ms": round(ms, 3), "ks_ms": round(ks, 3), "ks_scalar_ms": round(ks_scalar, 3), "ks_exact": bool(ks_ok), "pbs_per_s": round(B / ((ms + ks) * 1e-3), 1), "bit_exact": bool(ok), "q_bits": eng.q_bits}), flush=True)
+            print(json.dumps({"B": B, "variant": v, "br_ms": round(ms, 3), "ks_ms": round(ks, 3), "ks_scalar_ms": round(ks_scalar, 3), "ks_exact": bool(ks_ok), "pbs_per_s": round(B / ((ms + ks) * 1e-3), 1), "bit_exact": bool(ok), "q_bits": eng.q_bits, **kw}), flush=True)
 
 main()
