@@ -393,8 +393,10 @@ int bmi_preset_params(const char *name, bmi_params *out) {
     if (s == "secure128") {
         // n = 742 with LWE noise 7.07e-6 (2^-17.11) and a GLWE of size k N = 2048: the two security-relevant pairs of
         // TFHE-rs' published 128-bit set PARAM_MESSAGE_2_CARRY_2_KS_PBS (see bmi_tfhe.h); the GLWE noise is kept at
-        // 2^-44 >= that set's 2.94e-16, so the GLWE side is at least as hard.  Keyswitch 5 levels x 3 bits as in that set.
-        *out = bmi_params{742, 11, 1, 3, 15, 5, 3, 49, 7.069849454709433e-6, std::ldexp(1.0, -44)};
+        // 2^-44 >= that set's 2.94e-16, so the GLWE side is at least as hard.  Decompositions are this build's: bootstrap 2 x 15
+        // bits (output noise 2^-19.5: the circuits' linear combinations amplify it up to 75x), keyswitch 8 x 2 bits (its noise,
+        // set by the LWE noise that security dictates, is what bounds the look-up margin: finer digits = less of it).
+        *out = bmi_params{742, 11, 1, 2, 15, 8, 2, 49, 7.069849454709433e-6, std::ldexp(1.0, -44)};
         return 0;
     }
     return -1;
@@ -905,6 +907,7 @@ int keyswitch_mfma(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64_t *d
 int bmi_keyswitch_batch(bmi_ctx *c, const uint64_t *d_in, uint32_t count, uint64_t *d_small, void *stream) {
     if (!c || (count && (!d_in || !d_small))) return -1;
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
+    if (count == 0) return 0;
     HIP_OK(c, hipSetDevice(c->device));
     if (c->ks_variant == 0 && c->ks_mfma_ok && count >= BMI_KS_MFMA_MIN) return keyswitch_mfma(c, d_in, count, d_small, (hipStream_t)stream);
     if (c->P.n + 1 > 3 * 256)   // ks_lincomb.hpp: KS_COLS x KS_THREADS output columns per workgroup

@@ -46,8 +46,8 @@ typedef struct {
     uint32_t n;           /* small LWE dimension (630; up to 1024) */
     uint32_t log_N;       /* log2 polynomial size (10) */
     uint32_t k;           /* GLWE dimension (1) */
-    uint32_t bs_levels;   /* l: bootstrap decomposition levels (3) */
-    uint32_t bs_base_log; /* bootstrap decomposition base log (15) */
+    uint32_t bs_levels;   /* l: bootstrap decomposition levels (3; (2, 15) and (1, 23) on the 49-bit field at N <= 2048, */
+    uint32_t bs_base_log; /* bootstrap decomposition base log (15)                          (2, 15) on the 2^64 torus) */
     uint32_t ks_levels;   /* keyswitch levels (8) */
     uint32_t ks_base_log; /* keyswitch base log (4) */
     uint32_t q_bits;      /* ciphertext modulus: 64 -> q = 2^64 - 2^32 + 1 (Goldilocks, integer kernels);
@@ -66,13 +66,14 @@ int bmi_default_params_for(uint32_t q_bits, bmi_params *out);
 /* Named parameter sets:
  *   "north_star"            BASELINE.json's shape (n 630, N 1024, k 1, l 3) on the 49-bit field - bmi_default_params
  *   "north_star_torus64"    the same on the 2^64 torus;  "north_star_goldilocks": on 2^64 - 2^32 + 1
- *   "secure128"             n 742, N 2048, k 1, l 3 x 15 bits, keyswitch 5 x 3 bits, 49-bit field, LWE noise 7.07e-6
+ *   "secure128"             n 742, N 2048, k 1, l 2 x 15 bits, keyswitch 8 x 2 bits, 49-bit field, LWE noise 7.07e-6
  *                           (2^-17.1), GLWE noise 2^-44.  Security: the (dimension, noise / q) pairs are those of TFHE-rs'
  *                           published 128-bit set PARAM_MESSAGE_2_CARRY_2_KS_PBS (lwe_dimension 742, lwe std 7.07e-6;
  *                           glwe k N = 2048 with std 2.94e-16: here the GLWE noise is LARGER, 5.7e-14, hence at least as
  *                           hard), binary keys as there; the hardness of LWE depends on (n, sigma / q), not on q itself.
- *                           4-bit look-ups sit at ~14 sigma of keyswitch + mod-switch noise (measured,
- *                           tests/test_gpu_parity.py; that set's own target is a failure probability of 2^-40).  What compiler.compile's parameter
+ *                           The decompositions are this build's (security does not depend on them).  4-bit look-ups
+ *                           sit at ~8.7 sigma of keyswitch + mod-switch noise (measured, tests/test_gpu_parity.py: a
+ *                           failure probability of ~2^-58 each; that set's own target is 2^-40).  What compiler.compile's parameter
  *                           optimiser guarantees for the reference (main.py:66) - here a fixed, documented set.
  * The north-star sets keep n = 630 as BASELINE.json prescribes; their noise is sized for correctness, NOT for 128-bit
  * security. */

@@ -325,7 +325,7 @@ def test_secure128_preset_bit_exact_noise_and_margin():
     from bmi_amd import tfhe
     from oracle import tfhe_oracle as to
     P = tfhe.preset_params("secure128")
-    assert (P.n, P.N, P.k, P.bs_levels, P.q_bits, P.ks_levels, P.ks_base_log) == (742, 2048, 1, 3, 49, 5, 3) and abs(np.log2(P.lwe_noise) + 17.11) < 0.01
+    assert (P.n, P.N, P.k, P.bs_levels, P.bs_base_log, P.q_bits, P.ks_levels, P.ks_base_log) == (742, 2048, 1, 2, 15, 49, 8, 2) and abs(np.log2(P.lwe_noise) + 17.11) < 0.01
     e = tfhe.Engine(P)
     try:
         e.keygen(SEED + 5)
@@ -357,10 +357,23 @@ def test_secure128_preset_bit_exact_noise_and_margin():
         ratio = float(np.var(err)) / analytic
         # what reaches the blind rotation, in units of the 2N positions of the circle: keyswitch noise + mod-switch rounding
         sigma_pos = np.sqrt(np.var(err) * (2 * P.N) ** 2 + (P.n / 2.0 + 1) / 12.0)
-        margin = (2 * P.N / 32.0) / sigma_pos                                # half a 4-bit box in sigmas
+        margin = (P.N / 32.0) / sigma_pos       # half a 4-bit box (boxes are N / 2^4 positions wide) in sigmas
         print(f"secure128: keyswitch log2 std {0.5 * np.log2(np.var(err)):.2f} (analytic {0.5 * np.log2(analytic):.2f}, ratio "
               f"{ratio:.3f}); positions sigma {sigma_pos:.2f} of {2 * P.N}; 4-bit look-up margin {margin:.1f} sigma")
-        assert 0.75 < ratio < 1.3 and margin > 12.0
+        assert 0.75 < ratio < 1.3 and margin > 8.0
+        # bootstrap output noise at (l, Bg) = (2, 2^15): at the CGGI value, far below the keyswitch noise it feeds
+        want_m = table[msgs + 8]
+        oerr = np.array([((int(x) - (int(m) << dl)) + Q // 2) % Q - Q // 2 for x, m in zip(e.phase(out), want_m)], dtype=np.float64) / Q
+        oratio = float(np.var(oerr)) / cggi_output_variance(P, 49)
+        print(f"secure128: PBS output log2 std {0.5 * np.log2(np.var(oerr)):.2f} (CGGI ratio {oratio:.3f})")
+        assert 0.7 < oratio < 1.4 and np.var(oerr) * 75 ** 2 < np.var(err) / 4     # x75: the widest linear combination of the circuits
+        # latency of one bootstrap and of a full round (256 ciphertexts: one workgroup per CU)
+        import time
+        ids256 = np.full(256, lid, np.uint32)
+        e.pbs_host(ct[:256], ids256)
+        t0 = time.perf_counter(); e.pbs_host(ct[:256], ids256); t256 = time.perf_counter() - t0
+        t0 = time.perf_counter(); e.pbs_host(ct[:1], ids256[:1]); t1 = time.perf_counter() - t0
+        print(f"secure128: 1 PBS {t1 * 1e3:.2f} ms, 256 PBS {t256 * 1e3:.2f} ms (host-buffer calls, copies included)")
         ctx.close()
     finally:
         e.close()

@@ -13,7 +13,7 @@ def main():
     batches = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,64,4096").split(",")]
     variants = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1").split(",")]
     qb = int(sys.argv[3]) if len(sys.argv) > 3 else None
-    kw = {k[4:].lower(): int(v) for k, v in os.environ.items() if k.startswith("BMIP_")}   # e.g. BMIP_BS_LEVELS=2
+    kw = {k[5:].lower(): int(v) for k, v in os.environ.items() if k.startswith("BMIP_")}   # e.g. BMIP_BS_LEVELS=2
     eng = tfhe.Engine(tfhe.default_params(q_bits=qb, **kw)); eng.keygen(0x5EED)
     DL = eng.delta_log()
     sk_small, sk_big, bsk, ksk = eng.export_keys()
