@@ -442,8 +442,8 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
         if (hipMemcpy(c->d_tw, src, tw.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(twiddles) failed");
     }
-    if (c->f64()) {
-        const std::vector<double> th = to_centred_doubles(build_twiddles_half(c->f, nttf::PSI_U, nttf::PSI_INV_U));
+    if (c->f64() || c->t64()) {
+        const std::vector<double> th = to_centred_doubles(build_twiddles_half(Fq{f49::Q, 49}, nttf::PSI_U, nttf::PSI_INV_U));
         if (hipMalloc(&c->d_tw_half, th.size() * 8) != hipSuccess) return bail("hipMalloc(half-transform twiddles) failed");
         if (hipMemcpy(c->d_tw_half, th.data(), th.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(half-transform twiddles) failed");
@@ -645,6 +645,14 @@ int upload_eval_keys(bmi_ctx *c) {
         rc = bmit::launch_bsk_to_limbs(d_tmp, (double *)c->d_bsk, (const double *)c->d_tw, (uint32_t)(bsk_words / N),
                                        bmit::BSK_LIMBS, c->stream);
         if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_limbs launch failed"); }
+        // second copy for the latency kernel, per limb in the slot order of the two-wave half transform
+        if (c->d_bsk_lat) { (void)hipFree(c->d_bsk_lat); c->d_bsk_lat = nullptr; }
+        if (hipMalloc(&c->d_bsk_lat, bsk_words * 8 * bmit::BSK_LIMBS) != hipSuccess) {
+            (void)hipFree(d_tmp);
+            return fail(c, -2, "hipMalloc(torus latency-kernel key) failed");
+        }
+        rc = bmit::launch_bsk_to_lat(d_tmp, c->d_bsk_lat, c->d_tw_half, (uint32_t)(bsk_words / N), bmit::BSK_LIMBS, c->stream);
+        if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat (torus) launch failed"); }
     } else if (c->wide() || c->quad()) {  // N = 2048 / 4096: one key copy, in the slot order of k_blind_rotate_wide49 / quad49
         if (!c->d_bsk_lat && hipMalloc(&c->d_bsk_lat, bsk_words * 8) != hipSuccess) {
             (void)hipFree(d_tmp);
@@ -945,7 +953,13 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     // with wave-pair work, the throughput kernel beyond that (49-bit field: the exchange-once form).
     const bool latency = c->variant == 2 || (c->variant == 0 && count <= c->lat_threshold);
     int rc;
-    if (c->t64()) {   // 2^64 torus: one kernel for every batch size
+    if (c->t64()) {   // 2^64 torus: latency kernel (one workgroup per ciphertext) for small batches, wave pairs beyond
+        const bool lat_t = c->variant == 2 || c->variant == 4 || (c->variant == 0 && count <= c->lat_threshold);
+        if (lat_t) {
+            rc = bmit::launch_blind_rotate_lat(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_lat, c->d_tw_half, d_out,
+                                               count, c->P.n, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
+            return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+        }
         rc = bmit::launch_blind_rotate(d_small, d_lut_ids, (const u64 *)c->d_luts, (const double *)c->d_bsk,
                                        (const double *)c->d_tw, d_out, count, c->P.n, bmit::BSK_LIMBS, c->P.bs_levels, c->P.bs_base_log,
                                        (hipStream_t)stream);

@@ -151,6 +151,12 @@ int launch_bsk_to_limbs(const u64 *std_polys, double *limb_polys, const double *
 int launch_blind_rotate(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_limbs,
                         const double *g_tw, u64 *out, uint32_t count, uint32_t n, int limbs, uint32_t levels,
                         uint32_t base_log, hipStream_t s);   // (levels, base log) = (3, 15) or (2, 15)
+// latency form (one workgroup of 16 wavefronts per ciphertext): own key copy, per limb in the slot order of the two-wave
+// half transform ([poly][limb][A_lo 512, A_hi 512]); tables of ntt_half_f64.hpp
+int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, int limbs, hipStream_t s);
+int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_lat,
+                            const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, uint32_t levels, uint32_t base_log,
+                            hipStream_t s);
 int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
                      uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,
                      hipStream_t s);

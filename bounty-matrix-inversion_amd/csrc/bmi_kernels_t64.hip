@@ -22,6 +22,7 @@
 #include "bmi_internal.hpp"
 #include "ks_lincomb.hpp"
 #include "ks_mfma.hpp"
+#include "ntt_half_f64.hpp"
 #include "ntt_wave_f64.hpp"
 
 using f49::i64;
@@ -274,6 +275,208 @@ __global__ void __launch_bounds__(128 * T64_CTS)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// LATENCY form for the torus: one workgroup of 16 wavefronts per ciphertext, every transform split over two wavefronts
+// by parity (ntt_half_f64.hpp) - the structure of k_blind_rotate_lat2_49 with the limb dimension added:
+//   A  wavefronts 0 .. 4L-1 = (input polynomial c, level, parity): rotate / decompose 512 coefficients of the u64
+//      accumulator (integer rule of the oracle), forward half transform -> tile
+//   B  all 1,024 threads = (output polynomial o, slot p): A_lo = E + O', A_hi = E - O' of the 2L digit transforms once,
+//      then per limb the multiply-accumulate against the key (own copy in slot order, k_bsk_to_lat_t64) and the sums /
+//      differences for the inverse halves; the next limb's key words are requested while this one is multiplied
+//   C  wavefronts 0 .. 11 = (limb, o, parity): inverse half transform, conversion of the exact integers to words,
+//      shift by 22 j and ONE LDS atomic add per coefficient into the accumulator (three limbs meet in a slot)
+constexpr int LT_THREADS = 1024;
+constexpr int LT_LIMBS = 3;
+constexpr int LT_LDS_WORDS = ntth::HT_WORDS + 2 * N + 12 * ntth::HSCRATCH + LT_LIMBS * 2 * N + BMI_AT_WORDS;
+static_assert(LT_LDS_WORDS <= BMI_LDS_WORDS_MAX, "LT_LDS_WORDS exceeds the 160 KB of LDS");
+
+// standard-domain GGSW polynomials -> per limb, the slot-order pair (A_lo, A_hi) of the two-wave half transform:
+// out[((poly * limbs) + j) * N + p] = E + O', out[... + 512 + p] = E - O'
+__global__ void __launch_bounds__(256) k_bsk_to_lat_t64(const u64 *__restrict__ std_polys, double *__restrict__ lat_polys,
+                                                        const double *__restrict__ g_tw_h, uint32_t n_polys, int limbs) {
+    __shared__ double lds[ntth::HT_WORDS + 4 * ntth::HSCRATCH];
+    for (int i = threadIdx.x; i < ntth::HT_WORDS; i += blockDim.x) lds[i] = g_tw_h[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = wave & 1;
+    const uint32_t item = blockIdx.x * 2 + (wave >> 1);   // (polynomial, limb): two per workgroup, two wavefronts each
+    const bool ok = item < n_polys * (uint32_t)limbs;
+    const uint32_t poly = ok ? item / limbs : 0;
+    const int j = ok ? (int)(item % limbs) : 0;
+    double *tile = lds + ntth::HT_WORDS + wave * ntth::HSCRATCH;
+    if (ok) {
+        double x[8];
+        static_for<0, 8>([&](auto J) {
+            x[J] = (double)limb_of((i64)std_polys[(size_t)poly * N + 2 * (lane + 64 * J) + h], j, limbs);
+        });
+        if (h) ntth::forward_half<true>(x, lane, lds, tile);
+        else ntth::forward_half<false>(x, lane, lds, tile);
+        wave_sync();
+        static_for<0, 8>([&](auto R) { tile[R * 64 + lane] = x[R]; });
+    }
+    __syncthreads();
+    if (ok) {
+        const double *te = lds + ntth::HT_WORDS + (wave & ~1) * ntth::HSCRATCH, *to = te + ntth::HSCRATCH;
+        double *o = lat_polys + (size_t)item * N;
+        static_for<0, 4>([&](auto Q4) {
+            const int p = (h * 4 + Q4) * 64 + lane;
+            const double e = te[p], od = to[p];
+            o[p] = f49::red(e + od);
+            o[ntth::HALF + p] = f49::red(e - od);
+        });
+    }
+}
+
+template <int L>
+__global__ void __launch_bounds__(LT_THREADS)
+    k_blind_rotate_lat_t64(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids, const u64 *__restrict__ luts,
+                           const double *__restrict__ bsk_lat, const double *__restrict__ g_tw_h, u64 *__restrict__ out,
+                           uint32_t count, uint32_t n) {
+    constexpr int BG = 15, LIMBS = LT_LIMBS;
+    static_assert(2.0 * L * N * (double)(1ull << (BG - 1)) * (double)(1ull << (T64_LIMB_BITS - 1)) < f49::P / 2, "limb sums must stay below p/2");
+    extern __shared__ double lds[];
+    u64 *acc = reinterpret_cast<u64 *>(lds + ntth::HT_WORDS);   // [2 components][2 parities][512] words mod 2^64
+    double *tiles = lds + ntth::HT_WORDS + 2 * N;               // [12][HSCRATCH]
+    double *SD = tiles + 12 * ntth::HSCRATCH;                   // [limb][2 outputs][sum, difference][512]
+    uint16_t *at = reinterpret_cast<uint16_t *>(SD + LIMBS * 2 * N);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < ntth::HT_WORDS; i += LT_THREADS) lds[i] = g_tw_h[i];
+    const uint32_t ct = blockIdx.x;
+    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
+    for (uint32_t i = tid; i <= n; i += LT_THREADS) at[i] = (uint16_t)modswitch_t64(lwe[i]);
+    __syncthreads();
+    {
+        const u64 *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
+        const uint32_t bt = at[n];
+        const uint32_t nn = tid;  // coefficient index
+        const uint32_t e = (nn + bt) & (2 * N - 1);
+        const u64 v = tv[e & (N - 1)];
+        acc[(nn & 1) * ntth::HALF + (nn >> 1)] = 0;
+        acc[N + (nn & 1) * ntth::HALF + (nn >> 1)] = (e & N) ? (u64)0 - v : v;
+    }
+    __syncthreads();
+    const int mo = tid >> 9, mp = tid & 511;  // phase B: output polynomial, slot
+
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t a_t = at[i];
+        if (a_t == 0) continue;  // uniform over the workgroup
+        // key words of this thread's (output, slot): [row 2L][output 2][limb][A_lo, A_hi]
+        const double *bi = bsk_lat + (size_t)i * 4 * L * LIMBS * N;
+        auto key = [&](int r, int j, int hi) { return bi[(((size_t)(r * 2 + mo)) * LIMBS + j) * N + hi * ntth::HALF + mp]; };
+        double b0[2 * L][2];
+#pragma unroll
+        for (int r = 0; r < 2 * L; r++) {
+            b0[r][0] = key(r, 0, 0);
+            b0[r][1] = key(r, 0, 1);
+        }
+        if (wave < 4 * L) {
+            const int c = wave / (2 * L), lev = (wave % (2 * L)) >> 1, h = wave & 1;
+            const int pz = wave >> 1;
+            const u64 *ac = acc + c * N;
+            double x[8];
+            __builtin_amdgcn_s_setprio(3);
+            static_for<0, 8>([&](auto J) {
+                const uint32_t m = lane + 64 * J;
+                const uint32_t e = (2 * m + h + 2 * N - a_t) & (2 * N - 1);
+                const uint32_t n2 = e & (N - 1);
+                u64 v = ac[(n2 & 1) * ntth::HALF + (n2 >> 1)];
+                v = (e & N) ? (u64)0 - v : v;
+                const i64 t = (i64)(v - ac[h * ntth::HALF + m]) >> (64 - L * BG - 1);
+                double r = __builtin_floor(__builtin_fma(word_to_f64(t), 0.5, 0.5));   // round half up to L BG bits
+                double d = r;                                                          // digit `lev`, balanced [-2^14, 2^14)
+#pragma unroll
+                for (int s = L - 1; s > 0; s--) {
+                    const double rn = __builtin_floor(__builtin_fma(r, 1.0 / (double)(1ull << BG), 0.5));
+                    if (s == lev) d = __builtin_fma(-(double)(1ull << BG), rn, r);
+                    r = rn;
+                }
+                x[J] = lev == 0 ? r : d;
+            });
+            double *tile = tiles + (2 * pz + h) * ntth::HSCRATCH;
+            if (h) ntth::forward_half<true>(x, lane, lds, tile);
+            else ntth::forward_half<false>(x, lane, lds, tile);
+            wave_sync();
+            static_for<0, 8>([&](auto R) { tile[R * 64 + lane] = x[R]; });
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();
+        {
+            double alo[2 * L], ahi[2 * L];
+#pragma unroll
+            for (int r = 0; r < 2 * L; r++) {
+                const double e = tiles[(2 * r) * ntth::HSCRATCH + mp], od = tiles[(2 * r + 1) * ntth::HSCRATCH + mp];
+                alo[r] = e + od;
+                ahi[r] = e - od;
+            }
+            double bc[2 * L][2], bn[2 * L][2];
+#pragma unroll
+            for (int r = 0; r < 2 * L; r++) {
+                bc[r][0] = b0[r][0];
+                bc[r][1] = b0[r][1];
+            }
+            static_for<0, LIMBS>([&](auto JL) {
+                constexpr int j = JL;
+                if constexpr (j + 1 < LIMBS) {
+#pragma unroll
+                    for (int r = 0; r < 2 * L; r++) {
+                        bn[r][0] = key(r, j + 1, 0);
+                        bn[r][1] = key(r, j + 1, 1);
+                    }
+                }
+                sched_fence();
+                double ylo = 0.0, yhi = 0.0;  // lazy sums of 2 L products (<= 10.3 p)
+#pragma unroll
+                for (int r = 0; r < 2 * L; r++) {
+                    ylo += f49::mul(alo[r], bc[r][0]);
+                    yhi += f49::mul(ahi[r], bc[r][1]);
+                }
+                ylo = f49::red(ylo);
+                yhi = f49::red(yhi);
+                double *sd = SD + (size_t)j * 2 * N;
+                sd[(mo * 2 + 0) * ntth::HALF + mp] = ylo + yhi;
+                sd[(mo * 2 + 1) * ntth::HALF + mp] = ylo - yhi;
+                if constexpr (j + 1 < LIMBS) {
+#pragma unroll
+                    for (int r = 0; r < 2 * L; r++) {
+                        bc[r][0] = bn[r][0];
+                        bc[r][1] = bn[r][1];
+                    }
+                }
+            });
+        }
+        __syncthreads();
+        if (wave < 4 * LIMBS) {
+            const int j = wave >> 2, o = (wave >> 1) & 1, h = wave & 1;
+            double x[8];
+            const double *sd = SD + (size_t)j * 2 * N + (o * 2 + h) * ntth::HALF;
+            static_for<0, 8>([&](auto R) { x[R] = sd[R * 64 + lane]; });
+            double *tile = tiles + wave * ntth::HSCRATCH;
+            __builtin_amdgcn_s_setprio(2);
+            if (h) ntth::inverse_half<true>(x, lane, lds, tile);
+            else ntth::inverse_half<false>(x, lane, lds, tile);
+            __builtin_amdgcn_s_setprio(0);
+            unsigned long long *ao = reinterpret_cast<unsigned long long *>(acc + o * N + h * ntth::HALF);
+            const int sh = T64_LIMB_BITS * j;
+            static_for<0, 8>([&](auto J) {
+                // the limb's exact integer (|.| < 2^47.6 < p/2), shifted into place; the three limbs of a slot add atomically
+                atomicAdd(ao + lane + 64 * J, (unsigned long long)(f64_to_word(f49::red(x[J])) << sh));
+            });
+        }
+        __syncthreads();
+    }
+    u64 *o = out + (size_t)ct * (N + 1);
+    {
+        const uint32_t nn = tid;
+        const u64 a0 = acc[(nn & 1) * ntth::HALF + (nn >> 1)];
+        if (nn == 0) {
+            o[0] = a0;
+            o[N] = acc[N];
+        } else {
+            o[N - nn] = (u64)0 - a0;
+        }
+    }
+}
+
 // keyswitch / linear combinations: wrap-around arithmetic, the oracle's 64-bit decomposition rule
 struct FieldT {
     static __device__ __forceinline__ void digits(u64 a, uint32_t levels, uint32_t base_log, unsigned char *d) {
@@ -337,6 +540,36 @@ int launch_blind_rotate(const u64 *small_cts, const uint32_t *lut_ids, const u64
     if (limbs != 3 || base_log != 15) return (int)hipErrorInvalidValue;
     if (levels == 3) return launch_t64<3>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
     if (levels == 2) return launch_t64<2>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
+    return (int)hipErrorInvalidValue;
+}
+
+int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, int limbs, hipStream_t s) {
+    if (limbs != LT_LIMBS) return (int)hipErrorInvalidValue;
+    const uint32_t items = n_polys * (uint32_t)limbs;
+    hipLaunchKernelGGL(k_bsk_to_lat_t64, dim3((items + 1) / 2), dim3(256), 0, s, std_polys, lat_polys, g_tw_h, n_polys, limbs);
+    BMIT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int L>
+static int launch_lat_t64(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_lat,
+                          const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+    static std::atomic<uint64_t> configured{0};
+    const size_t lds = (size_t)LT_LDS_WORDS * sizeof(double);
+    auto kern = k_blind_rotate_lat_t64<L>;
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
+    hipLaunchKernelGGL(kern, dim3(count), dim3(LT_THREADS), lds, s, small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n);
+    BMIT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_lat,
+                            const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, uint32_t levels, uint32_t base_log,
+                            hipStream_t s) {
+    if (count == 0) return 0;
+    if (base_log != 15) return (int)hipErrorInvalidValue;
+    if (levels == 3) return launch_lat_t64<3>(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s);
+    if (levels == 2) return launch_lat_t64<2>(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s);
     return (int)hipErrorInvalidValue;
 }
 

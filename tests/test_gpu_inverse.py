@@ -16,7 +16,7 @@ def load(name):
         return json.load(f)
 
 
-@pytest.fixture(scope="module", params=[64, 49], ids=["goldilocks64", "p49_f64"])
+@pytest.fixture(scope="module", params=[64, 49, 65], ids=["goldilocks64", "p49_f64", "torus64"])
 def eng(request):
     from bmi_amd import tfhe
     e = tfhe.Engine(tfhe.default_params(q_bits=request.param))
@@ -96,7 +96,7 @@ def test_encrypted_inverse_modes_match_reference_golden(eng, tag):
     """The reference's other modes on ciphertexts: true_division=True (QFloat / QFloat through the long
     division instead of invert-and-multiply, qfloat.py:1183-1234) and tensorize=True (the multi_* twins)."""
     from bmi_amd.main import EncryptedMatrixInversion
-    if eng.q_bits == 64 and tag != "uniform_2x2_tensorize":
+    if eng.q_bits != 49 and tag != "uniform_2x2_tensorize":
         pytest.skip("the 3x3 mode cases run once, on the faster field")
     c = next(x for x in load("inverse.json") if x["tag"] == tag)
     emi = EncryptedMatrixInversion(c["n"], None, 2, c["len"], c["ints"], c["true_division"], c["tensorize"], engine=eng)
@@ -127,8 +127,8 @@ def test_encrypted_3x3_inverse_matches_reference_golden(eng):
 
 
 def test_encrypted_4x4_inverse_matches_reference_golden(eng):
-    if eng.q_bits == 64:
-        pytest.skip("config 4 is run once, on the faster field (the 64-bit field covers configs 2 and 3)")
+    if eng.q_bits != 49:
+        pytest.skip("config 4 is run once, on the fastest field (the 64-bit moduli cover configs 2 and 3)")
     """BASELINE config 4 (4x4, len 40, ints 16) on ONE MI355X: 323 k PBS, depth 1,858.  (BASELINE shards this
     config's PBS over 8 GPUs; the inverse's levels are narrower than one GPU's latency-kernel capacity, so a
     single GPU is the faster placement - DESIGN.md §6.)"""
@@ -152,8 +152,8 @@ def test_encrypted_4x4_inverse_matches_reference_golden(eng):
                                  "overflow_digit_3x3", "rand3x3_seed100", "rand3x3_seed101", "rand3x3_seed102"])
 def test_encrypted_inverse_of_further_matrices(eng, tag):
     """A second matrix for each of BASELINE configs 2-4 and the remaining 3x3 goldens, on ciphertexts (49-bit field)."""
-    if eng.q_bits == 64:
-        pytest.skip("run once, on the faster field")
+    if eng.q_bits != 49:
+        pytest.skip("run once, on the fastest field")
     from bmi_amd.main import EncryptedMatrixInversion
     c = next(x for x in load("inverse.json") if x["tag"] == tag)
     emi = EncryptedMatrixInversion(c["n"], None, 2, c["len"], c["ints"], False, False, engine=eng)
@@ -168,8 +168,8 @@ def test_encrypted_8x8_inverse_matches_reference_golden(eng):
     """BASELINE config 5 (8x8, len 48, ints 16) on ONE MI355X, every look-up on ciphertexts: 2.58 M PBS over 2,886
     levels; decrypted digits and signs == the reference's plaintext output (tests/golden/inverse.json,
     qfloat_matrix_inversion.py:672-720).  The ciphertext store holds the live set only (recycled rows)."""
-    if eng.q_bits == 64:
-        pytest.skip("config 5 is run once, on the faster field")
+    if eng.q_bits != 49:
+        pytest.skip("config 5 is run once, on the fastest field")
     import time
     from bmi_amd.main import EncryptedMatrixInversion
     c = next(x for x in load("inverse.json") if x["tag"] == "baseline_n8_len48_ints16")
@@ -196,7 +196,7 @@ def test_encrypted_inverse_with_a_non_binary_leading_digit(eng, tag):
     """An entry beyond 2^ints keeps a leading digit of 2 or 3 (from_float does not reduce it, base_p_arrays.py:42-46;
     SURVEY section 8d asks for such a matrix on ciphertexts): digits and signs == the reference's."""
     from bmi_amd.main import EncryptedMatrixInversion
-    if eng.q_bits == 64 and "3x3" in tag:
+    if eng.q_bits != 49 and "3x3" in tag:
         pytest.skip("the 3x3 case runs once, on the faster field")
     c = next(x for x in load("inverse.json") if x["tag"] == tag)
     assert max(row[0] for row in c["in_arrays"]) >= 2
