@@ -13,10 +13,14 @@ def main():
     qb = int(sys.argv[1]) if len(sys.argv) > 1 else 49
     budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
     log_N = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-    eng = tfhe.Engine(tfhe.default_params(q_bits=qb, log_N=log_N)); eng.keygen(77)
+    kw = {k[5:].lower(): int(v) for k, v in os.environ.items() if k.startswith("BMIP_")}   # e.g. BMIP_BS_LEVELS=2
+    eng = tfhe.Engine(tfhe.default_params(q_bits=qb, log_N=log_N, **kw)); eng.keygen(77)
     dl = eng.delta_log()
     _, _, bsk, ksk = eng.export_keys()
-    octx = to.Ctx(to.default_params(q_bits=qb, log_N=log_N), bsk, ksk)
+    to.set_field(qb)
+    octx = to.Ctx(to.default_params(q_bits=qb, log_N=log_N, **kw), bsk, ksk)
+    lb3 = (eng.P.bs_levels, eng.P.bs_base_log) == (3, 15)
+    all_variants = (0, 1, 2, 3, 4) if (lb3 or qb == 65) else (0, 2, 3)     # variants 1 / 4 of the 49-bit field exist for (3, 2^15) only
     rng = np.random.default_rng(2024)
     table = rng.integers(-8, 8, 16)
     lid = eng.lut_register(table, 4, dl)
@@ -31,7 +35,7 @@ def main():
             ct = eng.encrypt(msgs, dl)
             ids = np.full(B, lid, np.uint32)
             ref = None
-            for variant in ((0,) if log_N != 10 else (0, 1, 2, 3, 4) if B <= 600 else (0, 1, 3)):
+            for variant in ((0,) if log_N != 10 else all_variants if B <= 600 else tuple(v for v in all_variants if v in (0, 1, 3))):
                 eng.set_kernel_variant(variant)
                 out = eng.pbs_host(ct, ids)
                 assert np.array_equal(eng.decrypt(out, dl), table[msgs + 8]), (B, variant)
@@ -47,6 +51,6 @@ def main():
             if time.time() - t0 > budget:
                 break
         print(json.dumps({"elapsed_s": round(time.time() - t0, 1), "kernel_runs": runs, "oracle_checked": checked}), flush=True)
-    print("stress ok")
+    print("stress ok", json.dumps({"q_bits": qb, "log_N": log_N, **kw}))
 
 main()
