@@ -276,7 +276,7 @@ def main():
         res["cpu_baseline"] = {"value": sample / cpu_s, "unit": "PBS/s", "cores": threads, "kind": "port",
                                "ms_per_pbs_per_thread": cpu_s / sample * threads * 1e3,
                                "sample": f"first {sample} ciphertexts of the same batch, same keys/LUTs, oracle/tfhe_oracle.c "
-                                         + ("fast path (exact f64 arithmetic mod 2^49-720895, vectorised radix-2 transforms, no "
+                                         + ("fast path (exact f64 arithmetic mod 2^49-720895, vectorised 32 x 32 four-step transforms, no "
                                             "allocation per call; AVX-512/AVX2 clones)" if fast else "generic exact path")
                                          + f", OpenMP over the batch, {cpu_s:.1f} s",
                                "fast_path_matches_generic_path": self_check,

@@ -648,9 +648,55 @@ typedef struct {
     double inv_N;
     double *bsk;              /* [n][rows][k+1][N] transform domain, centred */
     double *ksk_lo, *ksk_hi;  /* [kN*lk][n+1]: word = hi * 2^25 + lo, both exact in f64 */
+    /* N = 1024 as 32 x 32 ("four-step"): every butterfly loop runs over 32 contiguous doubles.  t1: 32-point negacyclic
+     * tree (root psi^32) over the row index, tw: psi^(c (2 br5(rho) + 1)), t2: 32-point cyclic tree (root psi^64) over
+     * the column index after a transpose; *_i the inverses (1/N folded into twi).  NULL for other N (radix-2 path). */
+    double *t1, *t1i, *t2, *t2i, *tw, *twi;
 } ora_fctx;
 
+/* butterflies between ROWS of an R x C matrix (Cooley-Tukey, natural in / tree order out), inner loop over the C columns */
+F_CLONES static void f_rows_fwd(double *A, uint32_t R, uint32_t C, const double *tw) {
+    for (uint32_t m = 1, len = R >> 1; m < R; m <<= 1, len >>= 1)
+        for (uint32_t i = 0; i < m; i++) {
+            const double w = tw[m + i];
+            for (uint32_t j = 0; j < len; j++) {
+                double *x = A + (size_t)(2 * i * len + j) * C, *y = x + (size_t)len * C;
+                for (uint32_t cc = 0; cc < C; cc++) { double u = x[cc], v = f_mul(y[cc], w); x[cc] = u + v; y[cc] = u - v; }
+            }
+        }
+}
+F_CLONES static void f_rows_inv(double *A, uint32_t R, uint32_t C, const double *itw) {
+    for (uint32_t m = R >> 1, len = 1; m >= 1; m >>= 1, len <<= 1)
+        for (uint32_t i = 0; i < m; i++) {
+            const double w = itw[m + i];
+            for (uint32_t j = 0; j < len; j++) {
+                double *x = A + (size_t)(2 * i * len + j) * C, *y = x + (size_t)len * C;
+                for (uint32_t cc = 0; cc < C; cc++) { double u = x[cc], v = y[cc]; x[cc] = f_red(u + v); y[cc] = f_mul(u - v, w); }
+            }
+        }
+}
+F_CLONES static void f_transpose32(const double *a, double *b) {
+    for (uint32_t r = 0; r < 32; r++)
+        for (uint32_t cc = 0; cc < 32; cc++) b[cc * 32 + r] = a[r * 32 + cc];
+}
+/* N = 1024: a[32 r + c] -> transform in (column position, row position) order; |out| <= 8.4 p (lazy), callers reduce */
+F_CLONES static void f_ntt1024_fwd(const ora_fctx *c, double *a, double *tmp) {
+    f_rows_fwd(a, 32, 32, c->t1);
+    for (uint32_t x = 0; x < 1024; x++) a[x] = f_mul(a[x], c->tw[x]);
+    f_transpose32(a, tmp);
+    f_rows_fwd(tmp, 32, 32, c->t2);
+    memcpy(a, tmp, 1024 * 8);
+}
+F_CLONES static void f_ntt1024_inv(const ora_fctx *c, double *a, double *tmp) { /* input |.| <= 0.51 p */
+    f_rows_inv(a, 32, 32, c->t2i);
+    f_transpose32(a, tmp);
+    for (uint32_t x = 0; x < 1024; x++) tmp[x] = f_mul(tmp[x], c->twi[x]);
+    f_rows_inv(tmp, 32, 32, c->t1i);
+    memcpy(a, tmp, 1024 * 8);
+}
+
 F_CLONES static void f_ntt_fwd(const ora_fctx *c, double *a) {
+    if (c->t1) { double tmp[1024]; f_ntt1024_fwd(c, a, tmp); return; }
     uint32_t N = c->N, stage = 0;
     for (uint32_t m = 1, len = N >> 1; m < N; m <<= 1, len >>= 1, stage++) {
         for (uint32_t i = 0; i < m; i++) {
@@ -662,6 +708,7 @@ F_CLONES static void f_ntt_fwd(const ora_fctx *c, double *a) {
     }
 }
 F_CLONES static void f_ntt_inv(const ora_fctx *c, double *a) { /* input |.| <= 0.51 p */
+    if (c->t1) { double tmp[1024]; f_ntt1024_inv(c, a, tmp); return; }
     uint32_t N = c->N;
     for (uint32_t m = N >> 1, len = 1; m >= 1; m >>= 1, len <<= 1)
         for (uint32_t i = 0; i < m; i++) {
@@ -682,6 +729,33 @@ ora_fctx *ora_fctx_create(const ora_params *P, const u64 *bsk, const u64 *ksk) {
     c->psi_br = (double *)malloc(N * 8); c->ipsi_br = (double *)malloc(N * 8);
     for (uint32_t i = 0; i < N; i++) { c->psi_br[i] = f_center(t->psi_br[i]); c->ipsi_br[i] = f_center(t->ipsi_br[i]); }
     c->inv_N = f_center(t->inv_N);
+    if (P->log_N == 10) {
+        /* Cooley-Tukey tree over x^R - g^e: node idx (heap order) splits x^(2 len) - g^e into x^len -+ g^(e/2); its
+         * twiddle is g^(e/2), its children carry e/2 and e/2 + ord/2.  Negacyclic 32 with g = psi^32 (order 64): e_root =
+         * 32; cyclic 32 with g = psi^64 (order 32): e_root = 0. */
+        const u64 psi = powq(GEN, (Q - 1) / 2048), ipsi = powq(psi, Q - 2);
+        double **fw[2] = {&c->t1, &c->t2}, **iw[2] = {&c->t1i, &c->t2i};
+        const u64 g[2] = {powq(psi, 32), powq(psi, 64)}, ord[2] = {64, 32}, root_e[2] = {32, 0};
+        uint32_t leaf_e[32];
+        for (int t = 0; t < 2; t++) {
+            *fw[t] = (double *)calloc(32, 8); *iw[t] = (double *)calloc(32, 8);
+            uint32_t e[64]; e[1] = (uint32_t)root_e[t];
+            for (uint32_t idx = 1; idx < 32; idx++) {
+                uint32_t h = (e[idx] / 2) % ord[t];
+                (*fw[t])[idx] = f_center(powq(g[t], h));
+                (*iw[t])[idx] = f_center(powq(powq(g[t], h), Q - 2));
+                e[2 * idx] = h; e[2 * idx + 1] = (uint32_t)((h + ord[t] / 2) % ord[t]);
+            }
+            if (t == 0) for (uint32_t r = 0; r < 32; r++) leaf_e[r] = e[32 + r];   /* row position rho evaluates at (psi^32)^leaf_e */
+        }
+        c->tw = (double *)malloc(1024 * 8); c->twi = (double *)malloc(1024 * 8);
+        for (uint32_t r = 0; r < 32; r++)
+            for (uint32_t cc = 0; cc < 32; cc++) {
+                u64 w = powq(psi, (u64)cc * leaf_e[r] % 2048);
+                c->tw[r * 32 + cc] = f_center(w);
+                c->twi[r * 32 + cc] = f_center(mulq(powq(ipsi, (u64)cc * leaf_e[r] % 2048), t->inv_N));
+            }
+    }
     size_t polys = (size_t)n * (k + 1) * P->bs_levels * (k + 1);
     c->bsk = (double *)malloc(polys * N * 8);
 #pragma omp parallel for schedule(static)
@@ -697,7 +771,7 @@ ora_fctx *ora_fctx_create(const ora_params *P, const u64 *bsk, const u64 *ksk) {
     ntt_free(t);
     return c;
 }
-void ora_fctx_destroy(ora_fctx *c) { if (!c) return; free(c->psi_br); free(c->ipsi_br); free(c->bsk); free(c->ksk_lo); free(c->ksk_hi); free(c); }
+void ora_fctx_destroy(ora_fctx *c) { if (!c) return; free(c->t1); free(c->t1i); free(c->t2); free(c->t2i); free(c->tw); free(c->twi); free(c->psi_br); free(c->ipsi_br); free(c->bsk); free(c->ksk_lo); free(c->ksk_hi); free(c); }
 
 /* per-thread scratch of the fast path */
 typedef struct { double *acc, *dec, *res, *ks_lo, *ks_hi; u64 *small; } f_scratch;
