@@ -152,6 +152,37 @@ def _NE0(v):
     return int(v != 0)
 
 
+_SCALARS = (int, bool, str, float, tuple, frozenset, type(None))
+
+
+def _fn_key(fn, depth=0):
+    """Hashable identity of a look-up function by VALUE: code object + closure cells + defaults (plain scalars or nested
+    functions of the same kind); None when anything else is captured.  Two lambdas created by the same line with the same
+    captured numbers are the same function of v, so their tables can be shared without calling them 16 times each."""
+    code = getattr(fn, "__code__", None)
+    if code is None or depth > 3:
+        return None
+    cells = []
+    for cell in fn.__closure__ or ():
+        try:
+            v = cell.cell_contents
+        except ValueError:
+            return None
+        if isinstance(v, _SCALARS):
+            cells.append(v)
+        elif callable(v):
+            k = _fn_key(v, depth + 1)
+            if k is None:
+                return None
+            cells.append(k)
+        else:
+            return None
+    for v in fn.__defaults__ or ():
+        if not isinstance(v, _SCALARS):
+            return None
+    return (code, tuple(cells), fn.__defaults__)
+
+
 class Circuit:
     def __init__(self, msg_bits=MSG_BITS):
         """msg_bits: message bits of every ciphertext of this circuit (look-ups take 2^msg_bits values, lut_odd twice
@@ -170,6 +201,7 @@ class Circuit:
         self.outputs = []        # snapshots of output Lins
         self.stats = {"pbs": 0, "cse_hits": 0, "const_folds": 0}
         self.wide_leaves = set()  # outputs of lut_odd(): their PBS input may use the whole torus
+        self._table_memo = {}     # (function key, lo, hi) -> evaluated table data of lut()
 
     # ---- construction ----------------------------------------------------------------------------
     def input(self, lo, hi):
@@ -201,20 +233,28 @@ class Circuit:
         width = x.hi - x.lo + 1
         if width > (1 << self.msg_bits):
             raise RangeError(f"look-up input interval [{x.lo}, {x.hi}] wider than {1 << self.msg_bits} values")
-        vals = [int(fn(v)) for v in range(x.lo, x.hi + 1)]
-        olo, ohi = min(vals), max(vals)
+        fk = _fn_key(fn)
+        memo = self._table_memo.get((fk, x.lo, x.hi)) if fk is not None else None
+        if memo is None:
+            vals = [int(fn(v)) for v in range(x.lo, x.hi + 1)]
+            olo, ohi = min(vals), max(vals)
+            p = 1
+            while (1 << p) < width:
+                p += 1
+            half = 1 << (p - 1)
+            # table over m = x - off in [-half, half); entries outside the reachable interval repeat the nearest reachable value
+            table = tuple(vals[min(max(m + half, 0), width - 1)] for m in range(-half, half))
+            memo = (olo, ohi, p, table)
+            if fk is not None:
+                self._table_memo[(fk, x.lo, x.hi)] = memo
+        olo, ohi, p, table = memo
         if olo == ohi:
             self.stats["const_folds"] += 1
             return self.const(olo)
         if not (-(1 << self.msg_bits) <= olo and ohi < (1 << self.msg_bits)):
             raise RangeError(f"look-up output interval [{olo}, {ohi}] does not fit the message space")
-        p = 1
-        while (1 << p) < width:
-            p += 1
         half = 1 << (p - 1)
-        off = x.lo + half  # message m = x - off in [-half, half)
-        # table over m; entries outside the reachable interval repeat the nearest reachable value
-        table = tuple(vals[min(max(m + half, 0), width - 1)] for m in range(-half, half))
+        off = x.lo + half
         key = (p, table)
         li = self._lut_index.get(key)
         if li is None:
