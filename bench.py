@@ -209,7 +209,7 @@ def main():
                            + (1 + Pp.k * Pp.N / 2.0) / (12.0 * Bg ** (2 * Pp.bs_levels)))
         return {"samples": int(err.size), "log2_std_measured": float(0.5 * np.log2(np.var(err))),
                 "log2_std_cggi_formula": float(0.5 * np.log2(analytic)), "variance_ratio": float(np.var(err) / analytic),
-                "log2_max_abs": float(np.log2(np.abs(err).max())), "log2_half_box": -5.0}
+                "log2_max_abs": float(np.log2(np.abs(err).max())), "log2_half_box": -6.0}
 
     total_pbs = B * world * args.steps
     value = total_pbs / elapsed

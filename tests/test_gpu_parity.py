@@ -315,7 +315,7 @@ def test_pbs_output_noise_matches_the_cggi_formula(eng):
           f"variance ratio {ratio:.3f}, max |err| 2^{np.log2(np.abs(err).max()):.2f}")
     assert 0.85 < ratio < 1.15, ratio                     # 4,096 samples: the variance estimate itself is +-2.2 % (1 sigma)
     assert abs(err.mean()) < 4 * np.sqrt(measured / B)
-    assert np.abs(err).max() < 2.0 ** -9                  # half a box is 2^-5
+    assert np.abs(err).max() < 2.0 ** -9                  # half a box is 2^-6
 
 
 def test_secure128_preset_bit_exact_noise_and_margin():
