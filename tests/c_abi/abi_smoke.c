@@ -52,8 +52,43 @@ int main(void) {
     CHECK(bmi_pbs_batch_host(ctx, ct, ids, 0, out) == 0, "empty batch is a no-op");
     uint64_t bsk_b = 0, ksk_b = 0;
     CHECK(bmi_key_bytes(ctx, &bsk_b, &ksk_b) == 0 && bsk_b == 61931520ull, "bootstrap key bytes = 61,931,520");
+    /* fresh CSPRNG randomness: two encryptions of the same messages differ, both decrypt */
+    uint64_t *ct2 = (uint64_t *)malloc(5 * big * 8);
+    CHECK(bmi_encrypt(ctx, msgs, 5, DL, ct2) == 0 && memcmp(ct, ct2, 5 * big * 8) != 0, "encryptions are randomised");
+    CHECK(bmi_decrypt(ctx, ct2, 5, DL, dec) == 0 && dec[0] == -8 && dec[4] == 7, "second encryption decrypts");
+    /* the test-only seeded key generation is reproducible (keys and ciphertexts) */
+    CHECK(bmi_keygen_insecure_deterministic(ctx, 42) == 0 && bmi_encrypt(ctx, msgs, 5, DL, ct) == 0, "seeded keygen");
+    CHECK(bmi_keygen_insecure_deterministic(ctx, 42) == 0 && bmi_encrypt(ctx, msgs, 5, DL, ct2) == 0, "seeded keygen again");
+    CHECK(memcmp(ct, ct2, 5 * big * 8) == 0, "seeded path is deterministic");
     bmi_ctx_destroy(ctx);
+
+    /* named presets; the 2^64 torus (Concrete's modulus) end to end; the compiler passes (context-free, CPU) */
+    bmi_params S;
+    CHECK(bmi_preset_params("secure128", &S) == 0 && S.n == 742 && S.log_N == 11, "secure128 preset");
+    CHECK(bmi_preset_params("no such set", &S) < 0, "unknown preset rejected");
+    CHECK(bmi_preset_params("north_star_torus64", &S) == 0 && S.q_bits == BMI_Q_TORUS64, "torus preset");
+    CHECK(bmi_ctx_create(&S, 0, &ctx) == 0, "torus context");
+    CHECK(bmi_keygen(ctx) == 0, "torus keygen");
+    CHECK(bmi_lut_register(ctx, table, 4, 59, &lut) == 0, "torus lut");
+    for (int i = 0; i < 5; i++) ids[i] = lut;
+    CHECK(bmi_encrypt(ctx, msgs, 5, 59, ct) == 0 && bmi_pbs_batch_host(ctx, ct, ids, 5, out) == 0, "torus pbs");
+    CHECK(bmi_decrypt(ctx, out, 5, 59, dec) == 0, "torus decrypt");
+    for (int i = 0; i < 5; i++) CHECK(dec[i] == table[msgs[i] + 8], "torus LUT value");
+    bmi_ctx_destroy(ctx);
+    {
+        /* x0, x1 inputs; node 0 reads x0; node 1 reads node 0 and x1; node 2 reads x1 and feeds nothing; output = node 1 */
+        const int64_t ptr[4] = {0, 1, 3, 4};
+        const int32_t leaf[4] = {0, 2, 1, 1}, outl[1] = {3};
+        uint8_t live[3];
+        int32_t level[3], depth = 0;
+        CHECK(bmi_circuit_prune(2, 3, ptr, leaf, outl, 1, live) == 0 && live[0] && live[1] && !live[2], "prune");
+        CHECK(bmi_circuit_schedule(2, 3, ptr, leaf, 256, 1024, level, &depth) == 0 && depth == 2 && level[0] == 1 && level[1] == 2,
+              "schedule");
+        const int32_t bad_leaf[4] = {0, 4, 1, 1};   /* node 1 reading its own output: refused */
+        CHECK(bmi_circuit_schedule(2, 3, ptr, bad_leaf, 256, 1024, level, &depth) < 0, "malformed circuit rejected");
+    }
     free(ct);
+    free(ct2);
     free(out);
     printf("abi_smoke OK\n");
     return 0;

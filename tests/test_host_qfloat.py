@@ -685,3 +685,25 @@ def test_digit_array_primitives_take_the_reference_signatures():
     S = [[[0] * 4 for _ in range(2)] for _ in range(2)]
     bpa.insert_array_at_index_3D([[7, 8], [9, 1]], S, 1, 3)
     assert S[0][1] == [0, 0, 0, 7] and S[1][1] == [0, 0, 0, 9] and S[0][0] == [0] * 4
+
+
+def test_run_validates_the_plaintext_against_the_traced_ranges_before_encrypting(monkeypatch):
+    """EncryptedMatrixInversion.run(validate=True) evaluates the compiled program in plaintext, every interval claim
+    checked, BEFORE any encryption: a violated claim or an entry beyond the traced leading-digit range is refused while
+    no engine exists yet.  (A singular matrix is not such a case: like the reference it yields the all-ones quotient.)"""
+    emi = EncryptedMatrixInversion(2, None, 2, 16, 7)
+    with pytest.raises(ValueError):
+        emi.run(np.array([[5000.0, 1.0], [2.0, 3.0]]))
+    assert emi.engine is None
+    calls = []
+    real = emi.program.simulate
+    monkeypatch.setattr(emi.program, "simulate", lambda flat, check=True: (calls.append(check), real(flat, check))[1])
+
+    def no_gpu(*a, **k):
+        raise RuntimeError("encrypt reached")
+    monkeypatch.setattr(emi, "encrypt", no_gpu)
+    with pytest.raises(RuntimeError, match="encrypt reached"):
+        emi.run(np.array([[10.0, -3.5], [4.25, 20.0]]))
+    assert calls == [True]                                   # validated with the claim checks on, then went on to encrypt
+    singular = emi.run(np.array([[2.0, 4.0], [1.0, 2.0]]), simulate=True)
+    assert np.isfinite(singular).all()
