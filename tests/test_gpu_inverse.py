@@ -209,6 +209,28 @@ def test_encrypted_inverse_with_a_non_binary_leading_digit(eng, tag):
     assert emi.dequantize(out).flatten().tolist() == c["float"]
 
 
+def test_random_matrices_under_csprng_keys_match_the_plaintext_circuit(eng):
+    """Twelve random 2x2 matrices, fresh CSPRNG keys: decrypted digits == the plaintext evaluation of the same program.
+    (tools/gpu_random_inverses.py is the long form: 572 matrices / 11.6 M look-ups, profiles/r02_random_inverses.txt.)"""
+    from bmi_amd import tfhe
+    from bmi_amd.main import EncryptedMatrixInversion
+    e = tfhe.Engine(tfhe.default_params(q_bits=eng.q_bits))
+    try:
+        e.keygen()
+        emi = EncryptedMatrixInversion(2, None, 2, 20, 8, False, False, engine=e)
+        rng = np.random.default_rng(99)
+        done = 0
+        while done < 12:
+            M = rng.normal(0, 100, (2, 2))
+            q, s = emi.quantize(M)
+            if q[:, 0].max() > 3:
+                continue
+            assert np.array_equal(emi.decrypt(emi.evaluate(emi.encrypt(q, s))), emi.simulate(q, s)), M
+            done += 1
+    finally:
+        e.close()
+
+
 def test_executor_row_recycling_gives_the_same_ciphertexts(eng):
     """recycled store rows vs one row per look-up: identical output ciphertexts (same keys, same inputs)."""
     from bmi_amd.executor import Executor

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Many random matrices through the encrypted inverse on the GPU, each compared with the plaintext evaluation of the same
+compiled program (identical integers expected) and with numpy's inverse: an empirical look at the look-up failure rate
+(every 4-bit look-up sits at >= 5.6 sigma).  usage: gpu_random_inverses.py [n] [count] [q_bits]"""
+import json, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "bounty-matrix-inversion_amd"))
+import numpy as np
+from bmi_amd import tfhe
+from bmi_amd.main import EncryptedMatrixInversion
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    qb = int(sys.argv[3]) if len(sys.argv) > 3 else 49
+    ln, ints = {2: (20, 8), 3: (30, 12), 4: (40, 16)}[n]
+    eng = tfhe.Engine(tfhe.default_params(q_bits=qb)); eng.keygen()          # CSPRNG keys
+    emi = EncryptedMatrixInversion(n, None, 2, ln, ints, False, False, engine=eng)
+    rng = np.random.default_rng(4242 + n)
+    wrong = skipped = 0; pbs = emi.program.n_nodes; worst = 0.0; t0 = time.time()
+    for i in range(count):
+        M = rng.normal(0, 100, (n, n))
+        q, s = emi.quantize(M)
+        if q[:, 0].max() > 3:            # entry beyond the traced leading-digit range (|x| >= 2^(ints+2)): not an input of this circuit
+            skipped += 1; continue
+        want = emi.simulate(q, s)
+        got = emi.decrypt(emi.evaluate(emi.encrypt(q, s)))
+        if not np.array_equal(got, want):
+            wrong += 1
+        else:
+            err = np.max(np.abs(emi.dequantize(got) - np.linalg.inv(M)))
+            if np.isfinite(err): worst = max(worst, float(err))
+    done = count - skipped
+    print(json.dumps({"n": n, "q_bits": qb, "matrices": done, "mismatching_the_plaintext_circuit": wrong, "lookups_total": done * pbs,
+                      "lookups_per_inverse": pbs, "worst_abs_err_vs_numpy_among_matching": worst, "seconds": round(time.time() - t0, 1),
+                      "keys": "CSPRNG"}))
+    eng.close()
+    return 1 if wrong else 0
+
+sys.exit(main())
