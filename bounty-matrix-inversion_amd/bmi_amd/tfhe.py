@@ -250,6 +250,34 @@ class Engine:
         else:
             self._ck(self.lib.bmi_keygen_insecure_deterministic(self.h, C.c_uint64(seed)), "bmi_keygen_insecure_deterministic")
 
+    def keygen_shared(self, seed=None, group=None, src=0):
+        """One key set on every rank of a torch.distributed group WITHOUT the seeded (test-only) generator: rank `src`
+        generates it (CSPRNG when seed is None) and broadcasts secret and evaluation keys (about 100 MB at the north-star
+        set); the other ranks import them.  With a single process this is keygen(seed).  The sharded executor needs the
+        same evaluation keys on every GPU (executor.py); only the rank that encrypts / decrypts needs the secret ones."""
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return self.keygen(seed)
+        rank = dist.get_rank(group)
+        if rank == src:
+            self.keygen(seed)
+            parts = list(self.export_keys())
+        else:
+            P, rows = self.P, (self.P.k + 1) * self.P.bs_levels
+            parts = [np.zeros(P.n, np.uint64), np.zeros(P.k * P.N, np.uint64), np.zeros((P.n, rows, P.k + 1, P.N), np.uint64),
+                     np.zeros((P.k * P.N, P.ks_levels, P.n + 1), np.uint64)]
+        on_gpu = dist.get_backend(group) == "nccl"
+        for a in parts:
+            t = torch.from_numpy(a.view(np.int64))
+            if on_gpu:
+                t = t.to(torch.device("cuda", self.device))
+            dist.broadcast(t, src=src, group=group)
+            if on_gpu:
+                a.view(np.int64)[...] = t.cpu().numpy()
+        if rank != src:
+            self.import_keys(*parts)
+
     def export_keys(self, secret=True):
         """(sk_small, sk_big, bsk, ksk), standard domain; secret=False returns (None, None, bsk, ksk) and also works on
         an evaluation-only context"""

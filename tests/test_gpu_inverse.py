@@ -289,12 +289,16 @@ def _two_rank_worker(rank, world, port, out_dir, tag):
     from bmi_amd import tfhe
     from bmi_amd.main import EncryptedMatrixInversion
     c = next(x for x in load("inverse.json") if x["tag"] == tag)
+    import torch
     eng = tfhe.Engine()
-    eng.keygen(0x5EED)                                   # same seed on every rank: replicated keys
+    eng.keygen_shared()                                  # CSPRNG keys made on rank 0, broadcast to the other rank
     emi = EncryptedMatrixInversion(2, None, 2, c["len"], c["ints"], False, False, engine=eng, shard_threshold=48)
     M = np.array(c["M"]).reshape(2, 2)
     q, s = emi.quantize(M)
-    out = emi.decrypt(emi.evaluate(emi.encrypt(q, s)))
+    enc = emi.encrypt(q, s) if rank == 0 else np.zeros((84, 1025), np.uint64)
+    t = torch.from_numpy(enc.view(np.int64))             # the client's ciphertexts reach every rank
+    dist.broadcast(t, src=0)
+    out = emi.decrypt(emi.evaluate(enc))
     ex = emi._executor()
     np.save(os.path.join(out_dir, f"out{rank}.npy"), out)
     np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array([ex.sharded_levels, len(ex.levels), ex.world]))
