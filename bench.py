@@ -104,7 +104,8 @@ def main():
     ap.add_argument("--inverse-sharded", action="store_true",
                     help="N > 1 only (opt-in): also run the encrypted-inverse leg with its wide levels split across the "
                          "ranks (executor.py; one RCCL all-gather per split level)")
-    ap.add_argument("--shard-threshold", type=int, default=1024, help="narrowest level that is split across ranks")
+    ap.add_argument("--shard-threshold", type=int, default=None,
+                    help="narrowest level that is split across ranks (default: every level wider than one kernel round)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

@@ -23,6 +23,7 @@ import numpy as np
 
 from .circuit import Circuit
 from .program import Program
+from .program import ROUND as Program_ROUND, WIDE_ROUND as Program_WIDE_ROUND
 
 
 def _torus(v, delta_log, q):
@@ -78,10 +79,13 @@ def assign_rows(prog: Program, recycle=True):
 
 
 class Executor:
-    def __init__(self, circuit, engine, group=None, shard_threshold=1024, recycle=True):
+    def __init__(self, circuit, engine, group=None, shard_threshold=None, recycle=True):
         """circuit: a program.Program (or a circuit.Circuit, frozen here); group: a torch.distributed process group (None:
         the default group when initialised with more than one rank, otherwise single-GPU execution); shard_threshold:
-        narrowest level that is split across the ranks; recycle: reuse store rows after a leaf's last consumer."""
+        narrowest level that is split across the ranks - None (default) = every level wider than one latency-kernel
+        round (257 ciphertexts), and the program's levels are then re-packed for `world` x 256 ciphertexts per round
+        (Program.rescheduled): G GPUs working on one level are one machine with G x 256 workgroup slots; recycle: reuse
+        store rows after a leaf's last consumer."""
         import torch
         self.torch = torch
         prog = Program.from_circuit(circuit) if isinstance(circuit, Circuit) else circuit
@@ -93,6 +97,11 @@ class Executor:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             self.dist, self.rank, self.world = dist, dist.get_rank(group), dist.get_world_size(group)
+        if shard_threshold is None:
+            shard_threshold = Program_ROUND + 1
+            if self.world > 1:
+                prog = prog.rescheduled(Program_ROUND * self.world, Program_WIDE_ROUND * self.world)
+                self.c = self.prog = prog
         self.shard_threshold = max(int(shard_threshold), 1)
         self.big = engine.P.big
         n_in = prog.n_inputs

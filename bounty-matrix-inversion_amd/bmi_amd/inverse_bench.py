@@ -13,7 +13,7 @@ from .main import EncryptedMatrixInversion
 CONFIGS = {2: (20, 8), 3: (30, 12), 4: (40, 16), 8: (48, 16)}
 
 
-def run(engine, sizes=(2, 3), shard_threshold=1024):
+def run(engine, sizes=(2, 3), shard_threshold=None):
     """With torch.distributed initialised on several ranks every rank must call this (the wide levels are split
     across the ranks' GPUs, executor.py); every rank returns the same report."""
     out = {}

@@ -106,10 +106,11 @@ class EncryptedMatrixInversion:
     shape: Tuple[int, int]
 
     def __init__(self, n, sampler=None, qfloat_base=2, qfloat_len=32, qfloat_ints=16, true_division=False,
-                 tensorize=False, engine=None, device=0, shard_threshold=1024, cache=True):
+                 tensorize=False, engine=None, device=0, shard_threshold=None, cache=True):
         """The reference's seven arguments (main.py:17-36), then: engine / device (the GPU context to use) and
         shard_threshold (with torch.distributed initialised on several ranks, levels at least this wide are split
-        across the ranks' GPUs, see executor.py)."""
+        across the ranks' GPUs; None = every level wider than one kernel round, levels re-packed for the rank count,
+        see executor.py)."""
         self.shape = (n, n)
         self.qfloat_base, self.qfloat_len, self.qfloat_ints = qfloat_base, qfloat_len, qfloat_ints
         self.true_division, self.tensorize = true_division, tensorize

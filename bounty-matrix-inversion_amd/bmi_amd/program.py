@@ -260,6 +260,14 @@ class Program:
                  const_folds=int(c.stats.get("const_folds", 0)))
         return cls(c.msg_bits, arrays, m)
 
+    def rescheduled(self, round_, wide_round):
+        """The same program with its levels re-packed for another round capacity (G GPUs sharing every level run
+        G x 256 ciphertexts per latency-kernel round): one call of the C++ scheduling pass, no re-tracing."""
+        from . import tfhe
+        arrays = {k: getattr(self, k) for k in self.ARRAYS}
+        arrays["node_level"] = tfhe.circuit_schedule(self.n_inputs, self.node_ptr, self.term_leaf, round_, wide_round)
+        return Program(self.msg_bits, arrays, dict(self.meta, round=int(round_), wide_round=int(wide_round)))
+
     # ---- disk ---------------------------------------------------------------------------------------------------------
     def save(self, path):
         os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -342,11 +350,15 @@ class Program:
         return [int(v) for v in rows(self.out_ptr, self.out_leaf, self.out_coef, self.out_const)]
 
 
-def estimated_evaluate_ms(widths):
-    """Cost model of one evaluation on one MI355X (measured): a level up to 512 ciphertexts wide runs
-    ceil(width / 256) rounds of the latency kernel (4.4 ms each: one workgroup per ciphertext, 256 CUs), a wider one
-    the throughput kernel (10.8 ms per started 1,024 ciphertexts, 96 PBS per ms once the chip is full)."""
-    w = np.asarray(widths, np.float64)
+def estimated_evaluate_ms(widths, gpus=1):
+    """Cost model of one evaluation (measured per-level costs on one MI355X): a level up to 512 ciphertexts
+    wide runs ceil(width / 256) rounds of the latency kernel (4.4 ms each: one workgroup per ciphertext, 256 CUs), a wider
+    one the throughput kernel (10.8 ms per started 1,024 ciphertexts, 96 PBS per ms once the chip is full).  gpus > 1:
+    every level wider than one round is split evenly (each rank bootstraps width / gpus rows; the all-gather of a few MB
+    per level over xGMI is not modelled) - an ESTIMATE, no multi-GPU box was available to measure it."""
+    w = np.ceil(np.asarray(widths, np.float64) / (gpus if gpus > 1 else 1))
+    if gpus > 1:
+        w = np.where(np.asarray(widths) <= 256, np.asarray(widths, np.float64), w)
     lat = 4.4 * np.ceil(w / 256)
     tp = np.maximum(10.8 * np.ceil(w / 1024), w / 96.0)
     return float(np.where(w <= 512, lat, tp).sum())

@@ -707,3 +707,22 @@ def test_run_validates_the_plaintext_against_the_traced_ranges_before_encrypting
     assert calls == [True]                                   # validated with the claim checks on, then went on to encrypt
     singular = emi.run(np.array([[2.0, 4.0], [1.0, 2.0]]), simulate=True)
     assert np.isfinite(singular).all()
+
+
+def test_program_rescheduled_for_more_round_capacity_keeps_depth_and_dependencies():
+    """Program.rescheduled (levels re-packed for G x 256 ciphertexts per round: what the executor does on G ranks): same
+    depth, every look-up after its producers, and fewer levels that need more than one round."""
+    from bmi_amd.main import compile_inverse
+    from bmi_amd.program import ROUND, WIDE_ROUND, estimated_evaluate_ms
+    prog, _ = compile_inverse(3, 18, 8)
+    p4 = prog.rescheduled(4 * ROUND, 4 * WIDE_ROUND)
+    assert p4.depth == prog.depth and p4.n_nodes == prog.n_nodes
+    lvl = p4.node_level
+    prod = np.repeat(np.arange(p4.n_nodes), np.diff(p4.node_ptr))
+    inner = p4.term_leaf >= p4.n_inputs
+    assert (lvl[p4.term_leaf[inner] - p4.n_inputs] < lvl[prod[inner]]).all()
+    flat = [int(v) for v in np.concatenate([np.array(c) for c in ([],)])] if False else None
+    g = next(x for x in load("inverse.json") if x["tag"] == "uniform_3x3_small")
+    vals = np.concatenate([np.array(g["in_arrays"]).reshape(-1), np.array(g["in_signs"])])
+    assert p4.simulate(vals) == prog.simulate(vals)
+    assert estimated_evaluate_ms(p4.level_widths(), 4) <= estimated_evaluate_ms(prog.level_widths(), 1)

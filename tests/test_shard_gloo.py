@@ -136,7 +136,8 @@ def test_two_rank_sharded_executor_matches_simulation(tmp_path):
     inputs = np.array([rng.integers(lo, hi + 1) for lo, hi in zip(circ.leaf_lo[:circ.n_inputs], circ.leaf_hi[:circ.n_inputs])])
     want = np.array(circ.simulate(list(inputs)))
     np.save(tmp_path / "inputs.npy", inputs)
-    for threshold in (1, 16):   # 1: every level is split (odd widths exercise the padding); 16: narrow levels stay replicated
+    for threshold in (1, 16, None):   # 1: every level is split (odd widths exercise the padding); 16: narrow levels stay
+        # replicated; None: the default - levels re-packed for 2 x 256 per round, only levels wider than a round are split
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -145,4 +146,7 @@ def test_two_rank_sharded_executor_matches_simulation(tmp_path):
         for r in range(2):
             assert np.array_equal(np.load(tmp_path / f"out{r}.npy"), want), (threshold, r)
         sharded, total = np.load(tmp_path / "sharded0.npy")
-        assert (sharded == total) if threshold == 1 else (0 < sharded < total)
+        if threshold is None:
+            assert sharded == 0      # no level of this small circuit needs more than one kernel round
+        else:
+            assert (sharded == total) if threshold == 1 else (0 < sharded < total)
