@@ -18,9 +18,12 @@ code; it never prints a line for fewer GPUs than were asked for.
 
 Rank 0 prints ONE JSON line.  `roofline` follows the north star's definition (bootstrap-key bytes per PBS,
 no-reuse convention, against peak HBM bandwidth) for the dominant kernel (blind rotation), whose launch
-duration is measured live with events on the launch stream; `alu` adds the integer-ALU view the path is
-really bound by.  `cpu_baseline` times the oracle (a scalar-per-thread C port, OpenMP over the
-batch) on this box's host cores, on a bounded sample of the same ciphertexts (N=1, rank 0 only).
+duration is measured live with events on the launch stream; `alu` adds the vector-ALU view the path is
+really bound by.  `cpu_baseline` times the oracle's fast path (exact f64 arithmetic, vectorised 32 x 32
+transforms, OpenMP over the batch; bit-identical to the generic oracle, re-checked on a sample inside the run) on this
+box's host cores, on a bounded sample of the same ciphertexts (N=1, rank 0 only).  `roofline_q64_torus` /
+`roofline_q64_goldilocks` repeat the batch on the 2^64 torus (Concrete's modulus) and on the Goldilocks field;
+`config.output_noise` compares the timed outputs' noise with the analytic CGGI variance.
 """
 import argparse
 import json
