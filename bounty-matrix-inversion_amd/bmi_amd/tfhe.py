@@ -74,6 +74,7 @@ _SIGS = {
     "bmi_field_to_torus64": [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p],
     "bmi_set_kernel_variant": [C.c_void_p, C.c_int],
     "bmi_set_keyswitch_variant": [C.c_void_p, C.c_int],
+    "bmi_set_bsk_precision": [C.c_void_p, C.c_uint32],
     "bmi_circuit_prune": [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p],
     "bmi_circuit_schedule": [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                              C.POINTER(C.c_int32)],
@@ -396,6 +397,10 @@ class Engine:
         """blind rotation: 0 auto, 1 pair kernel exchanging per level, 2 latency kernel (two wavefronts per transform on
         the 49-bit field), 3 pair kernel exchanging per CMUX, 4 latency kernel with one wavefront per transform"""
         self._ck(self.lib.bmi_set_kernel_variant(self.h, int(v)), "bmi_set_kernel_variant")
+
+    def set_bsk_precision(self, bits):
+        """2^64 torus, before keygen: 64 = exact key (three limbs), 42 = key rounded to 42 bits (two limbs, 2/3 of the work)"""
+        self._ck(self.lib.bmi_set_bsk_precision(self.h, int(bits)), "bmi_set_bsk_precision")
 
     def set_keyswitch_variant(self, v):
         """keyswitch: 0 auto (int8 matrix-core product), 1 scalar kernel"""

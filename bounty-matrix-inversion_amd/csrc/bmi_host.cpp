@@ -186,6 +186,7 @@ struct bmi_ctx {
     bool have_keys = false;
     bool have_secret = false;  // false for a context that imported evaluation keys only (no encrypt / decrypt)
     u64 seed = 0, enc_counter = 0;
+    int bsk_limbs = bmit::BSK_LIMBS;   // torus: 3 = exact 64-bit key words, 2 = key rounded to 42 bits (bmi_set_bsk_precision)
     bool secure_rng = false;       // true: keys / encryptions drawn from the CSPRNG below; false: test-only seeded streams
     ChaKey rng_secret, rng_public; // independent ChaCha20 keys from getrandom(): secrets + noise / public masks
     std::vector<u64> sk_small, sk_big, bsk_std, ksk;
@@ -630,28 +631,33 @@ int upload_eval_keys(bmi_ctx *c) {
     const bmi_params &P = c->P;
     const uint32_t n = P.n, N = c->N, k = P.k, lk = P.ks_levels;
     // --- upload: bootstrap key -> NTT domain on the GPU; keyswitch key with padded rows
+    if (c->t64() && c->bsk_limbs == 2) {
+        // key stored at 42 bits of precision: every word rounded (half up, as a signed integer) to a multiple of 2^22.  The
+        // rounded key IS the key from here on (bmi_export_keys returns it), so every consumer agrees on it.
+        for (u64 &w : c->bsk_std) w = (u64)((((long long)w + (1ll << 21)) >> 22)) << 22;
+    }
     const size_t bsk_words = c->bsk_std.size();
     if (!c->d_bsk && !c->wide() && !c->quad() && !c->t64()) HIP_OK(c, hipMalloc(&c->d_bsk, bsk_words * 8));
     u64 *d_tmp = nullptr;
     HIP_OK(c, hipMalloc(&d_tmp, bsk_words * sizeof(u64)));
     HIP_OK(c, hipMemcpy(d_tmp, c->bsk_std.data(), bsk_words * sizeof(u64), hipMemcpyHostToDevice));
     int rc = 0;
-    if (c->t64()) {  // 2^64 torus: BSK_LIMBS transform-domain limb polynomials per key polynomial
+    if (c->t64()) {  // 2^64 torus: bsk_limbs transform-domain limb polynomials per key polynomial
         if (c->d_bsk) { (void)hipFree(c->d_bsk); c->d_bsk = nullptr; }
-        if (hipMalloc(&c->d_bsk, bsk_words * 8 * bmit::BSK_LIMBS) != hipSuccess) {
+        if (hipMalloc(&c->d_bsk, bsk_words * 8 * c->bsk_limbs) != hipSuccess) {
             (void)hipFree(d_tmp);
             return fail(c, -2, "hipMalloc(torus limb key) failed");
         }
         rc = bmit::launch_bsk_to_limbs(d_tmp, (double *)c->d_bsk, (const double *)c->d_tw, (uint32_t)(bsk_words / N),
-                                       bmit::BSK_LIMBS, c->stream);
+                                       c->bsk_limbs, c->stream);
         if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_limbs launch failed"); }
         // second copy for the latency kernel, per limb in the slot order of the two-wave half transform
         if (c->d_bsk_lat) { (void)hipFree(c->d_bsk_lat); c->d_bsk_lat = nullptr; }
-        if (hipMalloc(&c->d_bsk_lat, bsk_words * 8 * bmit::BSK_LIMBS) != hipSuccess) {
+        if (hipMalloc(&c->d_bsk_lat, bsk_words * 8 * c->bsk_limbs) != hipSuccess) {
             (void)hipFree(d_tmp);
             return fail(c, -2, "hipMalloc(torus latency-kernel key) failed");
         }
-        rc = bmit::launch_bsk_to_lat(d_tmp, c->d_bsk_lat, c->d_tw_half, (uint32_t)(bsk_words / N), bmit::BSK_LIMBS, c->stream);
+        rc = bmit::launch_bsk_to_lat(d_tmp, c->d_bsk_lat, c->d_tw_half, (uint32_t)(bsk_words / N), c->bsk_limbs, c->stream);
         if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat (torus) launch failed"); }
     } else if (c->wide() || c->quad()) {  // N = 2048 / 4096: one key copy, in the slot order of k_blind_rotate_wide49 / quad49
         if (!c->d_bsk_lat && hipMalloc(&c->d_bsk_lat, bsk_words * 8) != hipSuccess) {
@@ -752,7 +758,7 @@ int bmi_export_keys(const bmi_ctx *c, uint64_t *sk_small, uint64_t *sk_big, uint
 
 int bmi_key_bytes(const bmi_ctx *c, uint64_t *bsk_bytes, uint64_t *ksk_bytes) {
     if (!c) return -1;
-    if (bsk_bytes) *bsk_bytes = (u64)c->P.n * c->rows * (c->P.k + 1) * c->N * 8 * (c->t64() ? bmit::BSK_LIMBS : 1);
+    if (bsk_bytes) *bsk_bytes = (u64)c->P.n * c->rows * (c->P.k + 1) * c->N * 8 * (c->t64() ? c->bsk_limbs : 1);
     if (ksk_bytes) *ksk_bytes = (u64)c->big_n * c->P.ks_levels * (c->P.n + 1) * 8;
     return 0;
 }
@@ -849,6 +855,15 @@ int bmi_lut_get(const bmi_ctx *c, uint32_t lut_id, uint64_t *test_vector) {
     if (!c || !test_vector) return -1;
     if (lut_id >= c->n_luts) return fail(c, -1, "unknown LUT id");
     std::memcpy(test_vector, c->luts_host[lut_id].data(), c->N * 8);
+    return 0;
+}
+
+int bmi_set_bsk_precision(bmi_ctx *c, uint32_t bits) {
+    if (!c) return -1;
+    if (!c->t64()) return fail(c, -1, "the bootstrap-key precision option exists on the 2^64 torus only");
+    if (bits != 64 && bits != 42) return fail(c, -1, "bootstrap-key precision must be 64 (exact) or 42 bits");
+    if (c->have_keys) return fail(c, -1, "set the bootstrap-key precision before generating or importing keys");
+    c->bsk_limbs = bits == 64 ? 3 : 2;
     return 0;
 }
 
@@ -957,11 +972,11 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
         const bool lat_t = c->variant == 2 || c->variant == 4 || (c->variant == 0 && count <= c->lat_threshold);
         if (lat_t) {
             rc = bmit::launch_blind_rotate_lat(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_lat, c->d_tw_half, d_out,
-                                               count, c->P.n, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
+                                               count, c->P.n, c->bsk_limbs, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }
         rc = bmit::launch_blind_rotate(d_small, d_lut_ids, (const u64 *)c->d_luts, (const double *)c->d_bsk,
-                                       (const double *)c->d_tw, d_out, count, c->P.n, bmit::BSK_LIMBS, c->P.bs_levels, c->P.bs_base_log,
+                                       (const double *)c->d_tw, d_out, count, c->P.n, c->bsk_limbs, c->P.bs_levels, c->P.bs_base_log,
                                        (hipStream_t)stream);
         return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
     }

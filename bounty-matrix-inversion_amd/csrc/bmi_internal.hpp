@@ -144,7 +144,7 @@ int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *id
 namespace bmit {
 using gl::i64;
 using gl::u64;
-constexpr int BSK_LIMBS = 3;        // balanced 22-bit limbs of a 64-bit key word
+constexpr int BSK_LIMBS = 3;        // balanced 22-bit limbs of a 64-bit key word (2 limbs of 21 bits for a key rounded to 42 bits)
 constexpr uint32_t KS_LIMBS = 9;    // balanced base-256 limbs of a keyswitch-key word
 int launch_bsk_to_limbs(const u64 *std_polys, double *limb_polys, const double *g_tw, uint32_t n_polys, int limbs,
                         hipStream_t s);
@@ -155,8 +155,8 @@ int launch_blind_rotate(const u64 *small_cts, const uint32_t *lut_ids, const u64
 // half transform ([poly][limb][A_lo 512, A_hi 512]); tables of ntt_half_f64.hpp
 int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, int limbs, hipStream_t s);
 int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_lat,
-                            const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, uint32_t levels, uint32_t base_log,
-                            hipStream_t s);
+                            const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, int limbs, uint32_t levels,
+                            uint32_t base_log, hipStream_t s);
 int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
                      uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,
                      hipStream_t s);

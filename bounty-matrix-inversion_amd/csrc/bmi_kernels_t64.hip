@@ -40,7 +40,16 @@ namespace {
 #ifndef BMI_T64_PRIO
 #define BMI_T64_PRIO 1    // 1 = issue priority steps down through the forward transforms (3, 2, 1), 0 in the limb loop; 0 = none
 #endif
-constexpr int T64_LIMB_BITS = 22;
+// Limb schemes.  3 limbs of 22 bits cover the whole 64-bit key word (exact key).  2 limbs of 21 bits cover a key word
+// whose low 22 bits are zero: the key ROUNDED to 42 bits of precision (bmi_set_bsk_precision; the rounding is applied to
+// the standard-domain key itself at upload, so what is exported - and what the oracle bootstraps with - is the key
+// actually used; the rounding errors of a row's mask words are summed over the key's set bits, so the effective key noise
+// becomes 2^-39.3 instead of 2^-44 at the north-star set: the output noise of the 49-bit field's default, measured).
+template <int LIMBS> struct LimbScheme;
+template <> struct LimbScheme<3> { static constexpr int BITS = 22, PRE = 0; };
+template <> struct LimbScheme<2> { static constexpr int BITS = 21, PRE = 22; };
+__host__ __device__ __forceinline__ int limb_bits(int limbs) { return limbs == 3 ? 22 : 21; }
+__host__ __device__ __forceinline__ int limb_pre(int limbs) { return limbs == 3 ? 0 : 22; }
 constexpr int T64_CTS = 4;
 constexpr int T64_AT_WORDS = BMI_AT_WORDS;
 constexpr int T64_LDS_WORDS = TW_WORDS + 2 * T64_CTS * (SCRATCH_WORDS + N) + T64_CTS * T64_AT_WORDS + 4 * T64_CTS;
@@ -50,12 +59,15 @@ __device__ __forceinline__ uint32_t modswitch_t64(u64 a) {   // round(a * 2N / 2
     return (uint32_t)(((a >> (63 - (LOG_N + 1))) + 1) >> 1) & (2 * N - 1);
 }
 
-// balanced limb j of a signed 64-bit word: k = sum_j limb_j 2^(22 j), limb_j in [-2^21, 2^21) (the last one takes the rest)
+// balanced limb j of a signed 64-bit word: k = 2^pre sum_j limb_j 2^(bits j), limb_j in [-2^(bits-1), 2^(bits-1)) (the last
+// one takes the rest)
 __host__ __device__ __forceinline__ i64 limb_of(i64 k, int j, int limbs) {
-    constexpr i64 B = (i64)1 << T64_LIMB_BITS, H = B >> 1;
+    const int bits = limb_bits(limbs);
+    const i64 B = (i64)1 << bits, H = B >> 1;
+    k >>= limb_pre(limbs);
     for (int t = 0; t < j; t++) {
         const i64 d = ((k + H) & (B - 1)) - H;
-        k = (k - d) >> T64_LIMB_BITS;
+        k = (k - d) >> bits;
     }
     if (j == limbs - 1) return k;
     return ((k + H) & (B - 1)) - H;
@@ -122,8 +134,9 @@ __global__ void __launch_bounds__(128 * T64_CTS)
                        uint32_t count, uint32_t n) {
     constexpr int CTS = T64_CTS;
     // exactness of a limb's sum: 2 L N terms of |digit| <= 2^(BG-1) times |limb| <= 2^(T64_LIMB_BITS-1) must stay below p/2
-    static_assert(2.0 * L * N * (double)(1ull << (BG - 1)) * (double)(1ull << (T64_LIMB_BITS - 1)) < f49::P / 2, "limb sums must stay below p/2");
-    static_assert(LIMBS * T64_LIMB_BITS >= 64 && L * BG < 63, "limbs must cover the 64-bit word");
+    constexpr int LB = LimbScheme<LIMBS>::BITS, PRE = LimbScheme<LIMBS>::PRE;
+    static_assert(2.0 * L * N * (double)(1ull << (BG - 1)) * (double)(1ull << (LB - 1)) < f49::P / 2, "limb sums must stay below p/2");
+    static_assert(PRE + LIMBS * LB >= 64 && L * BG < 63, "limbs must cover the 64-bit word");
     extern __shared__ double lds[];
     double *tiles = lds + TW_WORDS;
     u64 *accs = reinterpret_cast<u64 *>(tiles + 2 * CTS * SCRATCH_WORDS);
@@ -254,7 +267,7 @@ __global__ void __launch_bounds__(128 * T64_CTS)
             inverse(acc, lane, lds, tile);
             // the limb's exact integer result (|.| < 2^47.6 < p/2: the centred residue is the integer), shifted into place
             static_for<0, 16>([&](auto J) {
-                accl[lane + 64 * J] += f64_to_word(f49::red(acc[J])) << (T64_LIMB_BITS * j);
+                accl[lane + 64 * J] += f64_to_word(f49::red(acc[J])) << (PRE + LB * j);
             });
             pin();
         });
@@ -286,8 +299,7 @@ __global__ void __launch_bounds__(128 * T64_CTS)
 //   C  wavefronts 0 .. 11 = (limb, o, parity): inverse half transform, conversion of the exact integers to words,
 //      shift by 22 j and ONE LDS atomic add per coefficient into the accumulator (three limbs meet in a slot)
 constexpr int LT_THREADS = 1024;
-constexpr int LT_LIMBS = 3;
-constexpr int LT_LDS_WORDS = ntth::HT_WORDS + 2 * N + 12 * ntth::HSCRATCH + LT_LIMBS * 2 * N + BMI_AT_WORDS;
+constexpr int LT_LDS_WORDS = ntth::HT_WORDS + 2 * N + 12 * ntth::HSCRATCH + 3 * 2 * N + BMI_AT_WORDS;   // sized for 3 limbs
 static_assert(LT_LDS_WORDS <= BMI_LDS_WORDS_MAX, "LT_LDS_WORDS exceeds the 160 KB of LDS");
 
 // standard-domain GGSW polynomials -> per limb, the slot-order pair (A_lo, A_hi) of the two-wave half transform:
@@ -327,13 +339,13 @@ __global__ void __launch_bounds__(256) k_bsk_to_lat_t64(const u64 *__restrict__ 
     }
 }
 
-template <int L>
+template <int L, int LIMBS = 3>
 __global__ void __launch_bounds__(LT_THREADS)
     k_blind_rotate_lat_t64(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids, const u64 *__restrict__ luts,
                            const double *__restrict__ bsk_lat, const double *__restrict__ g_tw_h, u64 *__restrict__ out,
                            uint32_t count, uint32_t n) {
-    constexpr int BG = 15, LIMBS = LT_LIMBS;
-    static_assert(2.0 * L * N * (double)(1ull << (BG - 1)) * (double)(1ull << (T64_LIMB_BITS - 1)) < f49::P / 2, "limb sums must stay below p/2");
+    constexpr int BG = 15, LB = LimbScheme<LIMBS>::BITS, PRE = LimbScheme<LIMBS>::PRE;
+    static_assert(2.0 * L * N * (double)(1ull << (BG - 1)) * (double)(1ull << (LB - 1)) < f49::P / 2, "limb sums must stay below p/2");
     extern __shared__ double lds[];
     u64 *acc = reinterpret_cast<u64 *>(lds + ntth::HT_WORDS);   // [2 components][2 parities][512] words mod 2^64
     double *tiles = lds + ntth::HT_WORDS + 2 * N;               // [12][HSCRATCH]
@@ -456,7 +468,7 @@ __global__ void __launch_bounds__(LT_THREADS)
             else ntth::inverse_half<false>(x, lane, lds, tile);
             __builtin_amdgcn_s_setprio(0);
             unsigned long long *ao = reinterpret_cast<unsigned long long *>(acc + o * N + h * ntth::HALF);
-            const int sh = T64_LIMB_BITS * j;
+            const int sh = PRE + LB * j;
             static_for<0, 8>([&](auto J) {
                 // the limb's exact integer (|.| < 2^47.6 < p/2), shifted into place; the three limbs of a slot add atomically
                 atomicAdd(ao + lane + 64 * J, (unsigned long long)(f64_to_word(f49::red(x[J])) << sh));
@@ -513,19 +525,19 @@ namespace bmit {
 
 int launch_bsk_to_limbs(const u64 *std_polys, double *limb_polys, const double *g_tw, uint32_t n_polys, int limbs,
                         hipStream_t s) {
-    if (limbs != 3) return (int)hipErrorInvalidValue;
+    if (limbs != 3 && limbs != 2) return (int)hipErrorInvalidValue;
     const uint32_t items = n_polys * (uint32_t)limbs;
     hipLaunchKernelGGL(k_bsk_to_limbs_t64, dim3((items + 3) / 4), dim3(256), 0, s, std_polys, limb_polys, g_tw, n_polys, limbs);
     BMIT_LAUNCH_CHECK();
     return 0;
 }
 
-template <int L>
+template <int L, int LIMBS>
 static int launch_t64(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_limbs,
                       const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
     static std::atomic<uint64_t> configured{0};
     const size_t lds = (size_t)T64_LDS_WORDS * sizeof(double);
-    auto kern = k_blind_rotate_t64<3, L, 15>;
+    auto kern = k_blind_rotate_t64<LIMBS, L, 15>;
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
     hipLaunchKernelGGL(kern, dim3((count + T64_CTS - 1) / T64_CTS), dim3(128 * T64_CTS), lds, s, small_cts, lut_ids, luts,
                        bsk_limbs, g_tw, out, count, n);
@@ -537,26 +549,28 @@ int launch_blind_rotate(const u64 *small_cts, const uint32_t *lut_ids, const u64
                         const double *g_tw, u64 *out, uint32_t count, uint32_t n, int limbs, uint32_t levels,
                         uint32_t base_log, hipStream_t s) {
     if (count == 0) return 0;
-    if (limbs != 3 || base_log != 15) return (int)hipErrorInvalidValue;
-    if (levels == 3) return launch_t64<3>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
-    if (levels == 2) return launch_t64<2>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
+    if ((limbs != 3 && limbs != 2) || base_log != 15) return (int)hipErrorInvalidValue;
+    if (levels == 3 && limbs == 3) return launch_t64<3, 3>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
+    if (levels == 2 && limbs == 3) return launch_t64<2, 3>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
+    if (levels == 3 && limbs == 2) return launch_t64<3, 2>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
+    if (levels == 2 && limbs == 2) return launch_t64<2, 2>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
     return (int)hipErrorInvalidValue;
 }
 
 int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, int limbs, hipStream_t s) {
-    if (limbs != LT_LIMBS) return (int)hipErrorInvalidValue;
+    if (limbs != 3 && limbs != 2) return (int)hipErrorInvalidValue;
     const uint32_t items = n_polys * (uint32_t)limbs;
     hipLaunchKernelGGL(k_bsk_to_lat_t64, dim3((items + 1) / 2), dim3(256), 0, s, std_polys, lat_polys, g_tw_h, n_polys, limbs);
     BMIT_LAUNCH_CHECK();
     return 0;
 }
 
-template <int L>
+template <int L, int LIMBS>
 static int launch_lat_t64(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_lat,
                           const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
     static std::atomic<uint64_t> configured{0};
     const size_t lds = (size_t)LT_LDS_WORDS * sizeof(double);
-    auto kern = k_blind_rotate_lat_t64<L>;
+    auto kern = k_blind_rotate_lat_t64<L, LIMBS>;
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
     hipLaunchKernelGGL(kern, dim3(count), dim3(LT_THREADS), lds, s, small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n);
     BMIT_LAUNCH_CHECK();
@@ -564,12 +578,14 @@ static int launch_lat_t64(const u64 *small_cts, const uint32_t *lut_ids, const u
 }
 
 int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_lat,
-                            const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, uint32_t levels, uint32_t base_log,
-                            hipStream_t s) {
+                            const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, int limbs, uint32_t levels,
+                            uint32_t base_log, hipStream_t s) {
     if (count == 0) return 0;
-    if (base_log != 15) return (int)hipErrorInvalidValue;
-    if (levels == 3) return launch_lat_t64<3>(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s);
-    if (levels == 2) return launch_lat_t64<2>(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s);
+    if (base_log != 15 || (limbs != 3 && limbs != 2)) return (int)hipErrorInvalidValue;
+    if (levels == 3 && limbs == 3) return launch_lat_t64<3, 3>(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s);
+    if (levels == 2 && limbs == 3) return launch_lat_t64<2, 3>(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s);
+    if (levels == 3 && limbs == 2) return launch_lat_t64<3, 2>(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s);
+    if (levels == 2 && limbs == 2) return launch_lat_t64<2, 2>(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s);
     return (int)hipErrorInvalidValue;
 }
 

@@ -14,7 +14,9 @@ def main():
     variants = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1").split(",")]
     qb = int(sys.argv[3]) if len(sys.argv) > 3 else None
     kw = {k[5:].lower(): int(v) for k, v in os.environ.items() if k.startswith("BMIP_")}   # e.g. BMIP_BS_LEVELS=2
-    eng = tfhe.Engine(tfhe.default_params(q_bits=qb, **kw)); eng.keygen(0x5EED)
+    eng = tfhe.Engine(tfhe.default_params(q_bits=qb, **kw))
+    if os.environ.get('BMI_BSK_PRECISION'): eng.set_bsk_precision(int(os.environ['BMI_BSK_PRECISION']))
+    eng.keygen(0x5EED)
     DL = eng.delta_log()
     sk_small, sk_big, bsk, ksk = eng.export_keys()
     octx = to.Ctx(to.default_params(q_bits=eng.q_bits, **kw), bsk, ksk)
