@@ -580,6 +580,9 @@ int gen_eval_keys(bmi_ctx *c, uint64_t seed) {
         u64 *bsk = c->bsk_std.data();
         const double sigma = P.glwe_noise;
         const uint32_t bl = P.bs_base_log;
+        // (A torus key at 42 bits of precision is ROUNDED from this full-precision key at upload.  Drawing the masks on the
+        // 2^22 grid instead would keep the rounding error away from the secret key - measured: output noise 2^-20 - but the
+        // body's noise, std 2^20, is then rounded to the grid too and vanishes in 95 % of the words: not an LWE sample any more.)
         parallel_for((size_t)n * rows, [=](size_t ir) {
             RowRng sm(smp, *kpub, S_BSK_MASK, ir, secure), se(sep, *ksec, S_BSK_NOISE, ir, secure);
             const uint32_t i = (uint32_t)(ir / rows), r = (uint32_t)(ir % rows), comp = r / l, lev = r % l;

@@ -182,14 +182,15 @@ int bmi_sync(bmi_ctx *ctx, void *stream);
 int bmi_set_kernel_variant(bmi_ctx *ctx, int variant);
 
 /* 2^64 torus only, before keygen / import: precision the bootstrap key is stored at.  64 (default): exact - every key
- * word is split into three 22-bit limbs.  42: every key word is rounded to a multiple of 2^22 and split into two 21-bit
- * limbs: 2/3 of the multiply-accumulates and inverse transforms of a CMUX.  The rounded key is the key from then on
- * (bmi_export_keys returns it; results stay bit-exact against an oracle given that key).  Noise: every word carries an
- * extra uniform error of variance 2^44/12, and the errors of a row's mask words are summed over the ~N/2 set bits of the
- * GLWE key when the row is used: the effective key noise becomes 2^-39.3 (from 2^-44 at the north-star set) and the
- * bootstrap output noise 2^-15.15 (from 2^-19.85), measured on the formula.  A throughput option for flat PBS batches
- * (65-67 k PBS/s against 51 k); circuits whose linear combinations amplify the output noise (the encrypted inverse: L2
- * weight up to 75) should keep the exact key. */
+ * word is split into three 22-bit limbs.  42: every key word (generated here or imported) is rounded to a multiple of
+ * 2^22 and split into two 21-bit limbs: 2/3 of the multiply-accumulates and inverse transforms of a CMUX (65-67 k PBS/s
+ * against 51 k, 4.85 ms latency against 6.1).  The rounded key is the context's key from then on (bmi_export_keys
+ * returns it; results are bit-exact against an oracle given that key).  Its price is noise: the rounding errors of a
+ * row's mask words are summed over the ~N/2 set bits of the GLWE key when the row is used, so the effective key noise is
+ * 2^-39.3 (from 2^-44 at the north-star set) and the bootstrap output noise 2^-15.15 (from 2^-19.85), both measured on the
+ * formula (tests/test_gpu_parity.py).  A throughput option for flat PBS batches; circuits whose linear combinations amplify
+ * the output noise (the encrypted inverse: L2 weight up to 75) should keep the exact key.  (The rounding only ever adds
+ * noise to valid LWE samples; generating the key on the grid directly would instead round its own noise away.) */
 int bmi_set_bsk_precision(bmi_ctx *ctx, uint32_t bits);
 
 /* Selects the keyswitch kernel: 0 = auto (int8 matrix-core product when the parameter set allows it),
