@@ -100,6 +100,8 @@ def main():
                     help="ciphertext modulus: 49 = 2^49-720895 (f64 kernels, the default), 65 = 2^64 exactly (Concrete's "
                          "torus; exact products through limb-split f64 transforms), 64 = 2^64-2^32+1 (integer kernels)")
     ap.add_argument("--no-inverse", action="store_true", help="skip the encrypted-inverse wall-clock leg")
+    ap.add_argument("--no-readme-benchmark", action="store_true",
+                    help="skip the reference's README benchmark configurations (2x2 / 3x3 low precision, ~20 s with cold compiles)")
     ap.add_argument("--no-second-field", action="store_true",
                     help="skip the short extra legs that report PBS/s on the 2^64 torus and on the Goldilocks field (N=1, rank 0)")
     ap.add_argument("--inverse-sizes", default="2,3,4", help="matrix sizes of the encrypted-inverse leg (N=1, rank 0): "
@@ -346,6 +348,11 @@ def main():
             res["config"]["encrypted_inverse_wall_clock"] = inverse_bench.run(eng, sizes)
         except Exception as e:  # reported, never hidden
             res["config"]["encrypted_inverse_wall_clock"] = {"error": repr(e)}
+        if not args.no_readme_benchmark:
+            try:   # the reference's own published benchmark configurations (README.md:129-142), beside its figures
+                res["config"]["reference_readme_benchmark"] = inverse_bench.run_readme_low(eng)
+            except Exception as e:
+                res["config"]["reference_readme_benchmark"] = {"error": repr(e)}
 
     if args.inverse_sharded and world > 1:
         from bmi_amd import inverse_bench

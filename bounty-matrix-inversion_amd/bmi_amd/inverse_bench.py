@@ -56,3 +56,50 @@ def run(engine, sizes=(2, 3), shard_threshold=None):
             "max_abs_err_vs_numpy": float(np.max(np.abs(emi.dequantize(dec) - np.linalg.inv(M)))),
         }
     return out
+
+
+# The reference's own published benchmark (README.md:129-142): "low" precision = array length 23, 9 integer digits, base 2,
+# no true division; 2x2 and 3x3, tensorize yes / no; 64-core CPU instance, concrete-python 2.1.0.
+README_LOW = {
+    (2, True): {"compile_s": 41.0, "run_s": 85.0, "total_s": 126.0},
+    (2, False): {"compile_s": 42.0, "run_s": 85.0, "total_s": 127.0},
+    (3, True): {"compile_s": 4255.0, "run_s": 1768.0, "total_s": 6024.0},
+    (3, False): {"compile_s": 5487.0, "run_s": 1349.0, "total_s": 6837.0},
+}
+
+
+def run_readme_low(engine, cold=True):
+    """The reference's README benchmark configurations on this engine: compile (cold = traced from scratch, as the
+    reference does on every start; cached = a load of the program file), encrypt, evaluate, decrypt, beside the published
+    figures.  Results are checked against the plaintext evaluation of the same program."""
+    out = {}
+    for (n, tensorize), ref in README_LOW.items():
+        ln, ints = 23, 9
+        np.random.seed(1234 + n)
+        M = np.random.randn(n, n) * 100
+        t_cold = None
+        if cold:
+            t0 = time.time()
+            EncryptedMatrixInversion(n, None, 2, ln, ints, False, tensorize, engine=engine, cache=False)
+            t_cold = time.time() - t0
+        t0 = time.time()
+        emi = EncryptedMatrixInversion(n, None, 2, ln, ints, False, tensorize, engine=engine)
+        emi._executor()
+        t_compile = time.time() - t0
+        q, s = emi.quantize(M)
+        emi.evaluate(emi.encrypt(q, s))            # warm-up (LUT uploads, first launches)
+        t0 = time.time()
+        enc = emi.encrypt(q, s)
+        res = emi.evaluate(enc)
+        dec = emi.decrypt(res)
+        t_run = time.time() - t0
+        ok = bool(np.array_equal(dec, emi.simulate(q, s)))
+        total_cold = (t_cold if t_cold is not None else t_compile) + t_run
+        out[f"{n}x{n}_len23_ints9_tensorize_{'yes' if tensorize else 'no'}"] = {
+            "compile_cold_s": None if t_cold is None else round(t_cold, 3), "compile_cached_s": round(t_compile, 3),
+            "encrypt_run_decrypt_s": round(t_run, 3), "total_cold_s": round(total_cold, 3),
+            "total_cached_s": round(t_compile + t_run, 3), "pbs": emi.program.n_nodes, "depth": emi.program.depth,
+            "matches_plaintext_circuit": ok,
+            "reference_readme": ref, "speedup_run": round(ref["run_s"] / t_run, 1),
+            "speedup_total_cold": round(ref["total_s"] / total_cold, 1)}
+    return out

@@ -209,6 +209,21 @@ def test_encrypted_inverse_with_a_non_binary_leading_digit(eng, tag):
     assert emi.dequantize(out).flatten().tolist() == c["float"]
 
 
+@pytest.mark.parametrize("tag", ["baseline_n2_len23_ints9", "baseline_n3_len23_ints9"])
+def test_reference_readme_low_precision_configs_match_golden(eng, tag):
+    """The configurations of the reference's own published benchmark (README.md:129-142: "low" precision, len 23, ints 9;
+    85 s / 1,349-1,768 s of FHE run on a 64-core CPU there) on ciphertexts: digits == the reference's."""
+    if eng.q_bits != 49:
+        pytest.skip("run once, on the fastest field")
+    from bmi_amd.main import EncryptedMatrixInversion
+    c = next(x for x in load("inverse.json") if x["tag"] == tag)
+    emi = EncryptedMatrixInversion(c["n"], None, 2, 23, 9, False, False, engine=eng)
+    M = np.array(c["M"]).reshape(c["n"], c["n"])
+    q, s = emi.quantize(M)
+    out = emi.decrypt(emi.evaluate(emi.encrypt(q, s)))
+    assert out.tolist() == c["out"] and emi.dequantize(out).flatten().tolist() == c["float"]
+
+
 def test_random_matrices_under_csprng_keys_match_the_plaintext_circuit(eng):
     """Twelve random 2x2 matrices, fresh CSPRNG keys: decrypted digits == the plaintext evaluation of the same program.
     (tools/gpu_random_inverses.py is the long form: 572 matrices / 11.6 M look-ups, profiles/r02_random_inverses.txt.)"""
