@@ -224,6 +224,23 @@ def test_reference_readme_low_precision_configs_match_golden(eng, tag):
     assert out.tolist() == c["out"] and emi.dequantize(out).flatten().tolist() == c["float"]
 
 
+@pytest.mark.parametrize("tag", ["readme_medium_n2", "readme_medium_n3", "readme_mediumplus_n2", "readme_mediumplus_n3",
+                                 "readme_high_n2", "readme_high_n3"])
+def test_reference_readme_precision_presets_match_golden(eng, tag):
+    """The README's precision presets beyond "low" (README.md:107-114: Medium 31/16, Medium+ 31/16 with true division,
+    High 40/20 with true division), which the reference could not run in FHE (README.md:129), on ciphertexts: digits ==
+    the reference's plaintext QFloat output."""
+    if eng.q_bits != 49:
+        pytest.skip("run once, on the fastest field")
+    from bmi_amd.main import EncryptedMatrixInversion
+    c = next(x for x in load("inverse.json") if x["tag"] == tag)
+    emi = EncryptedMatrixInversion(c["n"], None, 2, c["len"], c["ints"], c["true_division"], False, engine=eng)
+    M = np.array(c["M"]).reshape(c["n"], c["n"])
+    q, s = emi.quantize(M)
+    out = emi.decrypt(emi.evaluate(emi.encrypt(q, s)))
+    assert out.tolist() == c["out"] and emi.dequantize(out).flatten().tolist() == c["float"]
+
+
 def test_random_matrices_under_csprng_keys_match_the_plaintext_circuit(eng):
     """Twelve random 2x2 matrices, fresh CSPRNG keys: decrypted digits == the plaintext evaluation of the same program.
     (tools/gpu_random_inverses.py is the long form: 572 matrices / 11.6 M look-ups, profiles/r02_random_inverses.txt.)"""

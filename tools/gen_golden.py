@@ -247,6 +247,11 @@ def gen_inverse():
     for n, ln, ints in [(2, 20, 8), (3, 30, 12), (4, 40, 16)]:
         np.random.seed(2234 + n)
         one(f"baseline_b_n{n}_len{ln}_ints{ints}", np.random.randn(n, n) * 100, ln, ints)
+    # the README's precision presets beyond "low" (README.md:107-114; the reference could not run them in FHE, :129)
+    for name, ln, ints, td in (("medium", 31, 16, False), ("mediumplus", 31, 16, True), ("high", 40, 20, True)):
+        for n in (2, 3):
+            np.random.seed(3234 + n)
+            one(f"readme_{name}_n{n}", np.random.randn(n, n) * 100, ln, ints, true_division=td)
     return cases
 
 
