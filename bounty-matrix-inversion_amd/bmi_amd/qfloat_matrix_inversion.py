@@ -111,22 +111,27 @@ def _select(c, bit, x, y):
     return x if bit else y
 
 
-def qfloat_argmax(indices, qfloats):
-    """reference :317-328 — encrypted arg-max (first maximum wins)."""
+def _argmax_flags(qfloats):
+    """One flag per candidate, exactly one of them 1: the FIRST maximum (what the reference's running `>` comparison
+    selects, :317-328).  Keeping the position as flags instead of one encrypted integer lets it grow with n (an index in
+    [0, 9] does not fit a 4-bit bivariate select; ten flags do) and hands the pivot its row masks without a look-up."""
     max_qf = qfloats[0].copy()
-    maxi = indices[0]
-    for i in range(1, len(indices)):
+    flags = [1]
+    for i in range(1, len(qfloats)):
         is_gt = qfloats[i] > max_qf
         c = _circ([is_gt], max_qf.array, qfloats[i].array)
         max_qf._array = [_select(c, is_gt, a, b) for a, b in zip(qfloats[i].array, max_qf.array)]
-        maxi = _select(c, is_gt, indices[i], maxi)
-    return maxi
+        keep = 1 - is_gt
+        flags = [f * keep if not (isinstance(f, Lin) and isinstance(keep, Lin)) else c.mul(f, keep) for f in flags] + [is_gt]
+    return flags
 
 
-def _eq_index(r, i):
-    if isinstance(r, Lin):
-        return r.c.lut(r - i, lambda v: int(v == 0))
-    return int(r == i)
+def qfloat_argmax(indices, qfloats):
+    """reference :317-328 - the index of the (first) largest QFloat: sum of index x flag, linear in the flags"""
+    total = 0
+    for idx, f in zip(indices, _argmax_flags(qfloats)):
+        total = total + f * idx
+    return total.assume(min(indices), max(indices)) if isinstance(total, Lin) else total
 
 
 def _bitmul(row, bit):
@@ -134,20 +139,21 @@ def _bitmul(row, bit):
 
 
 def qfloat_pivot_matrix(M):
-    """reference :331-369 — oblivious row swaps of an identity matrix."""
+    """reference :331-369 - oblivious row swaps of an identity matrix: column by column, the row holding the largest
+    |entry| at or below the diagonal is exchanged with the diagonal row."""
     assert len(M) == len(M[0])
     n = len(M)
     piv = [[int(i == j) for j in range(n)] for i in range(n)]
     for j in range(n - 1):
-        r = qfloat_argmax(list(range(j, n)), [abs(M[i][j]) for i in range(j, n)])
+        is_row = _argmax_flags([abs(M[i][j]) for i in range(j, n)])     # is_row[i - j] = [row i holds the maximum]
         tmp = [list(row) for row in piv]
-        acc = _bitmul(tmp[j], _eq_index(r, j))
+        acc = _bitmul(tmp[j], is_row[0])
         for i in range(j + 1, n):
-            acc = [a + b for a, b in zip(acc, _bitmul(tmp[i], _eq_index(r, i)))]
+            acc = [a + b for a, b in zip(acc, _bitmul(tmp[i], is_row[i - j]))]
         acc = [a.assume(0, 1) if isinstance(a, Lin) else a for a in acc]
         piv[j] = acc
         for jj in range(j + 1, n):
-            e = _eq_index(r, jj)
+            e = is_row[jj - j]
             c = _circ([e], tmp[jj], tmp[j])
             piv[jj] = [_select(c, e, b, a) for a, b in zip(tmp[jj], tmp[j])]
     return piv

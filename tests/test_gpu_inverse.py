@@ -241,6 +241,28 @@ def test_reference_readme_precision_presets_match_golden(eng, tag):
     assert out.tolist() == c["out"] and emi.dequantize(out).flatten().tolist() == c["float"]
 
 
+@pytest.mark.parametrize("tag", ["main_n5_len23_ints9", "main_n10_len23_ints9"])
+def test_larger_sizes_of_the_reference_driver_match_golden(eng, tag):
+    """n = 5 and n = 10, the larger sizes the reference's own driver loops over (main.py:157-201; its README precision table
+    goes to n = 10 in plaintext only), low precision, on ciphertexts: digits == the reference's.  The pivot keeps the
+    arg-max position as one-hot flags, so it does not depend on an index fitting a 4-bit look-up."""
+    if eng.q_bits != 49:
+        pytest.skip("run once, on the fastest field")
+    import time
+    from bmi_amd.main import EncryptedMatrixInversion
+    c = next(x for x in load("inverse.json") if x["tag"] == tag)
+    n = c["n"]
+    emi = EncryptedMatrixInversion(n, None, 2, 23, 9, False, False, engine=eng)
+    M = np.array(c["M"]).reshape(n, n)
+    q, s = emi.quantize(M)
+    enc = emi.encrypt(q, s)
+    emi._executor()
+    t0 = time.time()
+    out = emi.decrypt(emi.evaluate(enc))
+    print(f"encrypted {n}x{n} (len 23, ints 9): {time.time() - t0:.1f} s, {emi.circuit.summary()}")
+    assert out.tolist() == c["out"] and emi.dequantize(out).flatten().tolist() == c["float"]
+
+
 def test_random_matrices_under_csprng_keys_match_the_plaintext_circuit(eng):
     """Twelve random 2x2 matrices, fresh CSPRNG keys: decrypted digits == the plaintext evaluation of the same program.
     (tools/gpu_random_inverses.py is the long form: 572 matrices / 11.6 M look-ups, profiles/r02_random_inverses.txt.)"""

@@ -252,6 +252,10 @@ def gen_inverse():
         for n in (2, 3):
             np.random.seed(3234 + n)
             one(f"readme_{name}_n{n}", np.random.randn(n, n) * 100, ln, ints, true_division=td)
+    # the larger sizes of the reference's own driver (main.py:157-201 loops n over 2, 3, 5, 10), low precision
+    for n in (5, 10):
+        np.random.seed(4234 + n)
+        one(f"main_n{n}_len23_ints9", np.random.randn(n, n) * 100, 23, 9)
     return cases
 
 
