@@ -183,7 +183,11 @@ class Executor:
         dist, torch = self.dist, self.torch
         mine = region[self.rank * per: (self.rank + 1) * per]
         if dist.get_backend(self.group) == "nccl":
-            dist.all_gather_into_tensor(region, mine, group=self.group)   # RCCL, in place, on the compute stream order
+            # RCCL, in place (rank r's part already sits at its offset), ordered after this level's kernels: they were
+            # launched on torch's current stream, which the collective synchronises with.  Exercised by
+            # tests/test_gpu_inverse.py::test_two_gpu_rccl_sharded_inverse, which needs two GPUs (the build's test boxes
+            # have one: there the gloo branch below runs).
+            dist.all_gather_into_tensor(region, mine, group=self.group)
             return
         # other backends (gloo rehearsal): stage through the host
         if self.on_gpu:

@@ -379,6 +379,56 @@ def test_two_rank_sharded_encrypted_inverse(tmp_path):
     assert world == 2 and 0 < sharded < total
 
 
+def _two_gpu_worker(rank, world, port, out_dir, tag):
+    """one rank per GPU, RCCL: the in-place all_gather_into_tensor branch of the executor and keygen_shared over nccl"""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from bmi_amd import tfhe
+    from bmi_amd.main import EncryptedMatrixInversion
+    c = next(x for x in load("inverse.json") if x["tag"] == tag)
+    eng = tfhe.Engine(device=rank)
+    eng.keygen_shared()
+    emi = EncryptedMatrixInversion(c["n"], None, 2, c["len"], c["ints"], False, False, engine=eng, device=rank)
+    M = np.array(c["M"]).reshape(c["n"], c["n"])
+    q, s = emi.quantize(M)
+    enc = emi.encrypt(q, s) if rank == 0 else np.zeros((c["n"] ** 2 * (c["len"] + 1), 1025), np.uint64)
+    t = torch.from_numpy(enc.view(np.int64)).to(torch.device("cuda", rank))
+    dist.broadcast(t, src=0)
+    enc = t.cpu().numpy().view(np.uint64)
+    out = emi.decrypt(emi.evaluate(enc))
+    ex = emi._executor()
+    np.save(os.path.join(out_dir, f"out{rank}.npy"), out)
+    np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array([ex.sharded_levels, len(ex.levels), ex.world]))
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+def test_two_gpu_rccl_sharded_inverse(tmp_path):
+    """The RCCL branch of the sharded executor (in-place all-gather on the compute stream) and key broadcast over nccl, one
+    rank per GPU, default sharding: needs two GPUs - skipped on the one-GPU test boxes, there for a multi-GPU node."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import socket
+    import torch.multiprocessing as mp
+    tag = "baseline_n3_len30_ints12"
+    c = next(x for x in load("inverse.json") if x["tag"] == tag)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_gpu_worker, args=(2, port, str(tmp_path), tag), nprocs=2, join=True)
+    for r in range(2):
+        assert np.load(tmp_path / f"out{r}.npy").tolist() == c["out"], r
+    sharded, total, world = np.load(tmp_path / "meta0.npy")
+    assert world == 2 and 0 < sharded < total
+
+
 def test_encrypted_2x2_inverse_on_the_N2048_parameter_set():
     """The second parameter set (N = 2048, 49-bit field) under the whole stack: ciphertexts of 2,049 words through the
     executor, the 16,384-row keyswitch and k_blind_rotate_wide49; decrypted digits equal the reference's."""
