@@ -141,6 +141,14 @@ def _circ(*xs):
     return None
 
 
+PAIR_PRODUCTS = True    # _product: two bit x bit partial products of a column per look-up (False: one each, as in round 1)
+
+
+def _two_ands(v):
+    """v = 8 x + 4 y + 2 x' + y' with all four bits: x y + x' y'"""
+    return ((v >> 3) & (v >> 2) & 1) + ((v >> 1) & v & 1)
+
+
 def _mul(a, b):
     """product of two scalars, each an int or a Lin"""
     if _is_enc(a) and _is_enc(b):
@@ -604,14 +612,33 @@ def _product(a, b, newlength, newints):
     p = a.base
     c = _circ(a._array, b._array)
     cols = [[] for _ in range(newlength)]
+    # Two partial products of the same column in ONE look-up when all four digits are encrypted bits: the packed value
+    # 8 x + 4 y + 2 x' + y' spans the 16 entries of a 4-bit table, whose output x y + x' y' (0..2) goes into the column
+    # sum as one term.  Halves the look-ups of the schoolbook product (the widest levels of the inverse); the column sums,
+    # hence the digits, are unchanged.
+    waiting = {}
+
+    def is_bit(v):
+        return _is_enc(v) and v.lo >= 0 and v.hi <= 1
+
     for i in range(len(a)):
         off = newints - a.ints + i + 1 - b.ints
         for j in range(len(b)):
             col = off + j
             if 0 <= col < newlength:
-                t = _mul(a._array[i], b._array[j])
+                x, y = a._array[i], b._array[j]
+                if PAIR_PRODUCTS and is_bit(x) and is_bit(y):
+                    first = waiting.pop(col, None)
+                    if first is None:
+                        waiting[col] = (x, y)
+                    else:
+                        cols[col].append(c.lut(first[0] * 8 + first[1] * 4 + x * 2 + y, _two_ands))
+                    continue
+                t = _mul(x, y)
                 if not (not _is_enc(t) and t == 0):
                     cols[col].append(t)
+    for col, (x, y) in waiting.items():
+        cols[col].append(_mul(x, y))
     sign = _mul(a._sign, b._sign)
     if c is None:
         return QFloat(np.array([sum(col) for col in cols], dtype=np.int64), newints, p, False, sign)
