@@ -61,12 +61,18 @@ __global__ void __launch_bounds__(256) k_negacyclic_mul49(const u64 *__restrict_
     static_for<0, 16>([&](auto J) { c[(size_t)p * N + lane + 64 * J] = f49::to_u(x[J]); });
 }
 
-// Rounded value r = rint(v / 2^4) of a centred coefficient v (l = 3, base 2^15: 45 of the 49 bits are kept); the
-// three signed digits are recovered from r with round-half-even steps (digit_lev in [-2^14, 2^14]).
+// Decomposition rule of every modulus of this library (and of the oracle): the centred coefficient is rounded HALF UP to its
+// top l * Bg bits, r = floor(v / 2^shift + 1/2), and r is split into balanced signed digits d in [-Bg/2, Bg/2) from the
+// least significant one up, r <- floor(r / Bg + 1/2), the top digit taking the last carry - the closest-representative
+// signed decomposition of the TFHE literature.  In f64 every step is exact: one v_fma_f64 and one v_floor_f64.
+__device__ __forceinline__ double round_half_up(double x, double scale) { return __builtin_floor(__builtin_fma(x, scale, 0.5)); }
+
+// Rounded value r of a centred coefficient v (l = 3, base 2^15: 45 of the 49 bits are kept, r = round_half_up(v, 2^-4)); the
+// three signed digits recovered from r.
 __device__ __forceinline__ double digit_of(double r, int lev) {
-    const double r1 = __builtin_rint(r * 0x1p-15);
+    const double r1 = round_half_up(r, 0x1p-15);
     if (lev == 2) return __builtin_fma(-32768.0, r1, r);
-    const double r2 = __builtin_rint(r1 * 0x1p-15);
+    const double r2 = round_half_up(r1, 0x1p-15);
     if (lev == 1) return __builtin_fma(-32768.0, r2, r1);
     return r2;
 }
@@ -78,11 +84,11 @@ struct Dec {
     static constexpr double B = (double)(1ull << BG);
     static constexpr double BINV = 1.0 / (double)(1ull << BG);
     static_assert(L >= 1 && L <= 3 && L * BG <= 48, "decomposition must fit the 49-bit field");
-    // digit `lev` (0 = most significant) of the rounded value r, round-half-even steps
+    // digit `lev` (0 = most significant) of the rounded value r
     static __device__ __forceinline__ double digit(double r, int lev) {
 #pragma unroll
         for (int t = L - 1; t > 0; t--) {
-            const double rn = __builtin_rint(r * BINV);
+            const double rn = round_half_up(r, BINV);
             if (t == lev) return __builtin_fma(-B, rn, r);
             r = rn;
         }
@@ -90,7 +96,7 @@ struct Dec {
     }
     // peels the least significant remaining digit off r
     static __device__ __forceinline__ double peel(double &r) {
-        const double rn = __builtin_rint(r * BINV);
+        const double rn = round_half_up(r, BINV);
         const double d = __builtin_fma(-B, rn, r);
         r = rn;
         return d;
@@ -118,10 +124,10 @@ __device__ unsigned long long g_phase[128];
 #define PH_FLUSH()
 #endif
 
-// Peels the least significant remaining digit off r (round-half-even): returns it and leaves rint(r / 2^15) in r.
+// Peels the least significant remaining digit off r: returns it and leaves floor(r / 2^15 + 1/2) in r.
 // Walking the levels 2, 1, 0 this way keeps ONE array live (digit_of() from r would keep r, r1 and r2).
 __device__ __forceinline__ double peel_digit(double &r) {
-    const double rn = __builtin_rint(r * 0x1p-15);
+    const double rn = round_half_up(r, 0x1p-15);
     const double d = __builtin_fma(-32768.0, rn, r);
     r = rn;
     return d;
@@ -171,7 +177,7 @@ __global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
             const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
             double v = tile[e & (N - 1)];
             v = (e & N) ? -v : v;
-            r[J] = __builtin_rint(f49::red(v - acc[J]) * 0x1p-4);
+            r[J] = round_half_up(f49::red(v - acc[J]), 0x1p-4);
         });
         double accn[16];
         PH_MARK(0);
@@ -340,7 +346,7 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
             static_for<0, 16>([&](auto J) {
                 const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
                 const double v = (e & N) ? -vr[J] : vr[J];
-                r[J] = __builtin_rint(f49::red(v - vs[J]) * Dec<L, BG>::SC);
+                r[J] = round_half_up(f49::red(v - vs[J]), Dec<L, BG>::SC);
             });
         }
         double am[16], ao[16];  // partial sums: own component, partner's component
@@ -491,7 +497,7 @@ __global__ void __launch_bounds__(LAT_THREADS)
                 const uint32_t e = (mm + 2 * N - a_t) & (2 * N - 1);
                 double v = a[e & (N - 1)];
                 v = (e & N) ? -v : v;
-                x[J] = digit_of(__builtin_rint(f49::red(v - a[mm]) * 0x1p-4), lev);
+                x[J] = digit_of(round_half_up(f49::red(v - a[mm]), 0x1p-4), lev);
             });
             double *tile = tiles + wave * SCRATCH_WORDS;
             forward(x, lane, lds, tile);
@@ -637,7 +643,7 @@ __global__ void __launch_bounds__(L2_THREADS)
                 const uint32_t n2 = e & (N - 1);
                 double v = ac[(n2 & 1) * ntth::HALF + (n2 >> 1)];
                 v = (e & N) ? -v : v;
-                x[J] = Dec<L, BG>::digit(__builtin_rint(f49::red(v - ac[h * ntth::HALF + m]) * Dec<L, BG>::SC), lev);
+                x[J] = Dec<L, BG>::digit(round_half_up(f49::red(v - ac[h * ntth::HALF + m]), Dec<L, BG>::SC), lev);
             });
             double *tile = tiles + (2 * pz + h) * ntth::HSCRATCH;
             if (h) ntth::forward_half<true>(x, lane, lds, tile);
@@ -843,7 +849,7 @@ __global__ void __launch_bounds__(W_THREADS)
                     const uint32_t n2 = e & (W_N - 1);
                     double v = ac[(n2 & 1) * N + (n2 >> 1)];
                     v = (e & W_N) ? -v : v;
-                    x[J] = Dec<L, BG>::digit(__builtin_rint(f49::red(v - ac[h * N + m]) * Dec<L, BG>::SC), lev);
+                    x[J] = Dec<L, BG>::digit(round_half_up(f49::red(v - ac[h * N + m]), Dec<L, BG>::SC), lev);
                 });
                 pin();
                 load_rows(std::integral_constant<int, S1>(), std::integral_constant<int, S2>());
@@ -1047,7 +1053,7 @@ __global__ void __launch_bounds__(Q_THREADS)
                     const uint32_t n2 = e & (Q_N - 1);
                     double v = ac[(n2 & 3) * N + (n2 >> 2)];
                     v = (e & Q_N) ? -v : v;
-                    x[J] = digit_of(__builtin_rint(f49::red(v - ac[j * N + m]) * 0x1p-4), lev);
+                    x[J] = digit_of(round_half_up(f49::red(v - ac[j * N + m]), 0x1p-4), lev);
                 });
                 quad_forward_task<true>(x, j, lane, lds, g_t, tiles + wave * SCRATCH_WORDS);
             }
@@ -1133,13 +1139,16 @@ __global__ void __launch_bounds__(Q_THREADS)
 
 struct Field49 {
     static __device__ __forceinline__ void digits(u64 a, uint32_t levels, uint32_t base_log, unsigned char *d) {
-        // centred lift, every rounding round-half-to-even, digits in [-B/2, B/2]
-        const i64 half = (i64)1 << (base_log - 1);
-        i64 r = f49::rne_shift(f49::centered(a), f49::QBITS - levels * base_log);
+        // centred lift, round half up to the top levels * base_log bits, signed digits in [-B/2, B/2), top absorbs the carry
+        const uint32_t shift = f49::QBITS - levels * base_log;
+        const i64 B = (i64)1 << base_log, half = B >> 1;
+        const i64 c = f49::centered(a);
+        i64 r = (c >> shift) + ((c >> (shift - 1)) & 1);
         for (int lev = (int)levels - 1; lev >= 1; lev--) {
-            const i64 rn = f49::rne_shift(r, base_log);
-            d[lev] = (unsigned char)(r - (i64)((u64)rn << base_log) + half);
-            r = rn;
+            i64 v = r & (B - 1);
+            r >>= base_log;
+            if (v >= half) { v -= B; r += 1; }
+            d[lev] = (unsigned char)(v + half);
         }
         d[0] = (unsigned char)(r + half);
     }

@@ -49,11 +49,6 @@ F49_HD u64 negq(u64 a) { return a ? Q - a : 0; }
 F49_HD u64 mulq(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % Q); }
 F49_HD u64 from_i64(i64 v) { return v >= 0 ? (u64)v % Q : Q - ((u64)(-v) % Q); }
 F49_HD i64 centered(u64 a) { return a > (Q >> 1) ? (i64)a - (i64)Q : (i64)a; }
-// round-half-to-even of x / 2^k
-F49_HD i64 rne_shift(i64 x, uint32_t k) {
-    const i64 q = x >> k, rem = x - (i64)((u64)q << k), half = (i64)1 << (k - 1);
-    return (rem > half || (rem == half && (q & 1))) ? q + 1 : q;
-}
 F49_HD uint32_t modswitch(u64 a, uint32_t log2N) {
     return (uint32_t)(((a << log2N) + (Q >> 1)) / Q) & ((1u << log2N) - 1u);  // a < 2^49, log2N <= 14: no overflow
 }

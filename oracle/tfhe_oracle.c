@@ -126,7 +126,7 @@ static inline u64 rnd_gauss(u64 key, u64 idx, double sigma) { /* element of Z_q 
     return from_i64(llround(g * sigma * (QBITS == 64 ? 18446744073709551616.0 : (double)Q)));
 }
 enum { ST_SK_SMALL = 1, ST_SK_BIG = 2, ST_BSK_MASK = 3, ST_BSK_NOISE = 4, ST_KSK_MASK = 5, ST_KSK_NOISE = 6,
-       ST_ENC_MASK = 7, ST_ENC_NOISE = 8 };
+       ST_ENC_MASK = 7, ST_ENC_NOISE = 8, ST_BSK3_MASK = 9, ST_BSK3_NOISE = 10 };
 
 /* ------------------------------------------------------------ negacyclic NTT */
 typedef struct {
@@ -266,27 +266,11 @@ void ora_negacyclic_ntt(uint32_t logN, const u64 *a, const u64 *b, u64 *c) {
  * (gadget element 2^(64 - base_log*(lev+1))).  Lower digits lie in [-B/2, B/2); the top
  * digit absorbs the last carry and lies in [-B/2, B/2], so sum_lev digit*gadget equals the
  * centred lift rounded to a multiple of 2^(64 - levels*base_log), exactly (no wrap). */
-/* round-half-to-even of x / 2^k (what v_rndne_f64 computes on the GPU) */
-static inline i64 rne_shift(i64 x, uint32_t k) {
-    i64 q = x >> k, rem = x - (i64)((u64)q << k), half = (i64)1 << (k - 1);   /* shifts of negative values through u64: defined */
-    if (rem > half || (rem == half && (q & 1))) q++;
-    return q;
-}
 void ora_decompose(u64 a, uint32_t levels, uint32_t base_log, i64 *digits) {
+    /* one rule for every modulus: round half up to the top levels*base_log bits, then balanced digits from the least
+     * significant one, each step r <- floor(r / B + 1/2) (the signed decomposition of CGGI, Alg. 1 of the TFHE paper) */
     i64 c = centered(a);
     uint32_t shift = QBITS - levels * base_log;
-    if (QBITS != 64) {
-        /* 49-bit field: every rounding is round-half-to-even (the GPU does it with v_rndne_f64), digits lie in
-         * [-B/2, B/2] and recompose exactly to the rounded value */
-        i64 r = rne_shift(c, shift);
-        for (int lev = (int)levels - 1; lev >= 1; lev--) {
-            i64 rn = rne_shift(r, base_log);
-            digits[lev] = r - (i64)((u64)rn << base_log);
-            r = rn;
-        }
-        digits[0] = r;
-        return;
-    }
     i64 r = (c >> shift) + ((c >> (shift - 1)) & 1); /* round half up, no 64-bit overflow */
     i64 B = (i64)1 << base_log, half = B >> 1;
     for (int lev = (int)levels - 1; lev >= 1; lev--) {
@@ -320,15 +304,15 @@ static void poly_rot(uint32_t N, const u64 *in, uint32_t e, u64 *out) {
  *   bsk[n][(k+1)*l][(k+1)][N]   standard (coefficient) domain GGSW rows;
  *                               row r = comp*l + lev carries s_i * 2^(64-Bg*(lev+1)) on component comp
  *   ksk[k*N][l_ks][n+1]    LWE_small( sk_big[j] * 2^(64-Bks*(lev+1)) ), body last
+ *   bsk3[ceil(n/2)][3][(k+1)*l][(k+1)][N]   the UNROLLED bootstrap key (two LWE coefficients per blind-rotation step,
+ *                               ora_keygen_bsk_unrolled): GGSW(s s'), GGSW(s (1 - s')), GGSW((1 - s) s') of the pair
+ *                               (s, s') = (s_2i, s_2i+1); an odd n is completed by s_n = 0
  */
-void ora_keygen(const ora_params *P, u64 seed, u64 *sk_small, u64 *sk_big, u64 *bsk, u64 *ksk) {
-    ora_set_field(P->q_bits);
-    uint32_t n = P->n, N = 1u << P->log_N, k = P->k, l = P->bs_levels, lk = P->ks_levels;
-    u64 k1 = stream_key(seed, ST_SK_SMALL), k2 = stream_key(seed, ST_SK_BIG);
-    for (uint32_t i = 0; i < n; i++) sk_small[i] = rnd_u64(k1, i) & 1;
-    for (uint32_t i = 0; i < k * N; i++) sk_big[i] = rnd_u64(k2, i) & 1;
-
-    u64 km = stream_key(seed, ST_BSK_MASK), ke = stream_key(seed, ST_BSK_NOISE);
+/* count GGSW encryptions under the GLWE key sk_big, standard (coefficient) domain, of the bits msg[0..count): row ir =
+ * (g * (k+1) l + comp * l + lev) draws its masks from indices (ir (k+1) + j) N + x of stream km and its noise from indices
+ * ir N + x of stream ke, and carries msg[g] * 2^(QBITS - Bg (lev+1)) on component comp. */
+static void ggsw_rows(const ora_params *P, u64 km, u64 ke, const u64 *sk_big, const u64 *msg, uint32_t count, u64 *out) {
+    uint32_t N = 1u << P->log_N, k = P->k, l = P->bs_levels;
     ntt_tab *t = TORUS ? NULL : ntt_make(P->log_N);
     u64 *S = (u64 *)malloc((size_t)k * N * 8); /* NTT of the GLWE secret polynomials */
     memcpy(S, sk_big, (size_t)k * N * 8);
@@ -338,9 +322,9 @@ void ora_keygen(const ora_params *P, u64 seed, u64 *sk_small, u64 *sk_big, u64 *
     {
         u64 *tmp = (u64 *)malloc(N * 8), *acc = (u64 *)malloc(N * 8);
 #pragma omp for schedule(static)
-        for (uint32_t ir = 0; ir < n * rows; ir++) {
+        for (uint32_t ir = 0; ir < count * rows; ir++) {
             uint32_t i = ir / rows, r = ir % rows, comp = r / l, lev = r % l;
-            u64 *row = bsk + (size_t)ir * (k + 1) * N;
+            u64 *row = out + (size_t)ir * (k + 1) * N;
             memset(acc, 0, N * 8);
             for (uint32_t j = 0; j < k; j++) {
                 u64 *A = row + (size_t)j * N;
@@ -360,7 +344,7 @@ void ora_keygen(const ora_params *P, u64 seed, u64 *sk_small, u64 *sk_big, u64 *
             if (!TORUS) ntt_inv(t, acc);
             u64 *B = row + (size_t)k * N;
             for (uint32_t x = 0; x < N; x++) B[x] = addq(acc[x], rnd_gauss(ke, (u64)ir * N + x, P->glwe_noise));
-            if (sk_small[i]) {
+            if (msg[i]) {
                 u64 g = (u64)1 << (QBITS - P->bs_base_log * (lev + 1));
                 row[(size_t)comp * N] = addq(row[(size_t)comp * N], g);
             }
@@ -368,6 +352,16 @@ void ora_keygen(const ora_params *P, u64 seed, u64 *sk_small, u64 *sk_big, u64 *
         free(tmp); free(acc);
     }
     free(S); if (t) ntt_free(t);
+}
+
+void ora_keygen(const ora_params *P, u64 seed, u64 *sk_small, u64 *sk_big, u64 *bsk, u64 *ksk) {
+    ora_set_field(P->q_bits);
+    uint32_t n = P->n, N = 1u << P->log_N, k = P->k, l = P->bs_levels, lk = P->ks_levels;
+    u64 k1 = stream_key(seed, ST_SK_SMALL), k2 = stream_key(seed, ST_SK_BIG);
+    for (uint32_t i = 0; i < n; i++) sk_small[i] = rnd_u64(k1, i) & 1;
+    for (uint32_t i = 0; i < k * N; i++) sk_big[i] = rnd_u64(k2, i) & 1;
+
+    ggsw_rows(P, stream_key(seed, ST_BSK_MASK), stream_key(seed, ST_BSK_NOISE), sk_big, sk_small, n, bsk);
 
     u64 kkm = stream_key(seed, ST_KSK_MASK), kke = stream_key(seed, ST_KSK_NOISE);
 #pragma omp parallel for schedule(static)
@@ -382,6 +376,22 @@ void ora_keygen(const ora_params *P, u64 seed, u64 *sk_small, u64 *sk_big, u64 *
         if (sk_big[j]) b = addq(b, (u64)1 << (QBITS - P->ks_base_log * (lev + 1)));
         row[n] = b;
     }
+}
+
+/* Unrolled bootstrap key (Zhou et al. 2018 / Bourse et al. 2018, unrolling factor 2):
+ *   X^(a s + a' s') - 1 = s s' (X^(a+a') - 1) + s (1 - s') (X^a - 1) + (1 - s) s' (X^a' - 1)     for bits s, s',
+ * so one step ACC <- ACC + sum_j (X^(c_j) - 1) * (K_j [.] ACC), c = (a + a', a, a'), absorbs two LWE coefficients with ONE
+ * decomposition and one set of forward transforms.  Streams ST_BSK3_MASK / ST_BSK3_NOISE, rows numbered (3 i + j) rows + r. */
+void ora_keygen_bsk_unrolled(const ora_params *P, u64 seed, const u64 *sk_small, const u64 *sk_big, u64 *bsk3) {
+    ora_set_field(P->q_bits);
+    uint32_t n = P->n, pairs = (n + 1) / 2;
+    u64 *msg = (u64 *)malloc((size_t)pairs * 3 * 8);
+    for (uint32_t i = 0; i < pairs; i++) {
+        u64 s = sk_small[2 * i], s2 = 2 * i + 1 < n ? sk_small[2 * i + 1] : 0;
+        msg[3 * i] = s & s2; msg[3 * i + 1] = s & (s2 ^ 1); msg[3 * i + 2] = (s ^ 1) & s2;
+    }
+    ggsw_rows(P, stream_key(seed, ST_BSK3_MASK), stream_key(seed, ST_BSK3_NOISE), sk_big, msg, pairs * 3, bsk3);
+    free(msg);
 }
 
 /* LWE encryption of torus values under a binary key of dimension dim; ciphertext i
@@ -836,8 +846,8 @@ F_CLONES static void f_br_step(const ora_fctx *c, const u64 *lwe, uint32_t i, f_
         for (uint32_t comp = 0; comp <= k; comp++) {
             const double *a = acc + (size_t)comp * N;
             double *d0 = dec + (size_t)comp * l * N;
-            /* rot = X^at * a as two contiguous runs (no per-element branch), then (rot - a) centred, rounded (half to
-             * even) to its top l * Bg bits and peeled into signed digits: all three loops vectorise */
+            /* rot = X^at * a as two contiguous runs (no per-element branch), then (rot - a) centred, rounded (half
+             * up) to its top l * Bg bits and peeled into signed digits: all three loops vectorise */
             double *rot = res;   /* scratch: res is rewritten below */
             {
                 const uint32_t b = at & (N - 1);
@@ -845,11 +855,11 @@ F_CLONES static void f_br_step(const ora_fctx *c, const u64 *lwe, uint32_t i, f_
                 for (uint32_t x = 0; x < b; x++) rot[x] = -sg * a[x + N - b];
                 for (uint32_t x = b; x < N; x++) rot[x] = sg * a[x - b];
             }
-            for (uint32_t x = 0; x < N; x++) d0[x] = __builtin_rint(f_red(rot[x] - a[x]) * sc);
+            for (uint32_t x = 0; x < N; x++) d0[x] = __builtin_floor(__builtin_fma(f_red(rot[x] - a[x]), sc, 0.5));
             for (int lev = (int)l - 1; lev >= 1; lev--) {
                 double *dl_ = d0 + (size_t)lev * N;
                 for (uint32_t x = 0; x < N; x++) {
-                    double r = d0[x], rn = __builtin_rint(r * Binv);
+                    double r = d0[x], rn = __builtin_floor(__builtin_fma(r, Binv, 0.5));
                     dl_[x] = __builtin_fma(-B, rn, r);
                     d0[x] = rn;
                 }

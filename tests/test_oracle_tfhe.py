@@ -155,21 +155,27 @@ def test_p49_is_an_ntt_prime_and_ntt_matches_schoolbook(field49):
         assert np.array_equal(to.negacyclic(logN, a, b), to.negacyclic(logN, a, b, schoolbook=True))
 
 
-def test_p49_decompose_round_half_even(field49):
+def test_p49_decompose_round_half_up(field49):
+    """One decomposition rule on every modulus (oracle/tfhe_oracle.c ora_decompose): round half up to the top
+    levels * base_log bits, balanced digits in [-B/2, B/2) from the least significant one, the top digit taking the last carry."""
     q = field49
-    for levels, bl in [(3, 15), (8, 4), (2, 8)]:
+    for levels, bl in [(3, 15), (8, 4), (2, 8), (2, 15), (1, 23)]:
         shift = 49 - levels * bl
-        for a in list(rand_q49(300, q)) + [0, 1, q - 1, q // 2, q // 2 + 1, (1 << shift) // 2, 3 * (1 << shift) // 2]:
-            d = to.decompose(a, levels, bl)
-            assert all(abs(int(x)) <= (1 << (bl - 1)) for x in d)
+        B = 1 << bl
+        for a in list(rand_q49(300, q)) + [0, 1, q - 1, q // 2, q // 2 + 1, (1 << shift) // 2, 3 * (1 << shift) // 2,
+                                           (B // 2) << shift, ((B // 2) << shift) - (1 << (shift - 1))]:
+            d = [int(x) for x in to.decompose(a, levels, bl)]
+            assert all(-B // 2 <= x < B // 2 for x in d[1:]) and -B // 2 <= d[0] <= B // 2
             c = int(a) if int(a) <= q // 2 else int(a) - q
-            rec = sum(int(d[i]) << (49 - bl * (i + 1)) for i in range(levels))
-            assert abs(rec - c) <= 1 << (shift - 1)
-            # the rounded value is round-half-even of c / 2^shift
-            r, rem = divmod(c, 1 << shift)
-            if rem > (1 << (shift - 1)) or (rem == (1 << (shift - 1)) and r & 1):
-                r += 1
-            assert rec == r << shift
+            rec = sum(d[i] << (49 - bl * (i + 1)) for i in range(levels))
+            assert rec == ((c + (1 << (shift - 1))) >> shift) << shift          # floor(c / 2^shift + 1/2)
+            # digit by digit: r <- floor(r / B + 1/2)
+            r = (c + (1 << (shift - 1))) >> shift
+            for lev in range(levels - 1, 0, -1):
+                rn = (r + B // 2) >> bl
+                assert d[lev] == r - (rn << bl)
+                r = rn
+            assert d[0] == r
 
 
 @pytest.mark.parametrize("p", [1, 3, 4])
