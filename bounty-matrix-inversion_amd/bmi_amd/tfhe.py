@@ -75,6 +75,9 @@ _SIGS = {
     "bmi_set_kernel_variant": [C.c_void_p, C.c_int],
     "bmi_set_keyswitch_variant": [C.c_void_p, C.c_int],
     "bmi_set_bsk_precision": [C.c_void_p, C.c_uint32],
+    "bmi_set_bsk_unroll": [C.c_void_p, C.c_uint32],
+    "bmi_import_bsk_unrolled": [C.c_void_p, C.c_void_p],
+    "bmi_export_bsk_unrolled": [C.c_void_p, C.c_void_p],
     "bmi_circuit_prune": [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p],
     "bmi_circuit_schedule": [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                              C.POINTER(C.c_int32)],
@@ -401,6 +404,27 @@ class Engine:
     def set_bsk_precision(self, bits):
         """2^64 torus, before keygen: 64 = exact key (three limbs), 42 = key rounded to 42 bits (two limbs, 2/3 of the work)"""
         self._ck(self.lib.bmi_set_bsk_precision(self.h, int(bits)), "bmi_set_bsk_precision")
+
+    def set_bsk_unroll(self, factor):
+        """49-bit field, N = 1024: 1 = CGGI's blind rotation (default), 2 = two LWE coefficients per step with an unrolled
+        bootstrap key (generated by the next keygen, or at once from the secret keys already held); include/bmi_tfhe.h"""
+        self._ck(self.lib.bmi_set_bsk_unroll(self.h, int(factor)), "bmi_set_bsk_unroll")
+
+    def unrolled_key_shape(self):
+        P = self.P
+        return ((P.n + 1) // 2, 3, (P.k + 1) * P.bs_levels, P.k + 1, P.N)
+
+    def export_bsk_unrolled(self):
+        bsk3 = np.zeros(self.unrolled_key_shape(), np.uint64)
+        self._ck(self.lib.bmi_export_bsk_unrolled(self.h, _ptr(bsk3)), "bmi_export_bsk_unrolled")
+        return bsk3
+
+    def import_bsk_unrolled(self, bsk3):
+        """the unrolled bootstrap key of the key set this context holds (layout of export_bsk_unrolled)"""
+        bsk3 = np.ascontiguousarray(bsk3, dtype=np.uint64)
+        if bsk3.size != int(np.prod(self.unrolled_key_shape())):
+            raise BmiError("unrolled key array does not match this context's parameters")
+        self._ck(self.lib.bmi_import_bsk_unrolled(self.h, _ptr(bsk3)), "bmi_import_bsk_unrolled")
 
     def set_keyswitch_variant(self, v):
         """keyswitch: 0 auto (int8 matrix-core product), 1 scalar kernel"""

@@ -78,7 +78,7 @@ struct Stream {
         return f.from_i64(e);
     }
 };
-enum : u64 { S_SK_SMALL = 1, S_SK_BIG, S_BSK_MASK, S_BSK_NOISE, S_KSK_MASK, S_KSK_NOISE, S_ENC_MASK, S_ENC_NOISE };
+enum : u64 { S_SK_SMALL = 1, S_SK_BIG, S_BSK_MASK, S_BSK_NOISE, S_KSK_MASK, S_KSK_NOISE, S_ENC_MASK, S_ENC_NOISE, S_BSK3_MASK, S_BSK3_NOISE };
 
 // --------------------------------------------------------------------------- CSPRNG (production keys and encryptions)
 // ChaCha20 (D. J. Bernstein's original variant: 256-bit key, 64-bit nonce, 64-bit block counter) keyed from the
@@ -193,6 +193,14 @@ struct bmi_ctx {
     void *d_bsk = nullptr, *d_tw = nullptr, *d_luts = nullptr;  // u64 words (Goldilocks) or f64 words (49-bit field)
     double *d_tw_half = nullptr, *d_bsk_lat = nullptr;          // 49-bit field: tables and key copy of the split-transform latency kernel
     double *d_tw_wide = nullptr;                                // N = 2048: T / T^-1 of the even/odd combination (d_bsk_lat then holds the wide key copy)
+    // bootstrap-key unrolling (49-bit field, N = 1024; bmi_set_bsk_unroll): per pair of LWE coefficients the GGSW encryptions of
+    // s s', s (1 - s'), (1 - s) s'; host copy in the standard domain, device copy in the slot order of the latency kernel
+    uint32_t unroll = 1;
+    std::vector<u64> bsk3_std;
+    double *d_bsk3_lat = nullptr, *d_root_pow = nullptr;        // d_root_pow: psi^x, x in [0, 2N), centred doubles
+    bool have_bsk3 = false;
+    uint32_t pairs() const { return (P.n + 1) / 2; }
+    size_t bsk3_words() const { return (size_t)pairs() * 3 * rows * (P.k + 1) * N; }
     bool wide() const { return N == 2048; }
     bool quad() const { return N == 4096; }   // d_tw_wide then holds T_1..T_3 and their inverses, d_bsk_lat the quad key copy
     u64 *d_ksk = nullptr, *d_ks_bias = nullptr;
@@ -449,6 +457,15 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
         if (hipMemcpy(c->d_tw_half, th.data(), th.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(half-transform twiddles) failed");
     }
+    if (c->f64() && !c->wide() && !c->quad()) {   // psi^x for the unrolled blind rotation (X^c at the root psi^e is psi^(e c))
+        std::vector<u64> rp(2 * c->N);
+        rp[0] = 1;
+        for (uint32_t x = 1; x < 2 * c->N; x++) rp[x] = c->f.mul(rp[x - 1], nttf::PSI_U);
+        const std::vector<double> rpd = to_centred_doubles(rp);
+        if (hipMalloc(&c->d_root_pow, rpd.size() * 8) != hipSuccess) return bail("hipMalloc(root powers) failed");
+        if (hipMemcpy(c->d_root_pow, rpd.data(), rpd.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+            return bail("hipMemcpy(root powers) failed");
+    }
     if (c->wide() || c->quad()) {
         const std::vector<double> tw = to_centred_doubles(c->quad() ? build_twiddles_quad(c->f) : build_twiddles_wide(c->f));
         if (hipMalloc(&c->d_tw_wide, tw.size() * 8) != hipSuccess) return bail("hipMalloc(wide twiddles) failed");
@@ -467,7 +484,7 @@ void bmi_ctx_destroy(bmi_ctx *c) {
     for (void *p : {c->d_bsk, (void *)c->d_ksk, (void *)c->d_ks_bias, c->d_tw, c->d_luts, (void *)c->d_small,
                     (void *)c->d_io_a, (void *)c->d_io_b, (void *)c->d_io_ids, c->d_ks_partial,
                     (void *)c->d_ks_limbs, (void *)c->d_ks_digits, (void *)c->d_ks_sums, (void *)c->d_tw_half,
-                    (void *)c->d_bsk_lat, (void *)c->d_tw_wide})
+                    (void *)c->d_bsk_lat, (void *)c->d_tw_wide, (void *)c->d_bsk3_lat, (void *)c->d_root_pow})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -481,6 +498,7 @@ int bmi_get_params(const bmi_ctx *c, bmi_params *out) {
 
 namespace {
 int upload_eval_keys(bmi_ctx *c);
+int upload_bsk3(bmi_ctx *c);
 }
 
 namespace {
@@ -560,43 +578,60 @@ int bmi_field_to_torus64(uint32_t q_bits, const uint64_t *in, uint64_t words, ui
 }
 
 namespace {
+// GGSW encryptions (standard domain) of the bits msg[0..) under the GLWE key, rows numbered g * rows + comp * l + lev:
+// B = sum_j A_j * S_j + E by shifted adds (S binary); mask / noise streams as in oracle/tfhe_oracle.c ggsw_rows.
+void gen_ggsw_rows(bmi_ctx *c, uint64_t seed, u64 mask_stream, u64 noise_stream, const std::vector<u64> &msg, u64 *out) {
+    const bmi_params &P = c->P;
+    const uint32_t N = c->N, k = P.k, l = P.bs_levels, rows = c->rows;
+    const Stream sm_det(seed, mask_stream, c->f), se_det(seed, noise_stream, c->f);
+    const Stream *smp = &sm_det, *sep = &se_det;
+    const ChaKey *ksec = &c->rng_secret, *kpub = &c->rng_public;
+    const bool secure = c->secure_rng;
+    const Fq f = c->f;
+    const u64 *skb = c->sk_big.data();
+    const u64 *bits = msg.data();
+    const double sigma = P.glwe_noise;
+    const uint32_t bl = P.bs_base_log;
+    parallel_for(msg.size() * rows, [=](size_t ir) {
+        RowRng sm(smp, *kpub, mask_stream, ir, secure), se(sep, *ksec, noise_stream, ir, secure);
+        const uint32_t i = (uint32_t)(ir / rows), r = (uint32_t)(ir % rows), comp = r / l, lev = r % l;
+        u64 *row = out + ir * (k + 1) * N;
+        u64 *B = row + (size_t)k * N;
+        for (uint32_t x = 0; x < N; x++) B[x] = se.gauss((u64)ir * N + x, sigma);
+        for (uint32_t j = 0; j < k; j++) {
+            u64 *A = row + (size_t)j * N;
+            for (uint32_t x = 0; x < N; x++) A[x] = sm.uniform(((u64)ir * (k + 1) + j) * N + x);
+            for (uint32_t t = 0; t < N; t++)
+                if (skb[(size_t)j * N + t]) add_shifted(f, B, A, t, N);
+        }
+        if (bits[i]) row[(size_t)comp * N] = f.add(row[(size_t)comp * N], (u64)1 << (f.bits - bl * (lev + 1)));
+    });
+}
+
 // evaluation keys for the secret keys held in c->sk_small / c->sk_big, deterministic in `seed`
 int gen_eval_keys(bmi_ctx *c, uint64_t seed) {
     HIP_OK(c, hipSetDevice(c->device));
     const bmi_params &P = c->P;
-    const uint32_t n = P.n, N = c->N, k = P.k, l = P.bs_levels, lk = P.ks_levels, rows = c->rows;
+    const uint32_t n = P.n, N = c->N, k = P.k, lk = P.ks_levels, rows = c->rows;
     c->seed = seed;
     if (!c->secure_rng) c->enc_counter = 0;   // deterministic test keys: encryption i of a key set is reproducible
-    // --- bootstrap key: GGSW(s_i) rows, standard domain.  B = sum_j A_j * S_j + E by shifted adds (S binary).
+    // --- bootstrap key: GGSW(s_i) rows, standard domain
     c->bsk_std.assign((size_t)n * rows * (k + 1) * N, 0);
-    {
-        const Stream sm_det(seed, S_BSK_MASK, c->f), se_det(seed, S_BSK_NOISE, c->f);
-        const Stream *smp = &sm_det, *sep = &se_det;
-        const ChaKey *ksec = &c->rng_secret, *kpub = &c->rng_public;
-        const bool secure = c->secure_rng;
-        const Fq f = c->f;
-        const u64 *skb = c->sk_big.data();
-        const u64 *sks = c->sk_small.data();
-        u64 *bsk = c->bsk_std.data();
-        const double sigma = P.glwe_noise;
-        const uint32_t bl = P.bs_base_log;
-        // (A torus key at 42 bits of precision is ROUNDED from this full-precision key at upload.  Drawing the masks on the
-        // 2^22 grid instead would keep the rounding error away from the secret key - measured: output noise 2^-20 - but the
-        // body's noise, std 2^20, is then rounded to the grid too and vanishes in 95 % of the words: not an LWE sample any more.)
-        parallel_for((size_t)n * rows, [=](size_t ir) {
-            RowRng sm(smp, *kpub, S_BSK_MASK, ir, secure), se(sep, *ksec, S_BSK_NOISE, ir, secure);
-            const uint32_t i = (uint32_t)(ir / rows), r = (uint32_t)(ir % rows), comp = r / l, lev = r % l;
-            u64 *row = bsk + ir * (k + 1) * N;
-            u64 *B = row + (size_t)k * N;
-            for (uint32_t x = 0; x < N; x++) B[x] = se.gauss((u64)ir * N + x, sigma);
-            for (uint32_t j = 0; j < k; j++) {
-                u64 *A = row + (size_t)j * N;
-                for (uint32_t x = 0; x < N; x++) A[x] = sm.uniform(((u64)ir * (k + 1) + j) * N + x);
-                for (uint32_t t = 0; t < N; t++)
-                    if (skb[(size_t)j * N + t]) add_shifted(f, B, A, t, N);
-            }
-            if (sks[i]) row[(size_t)comp * N] = f.add(row[(size_t)comp * N], (u64)1 << (f.bits - bl * (lev + 1)));
-        });
+    // (A torus key at 42 bits of precision is ROUNDED from this full-precision key at upload.  Drawing the masks on the
+    // 2^22 grid instead would keep the rounding error away from the secret key - measured: output noise 2^-20 - but the
+    // body's noise, std 2^20, is then rounded to the grid too and vanishes in 95 % of the words: not an LWE sample any more.)
+    gen_ggsw_rows(c, seed, S_BSK_MASK, S_BSK_NOISE, c->sk_small, c->bsk_std.data());
+    c->have_bsk3 = false;
+    if (c->unroll == 2) {   // unrolled key: GGSW(s s'), GGSW(s (1 - s')), GGSW((1 - s) s') per pair; an odd n is completed by s_n = 0
+        std::vector<u64> msg((size_t)c->pairs() * 3);
+        for (uint32_t i = 0; i < c->pairs(); i++) {
+            const u64 s1 = c->sk_small[2 * i], s2 = 2 * i + 1 < n ? c->sk_small[2 * i + 1] : 0;
+            msg[3 * i] = s1 & s2;
+            msg[3 * i + 1] = s1 & (s2 ^ 1);
+            msg[3 * i + 2] = (s1 ^ 1) & s2;
+        }
+        c->bsk3_std.assign(c->bsk3_words(), 0);
+        gen_ggsw_rows(c, seed, S_BSK3_MASK, S_BSK3_NOISE, msg, c->bsk3_std.data());
     }
     // --- keyswitch key
     c->ksk.assign((size_t)k * N * lk * (n + 1), 0);
@@ -625,7 +660,28 @@ int gen_eval_keys(bmi_ctx *c, uint64_t seed) {
         });
     }
     c->have_secret = true;
-    return upload_eval_keys(c);
+    if (int rc = upload_eval_keys(c)) return rc;
+    return c->unroll == 2 ? upload_bsk3(c) : 0;
+}
+
+// unrolled bootstrap key (host copy in c->bsk3_std) -> device, in the slot order of the latency kernel
+int upload_bsk3(bmi_ctx *c) {
+    HIP_OK(c, hipSetDevice(c->device));
+    const size_t words = c->bsk3_words();
+    if (c->bsk3_std.size() != words) return fail(c, -1, "no unrolled bootstrap key to upload");
+    u64 *d_tmp = nullptr;
+    HIP_OK(c, hipMalloc(&d_tmp, words * 8));
+    if (!c->d_bsk3_lat && hipMalloc(&c->d_bsk3_lat, words * 8) != hipSuccess) {
+        (void)hipFree(d_tmp);
+        return fail(c, -2, "hipMalloc(unrolled key) failed");
+    }
+    HIP_OK(c, hipMemcpy(d_tmp, c->bsk3_std.data(), words * 8, hipMemcpyHostToDevice));
+    const int rc = bmi49::launch_bsk_to_lat(d_tmp, c->d_bsk3_lat, c->d_tw_half, (uint32_t)(words / c->N), c->stream);
+    if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat (unrolled key) launch failed"); }
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipFree(d_tmp));
+    c->have_bsk3 = true;
+    return 0;
 }
 
 // Evaluation keys (host copies in c->bsk_std / c->ksk) -> device: bootstrap key to the NTT domain (both layouts for
@@ -730,6 +786,7 @@ int bmi_import_keys(bmi_ctx *c, const uint64_t *sk_small, const uint64_t *sk_big
     for (size_t i = 0; i < ksk_words; i++)
         if (!c->f.canonical(ksk[i])) return fail(c, -1, "keyswitch key word not reduced mod q");
     c->have_keys = false;
+    c->have_bsk3 = false;   // an unrolled key belongs to the key set it was generated with: import it again (bmi_import_bsk_unrolled)
     c->bsk_std.assign(bsk, bsk + bsk_words);
     c->ksk.assign(ksk, ksk + ksk_words);
     c->have_secret = sk_small != nullptr;
@@ -870,6 +927,48 @@ int bmi_set_bsk_precision(bmi_ctx *c, uint32_t bits) {
     return 0;
 }
 
+int bmi_set_bsk_unroll(bmi_ctx *c, uint32_t factor) {
+    if (!c) return -1;
+    if (factor != 1 && factor != 2) return fail(c, -1, "the unrolling factor is 1 or 2");
+    if (factor == 2 && !(c->f64() && !c->wide() && !c->quad()))
+        return fail(c, -1, "bootstrap-key unrolling has a HIP kernel for the 49-bit field at N = 1024 only");
+    c->unroll = factor;
+    if (factor == 2 && c->have_keys && !c->have_bsk3) {
+        if (!c->have_secret) return 0;   // evaluation-only context: the key arrives through bmi_import_bsk_unrolled
+        // the unrolled key of the secret keys already held: fresh masks and noise (CSPRNG, or the seeded test streams)
+        std::vector<u64> msg((size_t)c->pairs() * 3);
+        for (uint32_t i = 0; i < c->pairs(); i++) {
+            const u64 s1 = c->sk_small[2 * i], s2 = 2 * i + 1 < c->P.n ? c->sk_small[2 * i + 1] : 0;
+            msg[3 * i] = s1 & s2;
+            msg[3 * i + 1] = s1 & (s2 ^ 1);
+            msg[3 * i + 2] = (s1 ^ 1) & s2;
+        }
+        c->bsk3_std.assign(c->bsk3_words(), 0);
+        gen_ggsw_rows(c, c->seed, S_BSK3_MASK, S_BSK3_NOISE, msg, c->bsk3_std.data());
+        return upload_bsk3(c);
+    }
+    return 0;
+}
+
+int bmi_import_bsk_unrolled(bmi_ctx *c, const uint64_t *bsk3) {
+    if (!c || !bsk3) return -1;
+    if (!(c->f64() && !c->wide() && !c->quad()))
+        return fail(c, -1, "bootstrap-key unrolling has a HIP kernel for the 49-bit field at N = 1024 only");
+    if (!c->have_keys) return fail(c, -1, "no keys: import or generate the key set first");
+    const size_t words = c->bsk3_words();
+    for (size_t i = 0; i < words; i++)
+        if (!c->f.canonical(bsk3[i])) return fail(c, -1, "unrolled bootstrap key word not reduced mod q");
+    c->bsk3_std.assign(bsk3, bsk3 + words);
+    return upload_bsk3(c);
+}
+
+int bmi_export_bsk_unrolled(const bmi_ctx *c, uint64_t *bsk3) {
+    if (!c || !bsk3) return -1;
+    if (!c->have_bsk3) return fail(c, -1, "no unrolled bootstrap key: bmi_set_bsk_unroll(ctx, 2) before keygen, or import one");
+    std::memcpy(bsk3, c->bsk3_std.data(), c->bsk3_std.size() * 8);
+    return 0;
+}
+
 int bmi_set_keyswitch_variant(bmi_ctx *c, int variant) {
     if (!c) return -1;
     if (variant < 0 || variant > 1) return fail(c, -1, "keyswitch variant must be 0 or 1");
@@ -998,6 +1097,13 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
         if (!lb3 && (c->variant == 1 || c->variant == 4))
             return fail(c, -1, "kernel variants 1 and 4 exist for (l, Bg) = (3, 2^15) only");
         const uint32_t lv = c->P.bs_levels, bl = c->P.bs_base_log;
+        if (c->unroll == 2) {   // unrolled key: one kernel (one workgroup per ciphertext) for every batch size, so that a
+                                // ciphertext's bits never depend on the batch it travelled in
+            if (!c->have_bsk3) return fail(c, -1, "unrolling selected but the context holds no unrolled key: generate keys after bmi_set_bsk_unroll, or bmi_import_bsk_unrolled");
+            rc = bmi49::launch_blind_rotate_lat2u(d_small, d_lut_ids, luts, c->d_bsk3_lat, c->d_tw_half, c->d_root_pow, d_out, count,
+                                                  c->P.n, lv, bl, st);
+            return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+        }
         if (c->variant == 4 || (latency && c->no_big_lds && lb3)) {
             rc = bmi49::launch_blind_rotate_lat(d_small, d_lut_ids, luts, bsk, tw, d_out, count, c->P.n, st);
         } else if (latency) {

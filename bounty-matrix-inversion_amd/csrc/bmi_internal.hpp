@@ -120,6 +120,11 @@ int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_t
 int launch_blind_rotate_lat2(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk_lat,
                              const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, uint32_t levels, uint32_t base_log,
                              hipStream_t s);
+// the same with the unrolled key (two LWE coefficients per step): bsk3_lat = [ceil(n/2)][3 keys] GGSW copies in the slot order
+// of launch_bsk_to_lat, g_root_pow = psi^x for x in [0, 2N) as centred doubles
+int launch_blind_rotate_lat2u(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk3_lat,
+                              const double *g_tw_h, const double *g_root_pow, u64 *out, uint32_t count, uint32_t n,
+                              uint32_t levels, uint32_t base_log, hipStream_t s);
 int launch_blind_rotate_tpx(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
                             const double *g_tw, u64 *out, uint32_t count, uint32_t n, uint32_t levels, uint32_t base_log,
                             hipStream_t s);

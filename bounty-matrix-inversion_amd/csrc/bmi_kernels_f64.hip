@@ -706,6 +706,150 @@ __global__ void __launch_bounds__(L2_THREADS)
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// LATENCY kernel with the UNROLLED bootstrap key (two LWE coefficients per step; oracle/tfhe_oracle.c
+// ora_blind_rotate_extract_unrolled):   ACC <- ACC + sum_{j<3} (X^(c_j) - 1) (K3[i][j] [.] ACC),  c = (a + a', a, a').
+// The structure of k_blind_rotate_lat2_49 with half the steps: phase A decomposes ACC itself (no rotation) and runs the
+// twelve forward half transforms ONCE per pair of coefficients; phase B multiplies the six digit transforms with the three
+// GGSW keys of the pair and scales each product by  psi^(e c_j) - 1,  the value of X^(c_j) - 1 at the slot's root psi^e
+// (e = 2 kk + 1 for A_lo, e + N for A_hi: a look-up in a 2N-entry table of root powers), so the rotation never touches the
+// coefficient domain; phase C is unchanged.  Per pair: 12 + 4 half transforms and 42 modular multiplications per thread,
+// against 24 + 8 and 24 of two plain steps.  The price is noise: the key-noise term of the output variance triples.
+constexpr int L2U_LDS_WORDS = L2_LDS_WORDS + 2 * N;
+static_assert(L2U_LDS_WORDS <= BMI_LDS_WORDS_MAX, "L2U_LDS_WORDS exceeds the 160 KB of LDS");
+
+template <int L = 3, int BG = 15>
+__global__ void __launch_bounds__(L2_THREADS)
+    k_blind_rotate_lat2u_49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
+                            const double *__restrict__ luts, const double *__restrict__ bsk3_lat,
+                            const double *__restrict__ g_tw_h, const double *__restrict__ g_root_pow,
+                            u64 *__restrict__ out, uint32_t count, uint32_t n) {
+    extern __shared__ double lds[];
+    double *acc = lds + ntth::HT_WORDS;              // [2 components][2 parities][512], centred (<= q/2 + 2)
+    double *tiles = acc + 2 * N;                     // [12][HSCRATCH]
+    double *SD = tiles + 12 * ntth::HSCRATCH;        // [2 outputs][sum, difference][512]
+    uint16_t *at = reinterpret_cast<uint16_t *>(SD + 2 * N);
+    double *RP = SD + 2 * N + BMI_AT_WORDS;          // psi^x, x in [0, 2N)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < ntth::HT_WORDS; i += L2_THREADS) lds[i] = g_tw_h[i];
+    for (int i = tid; i < 2 * N; i += L2_THREADS) RP[i] = g_root_pow[i];
+    const uint32_t ct = blockIdx.x;
+    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
+    for (uint32_t i = tid; i <= n; i += L2_THREADS) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 1);
+    __syncthreads();
+    {
+        const double *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
+        const uint32_t bt = at[n];
+        const uint32_t nn = tid;  // coefficient index
+        const uint32_t e = (nn + bt) & (2 * N - 1);
+        const double v = tv[e & (N - 1)];
+        acc[(nn & 1) * ntth::HALF + (nn >> 1)] = 0.0;
+        acc[N + (nn & 1) * ntth::HALF + (nn >> 1)] = (e & N) ? -v : v;
+    }
+    __syncthreads();
+    const int mo = tid >> 9, mp = tid & 511;  // phase B: output polynomial, slot
+    const uint32_t root_e = 2 * ntth::kk_of(mp & 63, mp >> 6) + 1;   // A_lo[mp] is the value at psi^root_e, A_hi[mp] at -psi^root_e
+    const uint32_t pairs = (n + 1) >> 1;
+
+    for (uint32_t ip = 0; ip < pairs; ip++) {
+        const uint32_t a1 = at[2 * ip], a2 = (2 * ip + 1 < n) ? at[2 * ip + 1] : 0u;
+        if ((a1 | a2) == 0) continue;  // uniform over the workgroup: every factor X^0 - 1 vanishes
+        const uint32_t cj[3] = {(a1 + a2) & (2 * N - 1), a1, a2};
+        const double *bi = bsk3_lat + (size_t)ip * 3 * 4 * L * N;   // [3 keys][2 L rows][2 outputs][A_lo 512, A_hi 512]
+        double b[2 * L][2];
+#pragma unroll
+        for (int r = 0; r < 2 * L; r++) {
+            b[r][0] = bi[(size_t)(r * 2 + mo) * N + mp];
+            b[r][1] = bi[(size_t)(r * 2 + mo) * N + ntth::HALF + mp];
+        }
+        if (wave < 4 * L) {
+            const int c = wave / (2 * L), lev = (wave % (2 * L)) >> 1, h = wave & 1;
+            const int pz = wave >> 1;
+            const double *ac = acc + c * N + h * ntth::HALF;
+            double x[8];
+#if BMI_LAT2_PRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
+            static_for<0, 8>([&](auto J) {
+                x[J] = Dec<L, BG>::digit(round_half_up(ac[lane + 64 * J], Dec<L, BG>::SC), lev);
+            });
+            double *tile = tiles + (2 * pz + h) * ntth::HSCRATCH;
+            if (h) ntth::forward_half<true>(x, lane, lds, tile);
+            else ntth::forward_half<false>(x, lane, lds, tile);
+            wave_sync();
+            static_for<0, 8>([&](auto R) { tile[R * 64 + lane] = x[R]; });
+#if BMI_LAT2_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+        }
+        __syncthreads();
+        {
+            double alo[2 * L], ahi[2 * L];
+#pragma unroll
+            for (int r = 0; r < 2 * L; r++) {
+                const double e = tiles[(2 * r) * ntth::HSCRATCH + mp], od = tiles[(2 * r + 1) * ntth::HSCRATCH + mp];
+                alo[r] = e + od;
+                ahi[r] = e - od;
+            }
+            double slo = 0.0, shi = 0.0;   // sums of three reduced products (<= 1.6 q)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                double bn[2 * L][2];
+                if (j < 2) {   // the next key's words are requested while this one is multiplied
+                    const double *bj = bi + (size_t)(j + 1) * 4 * L * N;
+#pragma unroll
+                    for (int r = 0; r < 2 * L; r++) {
+                        bn[r][0] = bj[(size_t)(r * 2 + mo) * N + mp];
+                        bn[r][1] = bj[(size_t)(r * 2 + mo) * N + ntth::HALF + mp];
+                    }
+                }
+                double ylo = 0.0, yhi = 0.0;  // lazy sums of 2 L <= six products (<= 10.2 q)
+#pragma unroll
+                for (int r = 0; r < 2 * L; r++) {
+                    ylo += f49::mul(alo[r], b[r][0]);
+                    yhi += f49::mul(ahi[r], b[r][1]);
+                }
+                const double w = RP[(root_e * cj[j]) & (2 * N - 1)];        // psi^(e c_j); at the root -psi^e: (-1)^c_j times it
+                const double wh = (cj[j] & 1) ? -w : w;
+                slo += f49::mul(f49::red(ylo), w - 1.0);
+                shi += f49::mul(f49::red(yhi), wh - 1.0);
+                if (j < 2) {
+#pragma unroll
+                    for (int r = 0; r < 2 * L; r++) { b[r][0] = bn[r][0]; b[r][1] = bn[r][1]; }
+                }
+            }
+            slo = f49::red(slo);
+            shi = f49::red(shi);
+            SD[(mo * 2 + 0) * ntth::HALF + mp] = slo + shi;
+            SD[(mo * 2 + 1) * ntth::HALF + mp] = slo - shi;
+        }
+        __syncthreads();
+        if (wave < 4) {
+            const int o = wave >> 1, h = wave & 1;
+            double x[8];
+            static_for<0, 8>([&](auto R) { x[R] = SD[(o * 2 + h) * ntth::HALF + R * 64 + lane]; });
+            double *tile = tiles + wave * ntth::HSCRATCH;
+            if (h) ntth::inverse_half<true>(x, lane, lds, tile);
+            else ntth::inverse_half<false>(x, lane, lds, tile);
+            double *ao = acc + o * N + h * ntth::HALF;
+            static_for<0, 8>([&](auto J) { ao[lane + 64 * J] = f49::red(ao[lane + 64 * J] + x[J]); });
+        }
+        __syncthreads();
+    }
+    u64 *o = out + (size_t)ct * (N + 1);
+    {
+        const uint32_t nn = tid;
+        const double a0 = acc[(nn & 1) * ntth::HALF + (nn >> 1)];
+        if (nn == 0) {
+            o[0] = f49::to_u(a0);
+            o[N] = f49::to_u(acc[N]);
+        } else {
+            o[N - nn] = f49::to_u(-a0);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
 // Second parameter set, N = 2048 (k = 1, l = 3): a 2048-point negacyclic transform is two 1024-point wave transforms
 // (nttf::forward / inverse on the even and the odd coefficients, root psi_4096^2 = the 2048th root they are built on)
 // combined exactly like the two halves of ntt_half_f64.hpp:  A[kk] = E[kk] + T[kk] O[kk],  A[kk + 1024] = E - T O,
@@ -1321,6 +1465,30 @@ int launch_blind_rotate_lat2(const u64 *small_cts, const uint32_t *lut_ids, cons
     if (count == 0) return 0;
     launch9_t f = pick_lat2(levels, base_log);
     return f ? f(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s) : (int)hipErrorInvalidValue;
+}
+
+template <int L, int BG>
+struct LaunchLat2u {
+    static int go(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk3_lat, const double *g_tw_h,
+                  const double *g_root_pow, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+        static std::atomic<uint64_t> configured{0};
+        const size_t lds = (size_t)L2U_LDS_WORDS * sizeof(double);
+        auto kern = k_blind_rotate_lat2u_49<L, BG>;
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
+        hipLaunchKernelGGL(kern, dim3(count), dim3(L2_THREADS), lds, s, small_cts, lut_ids, luts, bsk3_lat, g_tw_h, g_root_pow, out,
+                           count, n);
+        BMI49_LAUNCH_CHECK();
+        return 0;
+    }
+};
+static launch10_t pick_lat2u(uint32_t levels, uint32_t base_log) { BMI49_FOR_LB(levels, base_log, LaunchLat2u); }
+
+int launch_blind_rotate_lat2u(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk3_lat,
+                              const double *g_tw_h, const double *g_root_pow, u64 *out, uint32_t count, uint32_t n,
+                              uint32_t levels, uint32_t base_log, hipStream_t s) {
+    if (count == 0) return 0;
+    launch10_t f = pick_lat2u(levels, base_log);
+    return f ? f(small_cts, lut_ids, luts, bsk3_lat, g_tw_h, g_root_pow, out, count, n, s) : (int)hipErrorInvalidValue;
 }
 
 int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,

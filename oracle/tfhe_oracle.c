@@ -356,7 +356,7 @@ static void ggsw_rows(const ora_params *P, u64 km, u64 ke, const u64 *sk_big, co
 
 void ora_keygen(const ora_params *P, u64 seed, u64 *sk_small, u64 *sk_big, u64 *bsk, u64 *ksk) {
     ora_set_field(P->q_bits);
-    uint32_t n = P->n, N = 1u << P->log_N, k = P->k, l = P->bs_levels, lk = P->ks_levels;
+    uint32_t n = P->n, N = 1u << P->log_N, k = P->k, lk = P->ks_levels;
     u64 k1 = stream_key(seed, ST_SK_SMALL), k2 = stream_key(seed, ST_SK_BIG);
     for (uint32_t i = 0; i < n; i++) sk_small[i] = rnd_u64(k1, i) & 1;
     for (uint32_t i = 0; i < k * N; i++) sk_big[i] = rnd_u64(k2, i) & 1;
@@ -447,35 +447,45 @@ typedef struct {
     ora_params P;
     ntt_tab *t;
     u64 *bsk_ntt; /* [n][(k+1)l][(k+1)][N] forward-NTT of every GGSW row polynomial */
+    u64 *bsk3_ntt; /* unrolled key (ora_ctx_set_bsk_unrolled), same per-polynomial form, or NULL */
     const u64 *ksk;
 } ora_ctx;
 
+/* transform-domain copy of `polys` key polynomials (what the external product multiplies with) */
+static u64 *key_to_ntt(const ora_ctx *c, const u64 *key, size_t polys) {
+    uint32_t N = 1u << c->P.log_N;
+    u64 *out;
+    if (TORUS) {
+        /* torus: Goldilocks transforms of the low and the high 32-bit half of every key polynomial: [poly][2][N] */
+        out = (u64 *)malloc(polys * 2 * N * 8);
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < polys; i++) {
+            u64 *lo = out + i * 2 * N, *hi = lo + N;
+            for (uint32_t x = 0; x < N; x++) { lo[x] = key[i * N + x] & 0xFFFFFFFFull; hi[x] = key[i * N + x] >> 32; }
+            g_ntt_fwd(c->t, lo); g_ntt_fwd(c->t, hi);
+        }
+        return out;
+    }
+    out = (u64 *)malloc(polys * N * 8);
+    memcpy(out, key, polys * N * 8);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < polys; i++) ntt_fwd(c->t, out + i * N);
+    return out;
+}
 ora_ctx *ora_ctx_create(const ora_params *P, const u64 *bsk, const u64 *ksk) {
     ora_set_field(P->q_bits);
     ora_ctx *c = (ora_ctx *)malloc(sizeof *c);
-    c->P = *P; c->ksk = ksk;
-    uint32_t N = 1u << P->log_N;
-    size_t polys = (size_t)P->n * (P->k + 1) * P->bs_levels * (P->k + 1);
-    if (TORUS) {
-        /* torus: Goldilocks transforms of the low and the high 32-bit half of every key polynomial: [poly][2][N] */
-        c->t = g_ntt_make(P->log_N);
-        c->bsk_ntt = (u64 *)malloc(polys * 2 * N * 8);
-#pragma omp parallel for schedule(static)
-        for (size_t i = 0; i < polys; i++) {
-            u64 *lo = c->bsk_ntt + i * 2 * N, *hi = lo + N;
-            for (uint32_t x = 0; x < N; x++) { lo[x] = bsk[i * N + x] & 0xFFFFFFFFull; hi[x] = bsk[i * N + x] >> 32; }
-            g_ntt_fwd(c->t, lo); g_ntt_fwd(c->t, hi);
-        }
-        return c;
-    }
-    c->t = ntt_make(P->log_N);
-    c->bsk_ntt = (u64 *)malloc(polys * N * 8);
-    memcpy(c->bsk_ntt, bsk, polys * N * 8);
-#pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < polys; i++) ntt_fwd(c->t, c->bsk_ntt + i * N);
+    c->P = *P; c->ksk = ksk; c->bsk3_ntt = NULL;
+    c->t = TORUS ? g_ntt_make(P->log_N) : ntt_make(P->log_N);
+    c->bsk_ntt = key_to_ntt(c, bsk, (size_t)P->n * (P->k + 1) * P->bs_levels * (P->k + 1));
     return c;
 }
-void ora_ctx_destroy(ora_ctx *c) { ntt_free(c->t); free(c->bsk_ntt); free(c); }
+/* attaches the unrolled bootstrap key bsk3[ceil(n/2)][3][(k+1)l][(k+1)][N] (ora_keygen_bsk_unrolled or an exported one) */
+void ora_ctx_set_bsk_unrolled(ora_ctx *c, const u64 *bsk3) {
+    free(c->bsk3_ntt);
+    c->bsk3_ntt = key_to_ntt(c, bsk3, (size_t)((c->P.n + 1) / 2) * 3 * (c->P.k + 1) * c->P.bs_levels * (c->P.k + 1));
+}
+void ora_ctx_destroy(ora_ctx *c) { ntt_free(c->t); free(c->bsk_ntt); free(c->bsk3_ntt); free(c); }
 
 /* big-key LWE (k*N+1 words) -> small-key LWE (n+1 words) */
 void ora_keyswitch(const ora_ctx *c, const u64 *in, u64 *out) {
@@ -502,6 +512,47 @@ void ora_keyswitch(const ora_ctx *c, const u64 *in, u64 *out) {
     free(acc);
 }
 
+/* res[(k+1)][N] = sum over the (k+1) l rows of dec[row] * G[row][.]  (negacyclic, exact mod q): the external product of
+ * one GGSW ciphertext (transform-domain polynomials at g) with the digit polynomials dec (field elements / two's
+ * complement words; overwritten by their transforms). */
+static void external_product(const ora_ctx *c, const u64 *g, u64 *dec, u64 *res) {
+    const ora_params *P = &c->P;
+    uint32_t N = 1u << P->log_N, k = P->k, rows = (k + 1) * P->bs_levels;
+    if (TORUS) {
+        /* exact product mod 2^64: digits (|d| <= 2^(Bg-1)) as Goldilocks elements against both key halves; every
+         * half-sum is an integer below rows * N * 2^(Bg-1) * 2^32 < q/2, so its centred residue is the integer */
+        u64 *res_hi = (u64 *)calloc((size_t)(k + 1) * N, 8);
+        for (uint32_t r = 0; r < rows; r++) {
+            u64 *d = dec + (size_t)r * N;
+            for (uint32_t x = 0; x < N; x++) d[x] = g_from_i64((i64)d[x]);
+            g_ntt_fwd(c->t, d);
+        }
+        memset(res, 0, (size_t)(k + 1) * N * 8);
+        for (uint32_t r = 0; r < rows; r++)
+            for (uint32_t oc = 0; oc <= k; oc++) {
+                const u64 *blo = g + ((size_t)r * (k + 1) + oc) * 2 * N, *bhi = blo + N, *d = dec + (size_t)r * N;
+                u64 *o = res + (size_t)oc * N, *oh = res_hi + (size_t)oc * N;
+                for (uint32_t x = 0; x < N; x++) { o[x] = g_add(o[x], g_mul(d[x], blo[x])); oh[x] = g_add(oh[x], g_mul(d[x], bhi[x])); }
+            }
+        for (uint32_t oc = 0; oc <= k; oc++) {
+            g_ntt_inv(c->t, res + (size_t)oc * N); g_ntt_inv(c->t, res_hi + (size_t)oc * N);
+            u64 *o = res + (size_t)oc * N, *oh = res_hi + (size_t)oc * N;
+            for (uint32_t x = 0; x < N; x++) o[x] = (u64)g_centered(o[x]) + ((u64)g_centered(oh[x]) << 32);
+        }
+        free(res_hi);
+        return;
+    }
+    for (uint32_t r = 0; r < rows; r++) ntt_fwd(c->t, dec + (size_t)r * N);
+    memset(res, 0, (size_t)(k + 1) * N * 8);
+    for (uint32_t r = 0; r < rows; r++)
+        for (uint32_t oc = 0; oc <= k; oc++) {
+            const u64 *b = g + ((size_t)r * (k + 1) + oc) * N, *d = dec + (size_t)r * N;
+            u64 *o = res + (size_t)oc * N;
+            for (uint32_t x = 0; x < N; x++) o[x] = addq(o[x], mulq(d[x], b[x]));
+        }
+    for (uint32_t oc = 0; oc <= k; oc++) ntt_inv(c->t, res + (size_t)oc * N);
+}
+
 /* small-key LWE -> big-key LWE of tv[phase]: modulus switch, blind rotation, sample extraction.
  * tv has N coefficients (body polynomial; mask polynomials start at zero). */
 void ora_blind_rotate_extract(const ora_ctx *c, const u64 *lwe, const u64 *tv, u64 *out) {
@@ -526,45 +577,8 @@ void ora_blind_rotate_extract(const ora_ctx *c, const u64 *lwe, const u64 *tv, u
                 for (uint32_t lev = 0; lev < l; lev++) dec[((size_t)comp * l + lev) * N + x] = from_i64(dig[lev]);
             }
         }
-        if (TORUS) {
-            /* exact product mod 2^64: digits (|d| <= 2^(Bg-1)) as Goldilocks elements against both key halves; every
-             * half-sum is an integer below rows * N * 2^(Bg-1) * 2^32 < q/2, so its centred residue is the integer */
-            u64 *res_hi = (u64 *)calloc((size_t)(k + 1) * N, 8);
-            for (uint32_t r = 0; r < rows; r++) {
-                u64 *d = dec + (size_t)r * N;
-                for (uint32_t x = 0; x < N; x++) d[x] = g_from_i64((i64)d[x]);
-                g_ntt_fwd(c->t, d);
-            }
-            memset(res, 0, (size_t)(k + 1) * N * 8);
-            const u64 *g = c->bsk_ntt + (size_t)i * rows * (k + 1) * 2 * N;
-            for (uint32_t r = 0; r < rows; r++)
-                for (uint32_t oc = 0; oc <= k; oc++) {
-                    const u64 *blo = g + ((size_t)r * (k + 1) + oc) * 2 * N, *bhi = blo + N, *d = dec + (size_t)r * N;
-                    u64 *o = res + (size_t)oc * N, *oh = res_hi + (size_t)oc * N;
-                    for (uint32_t x = 0; x < N; x++) { o[x] = g_add(o[x], g_mul(d[x], blo[x])); oh[x] = g_add(oh[x], g_mul(d[x], bhi[x])); }
-                }
-            for (uint32_t oc = 0; oc <= k; oc++) {
-                g_ntt_inv(c->t, res + (size_t)oc * N); g_ntt_inv(c->t, res_hi + (size_t)oc * N);
-                u64 *a = acc + (size_t)oc * N, *o = res + (size_t)oc * N, *oh = res_hi + (size_t)oc * N;
-                for (uint32_t x = 0; x < N; x++) a[x] += (u64)g_centered(o[x]) + ((u64)g_centered(oh[x]) << 32);
-            }
-            free(res_hi);
-            continue;
-        }
-        for (uint32_t r = 0; r < rows; r++) ntt_fwd(c->t, dec + (size_t)r * N);
-        memset(res, 0, (size_t)(k + 1) * N * 8);
-        const u64 *g = c->bsk_ntt + (size_t)i * rows * (k + 1) * N;
-        for (uint32_t r = 0; r < rows; r++)
-            for (uint32_t oc = 0; oc <= k; oc++) {
-                const u64 *b = g + ((size_t)r * (k + 1) + oc) * N, *d = dec + (size_t)r * N;
-                u64 *o = res + (size_t)oc * N;
-                for (uint32_t x = 0; x < N; x++) o[x] = addq(o[x], mulq(d[x], b[x]));
-            }
-        for (uint32_t oc = 0; oc <= k; oc++) {
-            ntt_inv(c->t, res + (size_t)oc * N);
-            u64 *a = acc + (size_t)oc * N, *o = res + (size_t)oc * N;
-            for (uint32_t x = 0; x < N; x++) a[x] = addq(a[x], o[x]);
-        }
+        external_product(c, c->bsk_ntt + (size_t)i * rows * (k + 1) * N * (TORUS ? 2 : 1), dec, res);
+        for (uint32_t x = 0; x < (k + 1) * N; x++) acc[x] = addq(acc[x], res[x]);
     }
     /* sample extraction of coefficient 0 */
     for (uint32_t j = 0; j < k; j++) {
@@ -574,6 +588,50 @@ void ora_blind_rotate_extract(const ora_ctx *c, const u64 *lwe, const u64 *tv, u
     }
     out[(size_t)k * N] = acc[(size_t)k * N];
     free(acc); free(diff); free(dec); free(res);
+}
+
+/* The same with the UNROLLED key (ora_ctx_set_bsk_unrolled): step i absorbs the LWE coefficients (a, a') = (a_2i, a_2i+1)
+ *   ACC <- ACC + sum_{j<3} (X^(c_j) - 1) * (K3[i][j] [.] ACC),    c = (a + a' mod 2N, a, a'),
+ * with ONE decomposition of ACC itself per step (the rotation acts on the products, here in the coefficient domain).
+ * Returns -1 when no unrolled key is attached. */
+int ora_blind_rotate_extract_unrolled(const ora_ctx *c, const u64 *lwe, const u64 *tv, u64 *out) {
+    const ora_params *P = &c->P;
+    uint32_t n = P->n, N = 1u << P->log_N, k = P->k, l = P->bs_levels, rows = (k + 1) * l, log2N = P->log_N + 1;
+    if (!c->bsk3_ntt) return -1;
+    u64 *acc = (u64 *)calloc((size_t)(k + 1) * N, 8);
+    u64 *dec0 = (u64 *)malloc((size_t)rows * N * 8), *dec = (u64 *)malloc((size_t)rows * N * 8);
+    u64 *res = (u64 *)malloc((size_t)(k + 1) * N * 8), *rot = (u64 *)malloc(N * 8);
+    i64 dig[64];
+    uint32_t bt = ora_modswitch(lwe[n], log2N);
+    poly_rot(N, tv, (2 * N - bt) & (2 * N - 1), acc + (size_t)k * N);
+    for (uint32_t i = 0; i < (n + 1) / 2; i++) {
+        uint32_t a1 = ora_modswitch(lwe[2 * i], log2N), a2 = 2 * i + 1 < n ? ora_modswitch(lwe[2 * i + 1], log2N) : 0;
+        uint32_t cj[3] = {(a1 + a2) & (2 * N - 1), a1, a2};
+        if ((a1 | a2) == 0) continue; /* every factor X^0 - 1 vanishes */
+        for (uint32_t comp = 0; comp <= k; comp++)
+            for (uint32_t x = 0; x < N; x++) {
+                ora_decompose(acc[(size_t)comp * N + x], l, P->bs_base_log, dig);
+                for (uint32_t lev = 0; lev < l; lev++) dec0[((size_t)comp * l + lev) * N + x] = from_i64(dig[lev]);
+            }
+        for (uint32_t j = 0; j < 3; j++) {
+            if (cj[j] == 0) continue;
+            memcpy(dec, dec0, (size_t)rows * N * 8);   /* external_product overwrites its digit operand */
+            external_product(c, c->bsk3_ntt + ((size_t)i * 3 + j) * rows * (k + 1) * N * (TORUS ? 2 : 1), dec, res);
+            for (uint32_t oc = 0; oc <= k; oc++) {
+                u64 *a = acc + (size_t)oc * N, *r = res + (size_t)oc * N;
+                poly_rot(N, r, cj[j], rot);
+                for (uint32_t x = 0; x < N; x++) a[x] = addq(a[x], subq(rot[x], r[x]));
+            }
+        }
+    }
+    for (uint32_t j = 0; j < k; j++) {
+        const u64 *A = acc + (size_t)j * N;
+        out[(size_t)j * N] = A[0];
+        for (uint32_t x = 1; x < N; x++) out[(size_t)j * N + x] = negq(A[N - x]);
+    }
+    out[(size_t)k * N] = acc[(size_t)k * N];
+    free(acc); free(dec0); free(dec); free(res); free(rot);
+    return 0;
 }
 
 /* Concrete-order PBS on a batch: keyswitch -> blind rotate -> extract.
@@ -600,6 +658,29 @@ void ora_blind_rotate_batch(const ora_ctx *c, const u64 *in, const u64 *tvs, con
 #pragma omp parallel for schedule(dynamic, 1)
     for (uint32_t i = 0; i < count; i++)
         ora_blind_rotate_extract(c, in + (size_t)i * (n + 1), tvs + (size_t)tv_ids[i] * N, out + (size_t)i * big);
+}
+
+/* unrolled-key twins of the two batch entry points above */
+int ora_pbs_batch_unrolled(const ora_ctx *c, const u64 *in, const u64 *tvs, const uint32_t *tv_ids, uint32_t count, u64 *out, u64 *ks_out) {
+    uint32_t n = c->P.n, N = 1u << c->P.log_N, big = c->P.k * N + 1;
+    if (!c->bsk3_ntt) return -1;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (uint32_t i = 0; i < count; i++) {
+        u64 *small = (u64 *)malloc((n + 1) * 8);
+        ora_keyswitch(c, in + (size_t)i * big, small);
+        if (ks_out) memcpy(ks_out + (size_t)i * (n + 1), small, (n + 1) * 8);
+        ora_blind_rotate_extract_unrolled(c, small, tvs + (size_t)tv_ids[i] * N, out + (size_t)i * big);
+        free(small);
+    }
+    return 0;
+}
+int ora_blind_rotate_batch_unrolled(const ora_ctx *c, const u64 *in, const u64 *tvs, const uint32_t *tv_ids, uint32_t count, u64 *out) {
+    uint32_t n = c->P.n, N = 1u << c->P.log_N, big = c->P.k * N + 1;
+    if (!c->bsk3_ntt) return -1;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (uint32_t i = 0; i < count; i++)
+        ora_blind_rotate_extract_unrolled(c, in + (size_t)i * (n + 1), tvs + (size_t)tv_ids[i] * N, out + (size_t)i * big);
+    return 0;
 }
 
 /* out[i] = const_i + sum_j coef[j] * in[idx[j]]  over CSR rows (leveled linear ops) */

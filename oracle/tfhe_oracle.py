@@ -109,6 +109,18 @@ def keygen(P, seed):
     return Keys(P, sk_small, sk_big, bsk, ksk)
 
 
+def unrolled_key_shape(P):
+    return ((P.n + 1) // 2, 3, (P.k + 1) * P.bs_levels, P.k + 1, P.N)
+
+
+def keygen_bsk_unrolled(P, seed, sk_small, sk_big):
+    """unrolled bootstrap key (two LWE coefficients per blind-rotation step): per pair (s, s') the three GGSW
+    encryptions of s s', s (1 - s'), (1 - s) s'"""
+    bsk3 = np.zeros(unrolled_key_shape(P), np.uint64)
+    lib().ora_keygen_bsk_unrolled(C.byref(P), C.c_uint64(seed), _p(u64(sk_small)), _p(u64(sk_big)), _p(bsk3))
+    return bsk3
+
+
 def torus_negacyclic(logN, d, b, schoolbook=False, bound_log=14):
     """d * b mod (X^N + 1, 2^64); d small signed (decomposition digits).  schoolbook=True: wrap-around definition;
     otherwise the Goldilocks half-transform route the torus blind rotation uses."""
@@ -199,28 +211,37 @@ class Ctx:
         except Exception:
             pass
 
+    def set_bsk_unrolled(self, bsk3):
+        """attaches an unrolled bootstrap key; `unrolled=True` below then runs the two-coefficients-per-step blind rotation"""
+        bsk3 = u64(bsk3)
+        assert bsk3.size == int(np.prod(unrolled_key_shape(self.P)))
+        lib().ora_ctx_set_bsk_unrolled(self.h, _p(bsk3))
+
     def keyswitch(self, cts):
         cts = u64(cts).reshape(-1, self.P.big)
         out = np.zeros((cts.shape[0], self.P.n + 1), np.uint64)
         lib().ora_keyswitch_batch(self.h, _p(cts), C.c_uint32(cts.shape[0]), _p(out))
         return out
 
-    def blind_rotate(self, small, tvs, tv_ids):
+    def blind_rotate(self, small, tvs, tv_ids, unrolled=False):
         small = u64(small).reshape(-1, self.P.n + 1)
         tvs = u64(tvs).reshape(-1, self.P.N)
         ids = np.ascontiguousarray(tv_ids, dtype=np.uint32)
         out = np.zeros((small.shape[0], self.P.big), np.uint64)
-        lib().ora_blind_rotate_batch(self.h, _p(small), _p(tvs), _p(ids), C.c_uint32(small.shape[0]), _p(out))
+        f = lib().ora_blind_rotate_batch_unrolled if unrolled else lib().ora_blind_rotate_batch
+        if f(self.h, _p(small), _p(tvs), _p(ids), C.c_uint32(small.shape[0]), _p(out)) and unrolled:
+            raise ValueError("no unrolled bootstrap key attached")
         return out
 
-    def pbs(self, cts, tvs, tv_ids, want_ks=False):
+    def pbs(self, cts, tvs, tv_ids, want_ks=False, unrolled=False):
         cts = u64(cts).reshape(-1, self.P.big)
         tvs = u64(tvs).reshape(-1, self.P.N)
         ids = np.ascontiguousarray(tv_ids, dtype=np.uint32)
         out = np.zeros_like(cts)
         ks = np.zeros((cts.shape[0], self.P.n + 1), np.uint64) if want_ks else None
-        lib().ora_pbs_batch(self.h, _p(cts), _p(tvs), _p(ids), C.c_uint32(cts.shape[0]), _p(out),
-                            _p(ks) if want_ks else None)
+        f = lib().ora_pbs_batch_unrolled if unrolled else lib().ora_pbs_batch
+        if f(self.h, _p(cts), _p(tvs), _p(ids), C.c_uint32(cts.shape[0]), _p(out), _p(ks) if want_ks else None) and unrolled:
+            raise ValueError("no unrolled bootstrap key attached")
         return (out, ks) if want_ks else out
 
 

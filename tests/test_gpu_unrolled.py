@@ -1,0 +1,183 @@
+"""GPU parity tests of the UNROLLED blind rotation (bmi_set_bsk_unroll(ctx, 2); k_blind_rotate_lat2u_49): two LWE
+coefficients per step.  Bit for bit against oracle/tfhe_oracle.c ora_blind_rotate_extract_unrolled on the same keys (seeded
+key generation reproduces the oracle's keys word for word; CSPRNG keys are exported), output noise on the formula."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED
+
+
+def _engine(seed=SEED, **kw):
+    from bmi_amd import tfhe
+    e = tfhe.Engine(tfhe.default_params(q_bits=49, **kw))
+    e.set_bsk_unroll(2)
+    e.keygen(seed)
+    return e
+
+
+def _oracle(eng, bsk3=None):
+    from oracle import tfhe_oracle as to
+    to.set_field(49)
+    sk_small, sk_big, bsk, ksk = eng.export_keys()
+    P = to.default_params(q_bits=49, n=eng.P.n, bs_levels=eng.P.bs_levels, bs_base_log=eng.P.bs_base_log)
+    ctx = to.Ctx(P, bsk, ksk)
+    ctx.set_bsk_unrolled(eng.export_bsk_unrolled() if bsk3 is None else bsk3)
+    return to, P, ctx, sk_small, sk_big
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = _engine()
+    yield e
+    e.close()
+
+
+def test_seeded_unrolled_keygen_matches_the_oracle_keygen(eng):
+    from oracle import tfhe_oracle as to
+    to.set_field(49)
+    P = to.default_params(q_bits=49)
+    K = to.keygen(P, SEED)
+    sk_small, sk_big, bsk, _ = eng.export_keys()
+    assert np.array_equal(K.sk_small, sk_small) and np.array_equal(K.bsk, bsk)
+    assert np.array_equal(to.keygen_bsk_unrolled(P, SEED, K.sk_small, K.sk_big), eng.export_bsk_unrolled())
+
+
+@pytest.mark.parametrize("count", [1, 5, 300, 700])
+def test_unrolled_pbs_bit_exact_every_batch_size(eng, count):
+    """one kernel for every batch size: the ciphertext bits do not depend on the batch a ciphertext travelled in"""
+    to, P, ctx, sk_small, sk_big = _oracle(eng)
+    rng = np.random.default_rng(count)
+    dl = eng.delta_log()
+    tables = [np.arange(-8, 8), rng.integers(-8, 8, 16)]
+    lids = [eng.lut_register(t, 4, dl) for t in tables]
+    tvs = np.stack([eng.lut_get(l) for l in lids])
+    msgs = rng.integers(-8, 8, count)
+    sel = rng.integers(0, 2, count).astype(np.uint32)
+    ct = eng.encrypt(msgs, dl)
+    got = eng.pbs_host(ct, np.array(lids, np.uint32)[sel])
+    assert list(eng.decrypt(got, dl)) == [int(tables[s][m + 8]) for s, m in zip(sel, msgs)]
+    pick = np.arange(count) if count <= 8 else np.unique(np.concatenate([[0, count - 1, 255, 256, 511, 512][:6], rng.integers(0, count, 10)]) % count)
+    want = ctx.pbs(ct[pick], tvs, sel[pick], unrolled=True)
+    assert np.array_equal(got[pick], want)
+    ctx.close()
+
+
+def test_unrolled_blind_rotation_extreme_inputs(eng):
+    """arbitrary small-key words (zeros, maxima, the pair sums that wrap 2N) straight into the blind rotation"""
+    to, P, ctx, sk_small, sk_big = _oracle(eng)
+    Q = eng.modulus
+    rng = np.random.default_rng(11)
+    small = rng.integers(0, Q, (12, P.n + 1), dtype=np.uint64)
+    small[0] = 0                                # every exponent zero: the accumulator is the test polynomial
+    small[1] = np.uint64(Q - 1)
+    small[2] = np.uint64(Q // 2)                # every a = N: the pair sums wrap to 0
+    small[3, ::2] = 0                           # first coefficient of every pair zero
+    small[4, 1::2] = 0
+    small[5, :-1] = np.uint64((Q + 2047) // 2048)   # a = 1 everywhere
+    lid = eng.lut_register(rng.integers(-8, 8, 16), 4, eng.delta_log())
+    ids = np.full(12, lid, np.uint32)
+    got = eng.blind_rotate_host(small, ids)
+    want = ctx.blind_rotate(small, eng.lut_get(lid)[None, :], np.zeros(12, np.uint32), unrolled=True)
+    assert np.array_equal(got, want)
+    ctx.close()
+
+
+@pytest.mark.parametrize("kw", [dict(n=629), dict(n=1024), dict(bs_levels=2), dict(bs_levels=1, bs_base_log=23), dict(n=1)],
+                         ids=["odd_n", "n1024", "l2", "l1", "n1"])
+def test_unrolled_other_shapes_bit_exact(kw):
+    e = _engine(seed=77, **kw)
+    try:
+        to, P, ctx, sk_small, sk_big = _oracle(e)
+        rng = np.random.default_rng(3)
+        dl = e.delta_log()
+        table = rng.integers(-8, 8, 16)
+        lid = e.lut_register(table, 4, dl)
+        msgs = rng.integers(-8, 8, 6)
+        ct = e.encrypt(msgs, dl)
+        got = e.pbs_host(ct, np.full(6, lid, np.uint32))
+        if kw.get("n") != 1:      # (one coefficient cannot hold a message's phase; the bits are still compared)
+            assert list(e.decrypt(got, dl)) == [int(table[m + 8]) for m in msgs]
+        assert np.array_equal(got, ctx.pbs(ct, e.lut_get(lid)[None, :], np.zeros(6, np.uint32), unrolled=True))
+        ctx.close()
+    finally:
+        e.close()
+
+
+def test_unrolled_key_under_csprng_and_on_an_evaluation_only_context():
+    """production key generation (no seed): the unrolled key is exported to the oracle; a second, evaluation-only context
+    imports both evaluation keys and reproduces the same ciphertexts"""
+    from bmi_amd import tfhe
+    e = tfhe.Engine(tfhe.default_params(q_bits=49))
+    e.keygen()                                  # plain keys first ...
+    e.set_bsk_unroll(2)                         # ... the unrolled key is derived from the secret keys already held
+    ev = tfhe.Engine(tfhe.default_params(q_bits=49))
+    try:
+        to, P, ctx, sk_small, sk_big = _oracle(e)
+        rng = np.random.default_rng(8)
+        dl = e.delta_log()
+        table = rng.integers(-8, 8, 16)
+        msgs = rng.integers(-8, 8, 9)
+        ct = e.encrypt(msgs, dl)
+        lid = e.lut_register(table, 4, dl)
+        got = e.pbs_host(ct, np.full(9, lid, np.uint32))
+        assert list(e.decrypt(got, dl)) == [int(table[m + 8]) for m in msgs]
+        assert np.array_equal(got, ctx.pbs(ct, e.lut_get(lid)[None, :], np.zeros(9, np.uint32), unrolled=True))
+        _, _, bsk, ksk = e.export_keys(secret=False)
+        ev.import_keys(None, None, bsk, ksk)
+        ev.set_bsk_unroll(2)
+        with pytest.raises(tfhe.BmiError):      # unrolling selected, no unrolled key yet
+            ev.pbs_host(ct, np.full(9, ev.lut_register(table, 4, dl), np.uint32))
+        ev.import_bsk_unrolled(e.export_bsk_unrolled())
+        assert np.array_equal(ev.pbs_host(ct, np.full(9, ev.lut_register(table, 4, dl), np.uint32)), got)
+        ctx.close()
+    finally:
+        e.close()
+        ev.close()
+
+
+def test_unrolled_output_noise_on_the_formula_and_timing(eng, capsys):
+    """4,096 bootstraps: output variance = 3 x the key-noise term of the CGGI value (+ the unchanged decomposition term);
+    prints the per-bootstrap latency of the unrolled kernel next to the plain latency kernel's"""
+    from bmi_amd import tfhe
+    rng = np.random.default_rng(21)
+    B = 4096
+    dl = eng.delta_log()
+    ident = np.arange(-8, 8)
+    msgs = rng.integers(-8, 8, B)
+    lid = eng.lut_register(ident, 4, dl)
+    ct = eng.encrypt(msgs, dl)
+    out = eng.pbs_host(ct, np.full(B, lid, np.uint32))
+    assert list(eng.decrypt(out, dl)) == list(msgs)
+    q = float(eng.modulus)
+    err = eng.phase(out).astype(np.int64) - (msgs.astype(np.int64) << dl)
+    err = np.where(err > q / 2, err - q, np.where(err < -q / 2, err + q, err)) / q
+    P = eng.P
+    N, l, Bg = 1024, P.bs_levels, 2.0 ** P.bs_base_log
+    key_term = P.n * l * 2 * N * (Bg * Bg + 2) / 12 * P.glwe_noise ** 2
+    dec_term = P.n * (1 + N / 2) / (12 * Bg ** (2 * l))
+    want = 3 * key_term + dec_term / 2
+    ratio = float(np.mean(err ** 2)) / want
+    plain = tfhe.Engine(tfhe.default_params(q_bits=49))
+    plain.keygen(SEED)
+    t = {}
+    for name, e in (("unrolled", eng), ("plain latency kernel", plain)):
+        l2 = e.lut_register(ident, 4, dl)
+        for cnt in (1, 256):
+            c = e.encrypt(msgs[:cnt], dl)
+            ids = np.full(cnt, l2, np.uint32)
+            small = e.keyswitch_host(c)
+            e.blind_rotate_host(small, ids)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                e.blind_rotate_host(small, ids)
+            t[(name, cnt)] = (time.perf_counter() - t0) / 3 * 1e3
+    plain.close()
+    with capsys.disabled():
+        print(f"\nunrolled PBS: output log2 std {0.5 * np.log2(np.mean(err ** 2)):.2f} (3 x key term + dec/2: {0.5 * np.log2(want):.2f}, "
+              f"variance ratio {ratio:.3f}); blind rotation ms (host-buffer calls, copies included): "
+              + ", ".join(f"{k[0]} x{k[1]}: {v:.2f}" for k, v in t.items()))
+    assert 0.9 < ratio < 1.1

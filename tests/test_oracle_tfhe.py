@@ -318,3 +318,67 @@ def test_fast_path_equals_generic_path(field49):
         slow.close(); fast.close()
     with pytest.raises(ValueError):
         to.FastCtx(to.default_params(q_bits=64, n=4), np.zeros((4, 6, 2, 1024), np.uint64), np.zeros((1024, 8, 5), np.uint64))
+
+
+# ------------------------------------------------------------------ unrolled bootstrap key (two coefficients per step)
+
+@pytest.mark.parametrize("q_bits,n", [(49, 16), (49, 15), (64, 16), (to.TORUS64, 15)])
+def test_unrolled_blind_rotation_evaluates_every_lut_entry(q_bits, n):
+    """ACC <- ACC + sum_j (X^c_j - 1)(K_j [.] ACC), c = (a + a', a, a'), K = GGSW(s s'), GGSW(s (1 - s')), GGSW((1 - s) s'):
+    decrypt(PBS(enc m)) == LUT[m] for every m, even and odd n (an odd n is completed by a zero key bit), every modulus."""
+    to.set_field(q_bits)
+    try:
+        P = to.default_params(n=n, log_N=8, q_bits=q_bits, lwe_noise=2.0 ** -36, glwe_noise=2.0 ** -40)
+        K = to.keygen(P, 77 + n)
+        ctx = to.Ctx(P, K.bsk, K.ksk)
+        with pytest.raises(ValueError):
+            ctx.pbs(np.zeros((1, P.big), np.uint64), np.zeros((1, P.N), np.uint64), np.zeros(1, np.uint32), unrolled=True)
+        bsk3 = to.keygen_bsk_unrolled(P, 77 + n, K.sk_small, K.sk_big)
+        assert bsk3.shape == ((n + 1) // 2, 3, 6, 2, 256)
+        ctx.set_bsk_unrolled(bsk3)
+        p = 4
+        M = 1 << p
+        msgs = np.arange(-M // 2, M // 2)
+        table = np.array([(3 * m * m + 5 * m + 1) % M - M // 2 for m in msgs], dtype=np.int64)
+        dl = to.log_q(q_bits) - 1 - p
+        tv = to.make_test_vector(P.log_N, p, table, dl)
+        ct = to.lwe_encrypt(K.sk_big, P.glwe_noise, 9, 0, to.encode(msgs, dl))
+        out_u, ks = ctx.pbs(ct, tv, np.zeros(M, np.uint32), want_ks=True, unrolled=True)
+        out_s = ctx.pbs(ct, tv, np.zeros(M, np.uint32))
+        assert list(to.decode(to.lwe_phase(K.sk_big, out_u), dl)) == list(table)
+        assert list(to.decode(to.lwe_phase(K.sk_big, out_s), dl)) == list(table)
+        assert not np.array_equal(out_u, out_s)                    # different ciphertexts of the same messages
+        assert np.array_equal(ctx.blind_rotate(ks, tv, np.zeros(M, np.uint32), unrolled=True), out_u)
+        ctx.close()
+    finally:
+        to.set_field(64)
+
+
+def test_unrolled_blind_rotation_output_noise_on_the_formula(field49):
+    """Unrolling keeps the decomposition term and triples the key-noise term of a pair of steps (three GGSW products,
+    each scaled by X^c - 1 of squared norm 2, against two plain products): output variance 3 x the CGGI value when the key
+    noise dominates, as it does at the default parameters."""
+    P = to.default_params(q_bits=49, n=64)            # 64 coefficients: 1/10 of the work, same per-step noise
+    K = to.keygen(P, 0xABCD)
+    ctx = to.Ctx(P, K.bsk, K.ksk)
+    ctx.set_bsk_unrolled(to.keygen_bsk_unrolled(P, 0xABCD, K.sk_small, K.sk_big))
+    dl = 44
+    rng = np.random.default_rng(5)
+    msgs = rng.integers(-8, 8, 96)
+    ident = np.arange(-8, 8, dtype=np.int64)
+    tv = to.make_test_vector(10, 4, ident, dl)
+    small = to.lwe_encrypt(K.sk_small, 2.0 ** -30, 3, 0, to.encode(msgs, dl))      # straight to the blind rotation
+    q = float(field49)
+    var = {}
+    for unrolled in (False, True):
+        out = ctx.blind_rotate(small, tv, np.zeros(msgs.size, np.uint32), unrolled=unrolled)
+        ph = to.lwe_phase(K.sk_big, out).astype(np.int64)
+        assert list(to.decode(ph.astype(np.uint64), dl)) == list(msgs)
+        err = ph - (msgs.astype(np.int64) << dl)
+        err = np.where(err > q / 2, err - q, np.where(err < -q / 2, err + q, err)) / q
+        var[unrolled] = float(np.mean(err ** 2))
+    N, l, Bg = 1024, 3, 2.0 ** 15
+    cggi = P.n * (l * 2 * N * (Bg * Bg + 2) / 12 * P.glwe_noise ** 2 + (1 + N / 2) / (12 * Bg ** (2 * l)))
+    assert 0.6 < var[False] / cggi < 1.5
+    assert 2.0 < var[True] / cggi < 4.2                # 3 x, 96 samples
+    ctx.close()
