@@ -206,13 +206,15 @@ def main():
                  "against three 22-bit limbs of every key word, recombined mod 2^64; keyswitch: int8 matrix cores"}
     DTYPE = {64: "u64", 49: "f64", 65: "u64/f64"}
     # output noise of the timed batch against the analytic CGGI variance (tests/test_gpu_parity.py holds it to +-15 %)
-    def output_noise(e, outputs, expected):
+    def output_noise(e, outputs, expected, unrolled=False):
         Pp, Qm, dlx = e.P, e.modulus, e.delta_log()
         err = np.array([((int(x) - (int(m) << dlx)) + Qm // 2) % Qm - Qm // 2 for x, m in zip(e.phase(outputs), expected)],
                        dtype=np.float64) / float(Qm)
         Bg = 2.0 ** Pp.bs_base_log
-        analytic = Pp.n * (Pp.bs_levels * (Pp.k + 1) * Pp.N * (Bg * Bg + 2) / 12.0 * Pp.glwe_noise ** 2
-                           + (1 + Pp.k * Pp.N / 2.0) / (12.0 * Bg ** (2 * Pp.bs_levels)))
+        key_term = Pp.n * Pp.bs_levels * (Pp.k + 1) * Pp.N * (Bg * Bg + 2) / 12.0 * Pp.glwe_noise ** 2
+        dec_term = Pp.n * (1 + Pp.k * Pp.N / 2.0) / (12.0 * Bg ** (2 * Pp.bs_levels))
+        # unrolled key: three products per pair of coefficients, each scaled by X^c - 1 (squared norm 2), half the decompositions
+        analytic = 3 * key_term + dec_term / 2 if unrolled else key_term + dec_term
         return {"samples": int(err.size), "log2_std_measured": float(0.5 * np.log2(np.var(err))),
                 "log2_std_cggi_formula": float(0.5 * np.log2(analytic)), "variance_ratio": float(np.var(err) / analytic),
                 "log2_max_abs": float(np.log2(np.abs(err).max())), "log2_half_box": -6.0}
@@ -294,11 +296,13 @@ def main():
     if rank == 0 and world == 1 and args.q_bits is None and not args.no_second_field:
         # the same batch on the 2^64 torus and on the Goldilocks field: 1 warm-up + 3 timed steps each, kernel time by events;
         # reported beside the headline, never `value`
-        def other_modulus(qb, key_bits=None):
-            e2 = tfhe.Engine(tfhe.default_params(q_bits=qb), device=dev_index)
+        def other_modulus(qb, key_bits=None, unroll=False):
+            e2 = tfhe.Engine(tfhe.default_params(q_bits=qb, **({"glwe_noise": 2.0 ** -41} if unroll else {})), device=dev_index)
             try:
                 if key_bits:
                     e2.set_bsk_precision(key_bits)
+                if unroll:
+                    e2.set_bsk_unroll(2)
                 e2.keygen(0x5EED)
                 dl2 = e2.delta_log()
                 i2 = e2.lut_register(np.arange(-8, 8), 4, dl2)
@@ -324,10 +328,38 @@ def main():
                 ok2 = bool(np.array_equal(e2.decrypt(d_out2.cpu().numpy().view(np.uint64), dl2), want))
                 gbs = BSK_BYTES_PER_PBS * B / (kms * 1e-3) / 1e9
                 out2 = d_out2.cpu().numpy().view(np.uint64)
-                return {"q_bits": qb, "pbs_per_s": B / dt, "ms_per_step": dt * 1e3, "verified_decrypt": ok2,
-                        "output_noise": output_noise(e2, out2, want),
-                        "kernel": KERNEL[qb], "kernel_ms": kms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": gbs / HBM_PEAK_GBS, "arithmetic": ARITH[qb]}
+                rep = {"q_bits": qb, "pbs_per_s": B / dt, "ms_per_step": dt * 1e3, "verified_decrypt": ok2,
+                       "output_noise": output_noise(e2, out2, want, unrolled=unroll),
+                       "kernel": "k_blind_rotate_lat2u_49" if unroll else KERNEL[qb], "kernel_ms": kms, "achieved": gbs,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "arithmetic": ARITH[qb]}
+                if unroll:
+                    # latency of one bootstrap and of one full round of 256 (events around the kernel), the oracle's unrolled
+                    # blind rotation on a few ciphertexts of the batch, then the encrypted inverses on this engine
+                    for cnt in (1, 256):
+                        e2.blind_rotate(d_small2, d_ids2, cnt, d_out2, stream)
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record()
+                        for _ in range(5):
+                            e2.blind_rotate(d_small2, d_ids2, cnt, d_out2, stream)
+                        b.record()
+                        torch.cuda.synchronize()
+                        rep[f"latency_ms_{cnt}"] = a.elapsed_time(b) / 5
+                    if not args.no_cpu_baseline:
+                        from oracle import tfhe_oracle as to
+                        _, _, bsk_u, ksk_u = e2.export_keys()
+                        oc = to.Ctx(to.default_params(q_bits=49), bsk_u, ksk_u)
+                        oc.set_bsk_unrolled(e2.export_bsk_unrolled())
+                        tv2 = np.stack([e2.lut_get(i2), e2.lut_get(r2)])
+                        pick = np.arange(0, B, max(1, B // 8))[:8]
+                        wantu = oc.pbs(d_in2[torch.from_numpy(pick).to(dev)].cpu().numpy().view(np.uint64), tv2, lut_sel[pick].astype(np.uint32), unrolled=True)
+                        rep["bit_exact_vs_oracle_unrolled"] = bool(np.array_equal(wantu, out2[pick]))
+                        oc.close()
+                        to.set_field(eng.q_bits)
+                    if not args.no_inverse:
+                        from bmi_amd import inverse_bench
+                        sizes = tuple(int(x) for x in args.inverse_sizes.split(",") if x)
+                        rep["encrypted_inverse_wall_clock"] = inverse_bench.run(e2, sizes)
+                return rep
             finally:
                 e2.close()
         for name, qb, kb in (("roofline_q64_torus", 65, None), ("roofline_q64_torus_key42", 65, 42), ("roofline_q64_goldilocks", 64, None)):
@@ -340,6 +372,15 @@ def main():
                                         "output noise 2^-15.15 (the formula printed here is for the exact key); a throughput option")
             except Exception as e:  # reported, never hidden
                 res[name] = {"q_bits": qb, "error": repr(e)}
+        if eng.q_bits == 49:
+            # bootstrap-key unrolling (bmi_set_bsk_unroll(ctx, 2)): two LWE coefficients per blind-rotation step, key noise
+            # 2^-41 so that the output noise stays at the default set's; an option, never `value`
+            try:
+                res["unrolled_key_49"] = other_modulus(49, unroll=True)
+                res["unrolled_key_49"]["key"] = ("unrolled bootstrap key, 1.5 x the plain key (92.9 MB); glwe_noise 2^-41 (plain default: 2^-40) "
+                                                 "keeps the output noise of the default set; `achieved` / `frac` use the PLAIN key's bytes per PBS")
+            except Exception as e:
+                res["unrolled_key_49"] = {"error": repr(e)}
 
     if not args.no_inverse and rank == 0 and world == 1:
         try:

@@ -181,3 +181,32 @@ def test_unrolled_output_noise_on_the_formula_and_timing(eng, capsys):
               f"variance ratio {ratio:.3f}); blind rotation ms (host-buffer calls, copies included): "
               + ", ".join(f"{k[0]} x{k[1]}: {v:.2f}" for k, v in t.items()))
     assert 0.9 < ratio < 1.1
+
+
+@pytest.mark.parametrize("tag", ["baseline_n2_len20_ints8", "baseline_n3_len30_ints12", "baseline_n4_len40_ints16", "overflow_digit_2x2"])
+def test_encrypted_inverse_with_the_unrolled_key_matches_reference_golden(tag, capsys):
+    """BASELINE configs 2-4 and an overflow-digit case on ciphertexts with EncryptedMatrixInversion(unroll=True): decrypted
+    digits == the reference's plaintext QFloat output (tests/golden/inverse.json, generated from the reference)."""
+    import json, os
+    from bmi_amd.main import EncryptedMatrixInversion
+    with open(os.path.join(os.path.dirname(__file__), "golden", "inverse.json")) as f:
+        cases = json.load(f)
+    c = next(x for x in cases if x["tag"] == tag)
+    emi = EncryptedMatrixInversion(c["n"], None, 2, c["len"], c["ints"], c["true_division"], c["tensorize"], unroll=True)
+    try:
+        emi.keygen()                                # CSPRNG keys
+        assert emi.engine.P.glwe_noise == 2.0 ** -41
+        M = np.array(c["M"]).reshape(c["n"], c["n"])
+        q, s = emi.quantize(M)
+        enc = emi.encrypt(q, s)
+        emi._executor()
+        emi.evaluate(enc)                           # warm-up
+        t0 = time.time()
+        res = emi.evaluate(enc)
+        wall = time.time() - t0
+        out = emi.decrypt(res)
+        assert out.tolist() == c["out"]
+        with capsys.disabled():
+            print(f"\nunrolled key, {tag}: evaluate {wall:.2f} s, {emi.circuit.summary()['depth']} levels, {wall / emi.circuit.summary()['depth'] * 1e3:.2f} ms per level")
+    finally:
+        emi.engine.close()

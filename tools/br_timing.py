@@ -16,10 +16,13 @@ def main():
     kw = {k[5:].lower(): int(v) for k, v in os.environ.items() if k.startswith("BMIP_")}   # e.g. BMIP_BS_LEVELS=2
     eng = tfhe.Engine(tfhe.default_params(q_bits=qb, **kw))
     if os.environ.get('BMI_BSK_PRECISION'): eng.set_bsk_precision(int(os.environ['BMI_BSK_PRECISION']))
+    unroll = int(os.environ.get('BMI_UNROLL', '1'))   # 2: the unrolled blind rotation (one kernel for every variant / batch)
+    eng.set_bsk_unroll(unroll)
     eng.keygen(0x5EED)
     DL = eng.delta_log()
     sk_small, sk_big, bsk, ksk = eng.export_keys()
     octx = to.Ctx(to.default_params(q_bits=eng.q_bits, **kw), bsk, ksk)
+    if unroll == 2: octx.set_bsk_unrolled(eng.export_bsk_unrolled())
     lid = eng.lut_register(np.random.default_rng(9).integers(-8, 8, 16), 4, DL)
     tv = eng.lut_get(lid)[None, :]
     dev = torch.device("cuda:0")
@@ -34,7 +37,7 @@ def main():
         d_in = torch.from_numpy(ct.view(np.int64)).to(dev)
         d_ks = torch.empty((B, 631), dtype=torch.int64, device=dev)
         nchk = min(B, 4)
-        want = octx.blind_rotate(small[:nchk], tv, np.zeros(nchk, np.uint32))
+        want = octx.blind_rotate(small[:nchk], tv, np.zeros(nchk, np.uint32), unrolled=unroll == 2)
         for v in variants:
             eng.set_kernel_variant(v)
             eng.blind_rotate(d_small, d_ids, B, d_out, s); torch.cuda.synchronize()

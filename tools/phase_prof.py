@@ -13,7 +13,8 @@ LAT_NAMES = ["key loads issue + decompose + forward (waves 0-5)", "barrier 1 wai
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     log_N = int(sys.argv[3]) if len(sys.argv) > 3 else 10   # 11: k_blind_rotate_wide49 (8 waves; pass variant 0)
-    eng = tfhe.Engine(tfhe.default_params(q_bits=49, log_N=log_N)); eng.keygen(0x5EED)
+    unroll = int(sys.argv[4]) if len(sys.argv) > 4 else 1   # 2: k_blind_rotate_lat2u_49 (pass variant 2 for the phase names); cycles are then per PAIR of coefficients / 2
+    eng = tfhe.Engine(tfhe.default_params(q_bits=49, log_N=log_N)); eng.set_bsk_unroll(unroll); eng.keygen(0x5EED)
     DL = eng.delta_log()
     lid = eng.lut_register(np.arange(-8, 8), 4, DL)
     ct = eng.encrypt(np.random.default_rng(1).integers(-8, 8, B), DL)
