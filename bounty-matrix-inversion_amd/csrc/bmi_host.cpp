@@ -676,7 +676,7 @@ int upload_bsk3(bmi_ctx *c) {
         return fail(c, -2, "hipMalloc(unrolled key) failed");
     }
     HIP_OK(c, hipMemcpy(d_tmp, c->bsk3_std.data(), words * 8, hipMemcpyHostToDevice));
-    const int rc = bmi49::launch_bsk_to_lat(d_tmp, c->d_bsk3_lat, c->d_tw_half, (uint32_t)(words / c->N), c->stream);
+    const int rc = bmi49::launch_bsk_to_lat(d_tmp, c->d_bsk3_lat, c->d_tw_half, (uint32_t)(words / c->N), true, c->stream);
     if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat (unrolled key) launch failed"); }
     HIP_OK(c, hipStreamSynchronize(c->stream));
     HIP_OK(c, hipFree(d_tmp));
@@ -734,7 +734,7 @@ int upload_eval_keys(bmi_ctx *c) {
                 (void)hipFree(d_tmp);
                 return fail(c, -2, "hipMalloc(latency-kernel key) failed");
             }
-            rc = bmi49::launch_bsk_to_lat(d_tmp, c->d_bsk_lat, c->d_tw_half, (uint32_t)(bsk_words / N), c->stream);
+            rc = bmi49::launch_bsk_to_lat(d_tmp, c->d_bsk_lat, c->d_tw_half, (uint32_t)(bsk_words / N), false, c->stream);
             if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat launch failed"); }
         }
     }

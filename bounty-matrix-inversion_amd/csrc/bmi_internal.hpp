@@ -114,14 +114,15 @@ int launch_blind_rotate_wide(const u64 *small_cts, const uint32_t *lut_ids, cons
                              const double *g_tw, const double *g_tw_wide, u64 *out, uint32_t count, uint32_t n,
                              uint32_t levels, uint32_t base_log, hipStream_t s);
 // latency kernel, two wavefronts per transform (ntt_half_f64.hpp): own key copy in slot order, own twiddle tables
-int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, hipStream_t s);
+// paired: A_lo[p], A_hi[p] side by side (one 16-byte request per slot; the unrolled kernel's layout), else [A_lo 512][A_hi 512]
+int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, bool paired, hipStream_t s);
 // (levels, base log) of the bootstrap decomposition: (3, 15), (2, 15) and (1, 23) are instantiated in the three kernels
 // below; the other 49-bit kernels (variants 1 and 4, N = 4096) and the Goldilocks ones take (3, 15) only
 int launch_blind_rotate_lat2(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk_lat,
                              const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, uint32_t levels, uint32_t base_log,
                              hipStream_t s);
-// the same with the unrolled key (two LWE coefficients per step): bsk3_lat = [ceil(n/2)][3 keys] GGSW copies in the slot order
-// of launch_bsk_to_lat, g_root_pow = psi^x for x in [0, 2N) as centred doubles
+// the same with the unrolled key (two LWE coefficients per step): bsk3_lat = [ceil(n/2)][3 keys] GGSW copies in the PAIRED slot
+// order of launch_bsk_to_lat, g_root_pow = psi^x for x in [0, 2N) as centred doubles
 int launch_blind_rotate_lat2u(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk3_lat,
                               const double *g_tw_h, const double *g_root_pow, u64 *out, uint32_t count, uint32_t n,
                               uint32_t levels, uint32_t base_log, hipStream_t s);

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bmi_internal.hpp"
+#include "dec49.hpp"
 #include "ks_lincomb.hpp"
 #include "ks_mfma.hpp"
 #include "ntt_half_f64.hpp"
@@ -18,6 +19,9 @@
 using f49::i64;
 using f49::u64;
 using namespace nttf;
+using dec49::Dec;
+using dec49::digit_of;
+using dec49::round_half_up;
 
 namespace {
 
@@ -60,48 +64,6 @@ __global__ void __launch_bounds__(256) k_negacyclic_mul49(const u64 *__restrict_
     inverse(x, lane, lds, scratch);
     static_for<0, 16>([&](auto J) { c[(size_t)p * N + lane + 64 * J] = f49::to_u(x[J]); });
 }
-
-// Decomposition rule of every modulus of this library (and of the oracle): the centred coefficient is rounded HALF UP to its
-// top l * Bg bits, r = floor(v / 2^shift + 1/2), and r is split into balanced signed digits d in [-Bg/2, Bg/2) from the
-// least significant one up, r <- floor(r / Bg + 1/2), the top digit taking the last carry - the closest-representative
-// signed decomposition of the TFHE literature.  In f64 every step is exact: one v_fma_f64 and one v_floor_f64.
-__device__ __forceinline__ double round_half_up(double x, double scale) { return __builtin_floor(__builtin_fma(x, scale, 0.5)); }
-
-// Rounded value r of a centred coefficient v (l = 3, base 2^15: 45 of the 49 bits are kept, r = round_half_up(v, 2^-4)); the
-// three signed digits recovered from r.
-__device__ __forceinline__ double digit_of(double r, int lev) {
-    const double r1 = round_half_up(r, 0x1p-15);
-    if (lev == 2) return __builtin_fma(-32768.0, r1, r);
-    const double r2 = round_half_up(r1, 0x1p-15);
-    if (lev == 1) return __builtin_fma(-32768.0, r2, r1);
-    return r2;
-}
-
-// The same for any (levels L, base 2^BG) with L * BG <= 48: SC rounds a centred coefficient to its top L * BG bits.
-template <int L, int BG>
-struct Dec {
-    static constexpr double SC = 1.0 / (double)(1ull << (49 - L * BG));
-    static constexpr double B = (double)(1ull << BG);
-    static constexpr double BINV = 1.0 / (double)(1ull << BG);
-    static_assert(L >= 1 && L <= 3 && L * BG <= 48, "decomposition must fit the 49-bit field");
-    // digit `lev` (0 = most significant) of the rounded value r
-    static __device__ __forceinline__ double digit(double r, int lev) {
-#pragma unroll
-        for (int t = L - 1; t > 0; t--) {
-            const double rn = round_half_up(r, BINV);
-            if (t == lev) return __builtin_fma(-B, rn, r);
-            r = rn;
-        }
-        return r;
-    }
-    // peels the least significant remaining digit off r
-    static __device__ __forceinline__ double peel(double &r) {
-        const double rn = round_half_up(r, BINV);
-        const double d = __builtin_fma(-B, rn, r);
-        r = rn;
-        return d;
-    }
-};
 
 // Phase timing (debug build only: make prof): wall-clock cycles per phase of one wavefront, see tools/phase_prof.py
 #ifdef BMI_PHASE_PROF
@@ -558,6 +520,10 @@ constexpr int L2_THREADS = 1024;
 constexpr int L2_LDS_WORDS = ntth::HT_WORDS + 2 * N + 12 * ntth::HSCRATCH + 2 * N + BMI_AT_WORDS;   // 12 = 4 x (L = 3) tiles
 static_assert(L2_LDS_WORDS <= BMI_LDS_WORDS_MAX, "L2_LDS_WORDS exceeds the 160 KB of LDS");
 
+// PAIRED: the two words of a slot, A_lo[p] and A_hi[p], are stored side by side ([512][2]) so that the consumer requests them
+// as ONE 16-byte word: a compute unit takes in 47-50 B per cycle with 16-byte requests against 29 with 8-byte ones
+// (tools/microbench/cu_intake.hip), which is what the unrolled kernel's 295 KB of key per step need.
+template <bool PAIRED>
 __global__ void __launch_bounds__(256) k_bsk_to_lat49(const u64 *__restrict__ std_polys, double *__restrict__ lat_polys,
                                                       const double *__restrict__ g_tw_h, uint32_t n_polys) {
     __shared__ double lds[ntth::HT_WORDS + 4 * ntth::HSCRATCH];
@@ -582,8 +548,12 @@ __global__ void __launch_bounds__(256) k_bsk_to_lat49(const u64 *__restrict__ st
         static_for<0, 4>([&](auto Q4) {
             const int p = (h * 4 + Q4) * 64 + lane;   // the pair's 128 lanes cover the 512 slots in 4 steps
             const double e = te[p], od = to[p];
-            o[p] = f49::red(e + od);
-            o[ntth::HALF + p] = f49::red(e - od);
+            if constexpr (PAIRED) {
+                reinterpret_cast<double2 *>(o)[p] = make_double2(f49::red(e + od), f49::red(e - od));
+            } else {
+                o[p] = f49::red(e + od);
+                o[ntth::HALF + p] = f49::red(e - od);
+            }
         });
     }
 }
@@ -691,150 +661,6 @@ __global__ void __launch_bounds__(L2_THREADS)
     if (blockIdx.x == 0 && lane == 0)
         for (int k_ = 0; k_ < 8; k_++) g_phase[wave * 8 + k_] = ph_[k_];
 #endif
-    u64 *o = out + (size_t)ct * (N + 1);
-    {
-        const uint32_t nn = tid;
-        const double a0 = acc[(nn & 1) * ntth::HALF + (nn >> 1)];
-        if (nn == 0) {
-            o[0] = f49::to_u(a0);
-            o[N] = f49::to_u(acc[N]);
-        } else {
-            o[N - nn] = f49::to_u(-a0);
-        }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------------------------
-// LATENCY kernel with the UNROLLED bootstrap key (two LWE coefficients per step; oracle/tfhe_oracle.c
-// ora_blind_rotate_extract_unrolled):   ACC <- ACC + sum_{j<3} (X^(c_j) - 1) (K3[i][j] [.] ACC),  c = (a + a', a, a').
-// The structure of k_blind_rotate_lat2_49 with half the steps: phase A decomposes ACC itself (no rotation) and runs the
-// twelve forward half transforms ONCE per pair of coefficients; phase B multiplies the six digit transforms with the three
-// GGSW keys of the pair and scales each product by  psi^(e c_j) - 1,  the value of X^(c_j) - 1 at the slot's root psi^e
-// (e = 2 kk + 1 for A_lo, e + N for A_hi: a look-up in a 2N-entry table of root powers), so the rotation never touches the
-// coefficient domain; phase C is unchanged.  Per pair: 12 + 4 half transforms and 42 modular multiplications per thread,
-// against 24 + 8 and 24 of two plain steps.  The price is noise: the key-noise term of the output variance triples.
-constexpr int L2U_LDS_WORDS = L2_LDS_WORDS + 2 * N;
-static_assert(L2U_LDS_WORDS <= BMI_LDS_WORDS_MAX, "L2U_LDS_WORDS exceeds the 160 KB of LDS");
-
-template <int L = 3, int BG = 15>
-__global__ void __launch_bounds__(L2_THREADS)
-    k_blind_rotate_lat2u_49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
-                            const double *__restrict__ luts, const double *__restrict__ bsk3_lat,
-                            const double *__restrict__ g_tw_h, const double *__restrict__ g_root_pow,
-                            u64 *__restrict__ out, uint32_t count, uint32_t n) {
-    extern __shared__ double lds[];
-    double *acc = lds + ntth::HT_WORDS;              // [2 components][2 parities][512], centred (<= q/2 + 2)
-    double *tiles = acc + 2 * N;                     // [12][HSCRATCH]
-    double *SD = tiles + 12 * ntth::HSCRATCH;        // [2 outputs][sum, difference][512]
-    uint16_t *at = reinterpret_cast<uint16_t *>(SD + 2 * N);
-    double *RP = SD + 2 * N + BMI_AT_WORDS;          // psi^x, x in [0, 2N)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < ntth::HT_WORDS; i += L2_THREADS) lds[i] = g_tw_h[i];
-    for (int i = tid; i < 2 * N; i += L2_THREADS) RP[i] = g_root_pow[i];
-    const uint32_t ct = blockIdx.x;
-    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
-    for (uint32_t i = tid; i <= n; i += L2_THREADS) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 1);
-    __syncthreads();
-    {
-        const double *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
-        const uint32_t bt = at[n];
-        const uint32_t nn = tid;  // coefficient index
-        const uint32_t e = (nn + bt) & (2 * N - 1);
-        const double v = tv[e & (N - 1)];
-        acc[(nn & 1) * ntth::HALF + (nn >> 1)] = 0.0;
-        acc[N + (nn & 1) * ntth::HALF + (nn >> 1)] = (e & N) ? -v : v;
-    }
-    __syncthreads();
-    const int mo = tid >> 9, mp = tid & 511;  // phase B: output polynomial, slot
-    const uint32_t root_e = 2 * ntth::kk_of(mp & 63, mp >> 6) + 1;   // A_lo[mp] is the value at psi^root_e, A_hi[mp] at -psi^root_e
-    const uint32_t pairs = (n + 1) >> 1;
-
-    for (uint32_t ip = 0; ip < pairs; ip++) {
-        const uint32_t a1 = at[2 * ip], a2 = (2 * ip + 1 < n) ? at[2 * ip + 1] : 0u;
-        if ((a1 | a2) == 0) continue;  // uniform over the workgroup: every factor X^0 - 1 vanishes
-        const uint32_t cj[3] = {(a1 + a2) & (2 * N - 1), a1, a2};
-        const double *bi = bsk3_lat + (size_t)ip * 3 * 4 * L * N;   // [3 keys][2 L rows][2 outputs][A_lo 512, A_hi 512]
-        double b[2 * L][2];
-#pragma unroll
-        for (int r = 0; r < 2 * L; r++) {
-            b[r][0] = bi[(size_t)(r * 2 + mo) * N + mp];
-            b[r][1] = bi[(size_t)(r * 2 + mo) * N + ntth::HALF + mp];
-        }
-        if (wave < 4 * L) {
-            const int c = wave / (2 * L), lev = (wave % (2 * L)) >> 1, h = wave & 1;
-            const int pz = wave >> 1;
-            const double *ac = acc + c * N + h * ntth::HALF;
-            double x[8];
-#if BMI_LAT2_PRIO
-            __builtin_amdgcn_s_setprio(3);
-#endif
-            static_for<0, 8>([&](auto J) {
-                x[J] = Dec<L, BG>::digit(round_half_up(ac[lane + 64 * J], Dec<L, BG>::SC), lev);
-            });
-            double *tile = tiles + (2 * pz + h) * ntth::HSCRATCH;
-            if (h) ntth::forward_half<true>(x, lane, lds, tile);
-            else ntth::forward_half<false>(x, lane, lds, tile);
-            wave_sync();
-            static_for<0, 8>([&](auto R) { tile[R * 64 + lane] = x[R]; });
-#if BMI_LAT2_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-        }
-        __syncthreads();
-        {
-            double alo[2 * L], ahi[2 * L];
-#pragma unroll
-            for (int r = 0; r < 2 * L; r++) {
-                const double e = tiles[(2 * r) * ntth::HSCRATCH + mp], od = tiles[(2 * r + 1) * ntth::HSCRATCH + mp];
-                alo[r] = e + od;
-                ahi[r] = e - od;
-            }
-            double slo = 0.0, shi = 0.0;   // sums of three reduced products (<= 1.6 q)
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                double bn[2 * L][2];
-                if (j < 2) {   // the next key's words are requested while this one is multiplied
-                    const double *bj = bi + (size_t)(j + 1) * 4 * L * N;
-#pragma unroll
-                    for (int r = 0; r < 2 * L; r++) {
-                        bn[r][0] = bj[(size_t)(r * 2 + mo) * N + mp];
-                        bn[r][1] = bj[(size_t)(r * 2 + mo) * N + ntth::HALF + mp];
-                    }
-                }
-                double ylo = 0.0, yhi = 0.0;  // lazy sums of 2 L <= six products (<= 10.2 q)
-#pragma unroll
-                for (int r = 0; r < 2 * L; r++) {
-                    ylo += f49::mul(alo[r], b[r][0]);
-                    yhi += f49::mul(ahi[r], b[r][1]);
-                }
-                const double w = RP[(root_e * cj[j]) & (2 * N - 1)];        // psi^(e c_j); at the root -psi^e: (-1)^c_j times it
-                const double wh = (cj[j] & 1) ? -w : w;
-                slo += f49::mul(f49::red(ylo), w - 1.0);
-                shi += f49::mul(f49::red(yhi), wh - 1.0);
-                if (j < 2) {
-#pragma unroll
-                    for (int r = 0; r < 2 * L; r++) { b[r][0] = bn[r][0]; b[r][1] = bn[r][1]; }
-                }
-            }
-            slo = f49::red(slo);
-            shi = f49::red(shi);
-            SD[(mo * 2 + 0) * ntth::HALF + mp] = slo + shi;
-            SD[(mo * 2 + 1) * ntth::HALF + mp] = slo - shi;
-        }
-        __syncthreads();
-        if (wave < 4) {
-            const int o = wave >> 1, h = wave & 1;
-            double x[8];
-            static_for<0, 8>([&](auto R) { x[R] = SD[(o * 2 + h) * ntth::HALF + R * 64 + lane]; });
-            double *tile = tiles + wave * ntth::HSCRATCH;
-            if (h) ntth::inverse_half<true>(x, lane, lds, tile);
-            else ntth::inverse_half<false>(x, lane, lds, tile);
-            double *ao = acc + o * N + h * ntth::HALF;
-            static_for<0, 8>([&](auto J) { ao[lane + 64 * J] = f49::red(ao[lane + 64 * J] + x[J]); });
-        }
-        __syncthreads();
-    }
     u64 *o = out + (size_t)ct * (N + 1);
     {
         const uint32_t nn = tid;
@@ -1438,8 +1264,9 @@ int launch_blind_rotate_wide(const u64 *small_cts, const uint32_t *lut_ids, cons
     return f ? f(small_cts, lut_ids, luts, bsk_wide, g_tw, g_tw_wide, out, count, n, s) : (int)hipErrorInvalidValue;
 }
 
-int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, hipStream_t s) {
-    hipLaunchKernelGGL(k_bsk_to_lat49, dim3((n_polys + 1) / 2), dim3(256), 0, s, std_polys, lat_polys, g_tw_h, n_polys);
+int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, bool paired, hipStream_t s) {
+    if (paired) hipLaunchKernelGGL(k_bsk_to_lat49<true>, dim3((n_polys + 1) / 2), dim3(256), 0, s, std_polys, lat_polys, g_tw_h, n_polys);
+    else hipLaunchKernelGGL(k_bsk_to_lat49<false>, dim3((n_polys + 1) / 2), dim3(256), 0, s, std_polys, lat_polys, g_tw_h, n_polys);
     BMI49_LAUNCH_CHECK();
     return 0;
 }
@@ -1465,30 +1292,6 @@ int launch_blind_rotate_lat2(const u64 *small_cts, const uint32_t *lut_ids, cons
     if (count == 0) return 0;
     launch9_t f = pick_lat2(levels, base_log);
     return f ? f(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s) : (int)hipErrorInvalidValue;
-}
-
-template <int L, int BG>
-struct LaunchLat2u {
-    static int go(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk3_lat, const double *g_tw_h,
-                  const double *g_root_pow, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
-        static std::atomic<uint64_t> configured{0};
-        const size_t lds = (size_t)L2U_LDS_WORDS * sizeof(double);
-        auto kern = k_blind_rotate_lat2u_49<L, BG>;
-        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
-        hipLaunchKernelGGL(kern, dim3(count), dim3(L2_THREADS), lds, s, small_cts, lut_ids, luts, bsk3_lat, g_tw_h, g_root_pow, out,
-                           count, n);
-        BMI49_LAUNCH_CHECK();
-        return 0;
-    }
-};
-static launch10_t pick_lat2u(uint32_t levels, uint32_t base_log) { BMI49_FOR_LB(levels, base_log, LaunchLat2u); }
-
-int launch_blind_rotate_lat2u(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk3_lat,
-                              const double *g_tw_h, const double *g_root_pow, u64 *out, uint32_t count, uint32_t n,
-                              uint32_t levels, uint32_t base_log, hipStream_t s) {
-    if (count == 0) return 0;
-    launch10_t f = pick_lat2u(levels, base_log);
-    return f ? f(small_cts, lut_ids, luts, bsk3_lat, g_tw_h, g_root_pow, out, count, n, s) : (int)hipErrorInvalidValue;
 }
 
 int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,

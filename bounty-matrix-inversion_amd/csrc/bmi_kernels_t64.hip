@@ -333,8 +333,9 @@ __global__ void __launch_bounds__(256) k_bsk_to_lat_t64(const u64 *__restrict__ 
         static_for<0, 4>([&](auto Q4) {
             const int p = (h * 4 + Q4) * 64 + lane;
             const double e = te[p], od = to[p];
-            o[p] = f49::red(e + od);
-            o[ntth::HALF + p] = f49::red(e - od);
+            // A_lo[p], A_hi[p] side by side: the kernel requests them as ONE 16-byte word (a compute unit takes in 47-50 B
+            // per cycle with 16-byte requests against 29 with 8-byte ones, tools/microbench/cu_intake.hip)
+            reinterpret_cast<double2 *>(o)[p] = make_double2(f49::red(e + od), f49::red(e - od));
         });
     }
 }
@@ -372,15 +373,19 @@ __global__ void __launch_bounds__(LT_THREADS)
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t a_t = at[i];
         if (a_t == 0) continue;  // uniform over the workgroup
-        // key words of this thread's (output, slot): [row 2L][output 2][limb][A_lo, A_hi]
+        // key words of this thread's (output, slot): [row 2L][output 2][limb][512 slots][A_lo, A_hi], one 16-byte request per
+        // (row, limb)
         const double *bi = bsk_lat + (size_t)i * 4 * L * LIMBS * N;
-        auto key = [&](int r, int j, int hi) { return bi[(((size_t)(r * 2 + mo)) * LIMBS + j) * N + hi * ntth::HALF + mp]; };
-        double b0[2 * L][2];
+        auto load_limb = [&](double (&dst)[2 * L][2], int j) {
 #pragma unroll
-        for (int r = 0; r < 2 * L; r++) {
-            b0[r][0] = key(r, 0, 0);
-            b0[r][1] = key(r, 0, 1);
-        }
+            for (int r = 0; r < 2 * L; r++) {
+                const double2 w = reinterpret_cast<const double2 *>(bi + (((size_t)(r * 2 + mo)) * LIMBS + j) * N)[mp];
+                dst[r][0] = w.x;
+                dst[r][1] = w.y;
+            }
+        };
+        double b0[2 * L][2];
+        load_limb(b0, 0);
         if (wave < 4 * L) {
             const int c = wave / (2 * L), lev = (wave % (2 * L)) >> 1, h = wave & 1;
             const int pz = wave >> 1;
@@ -420,41 +425,31 @@ __global__ void __launch_bounds__(LT_THREADS)
                 alo[r] = e + od;
                 ahi[r] = e - od;
             }
-            double bc[2 * L][2], bn[2 * L][2];
-#pragma unroll
-            for (int r = 0; r < 2 * L; r++) {
-                bc[r][0] = b0[r][0];
-                bc[r][1] = b0[r][1];
-            }
-            static_for<0, LIMBS>([&](auto JL) {
-                constexpr int j = JL;
-                if constexpr (j + 1 < LIMBS) {
-#pragma unroll
-                    for (int r = 0; r < 2 * L; r++) {
-                        bn[r][0] = key(r, j + 1, 0);
-                        bn[r][1] = key(r, j + 1, 1);
-                    }
-                }
-                sched_fence();
+            // limb 0 was requested before the forward phase; limb 1 is requested now, limb 2 as soon as limb 0 has been consumed
+            // (its registers are reused): a request is in flight during every multiplication
+            auto one_limb = [&](const double (&kw)[2 * L][2], int j) {
                 double ylo = 0.0, yhi = 0.0;  // lazy sums of 2 L products (<= 10.3 p)
 #pragma unroll
                 for (int r = 0; r < 2 * L; r++) {
-                    ylo += f49::mul(alo[r], bc[r][0]);
-                    yhi += f49::mul(ahi[r], bc[r][1]);
+                    ylo += f49::mul(alo[r], kw[r][0]);
+                    yhi += f49::mul(ahi[r], kw[r][1]);
                 }
                 ylo = f49::red(ylo);
                 yhi = f49::red(yhi);
                 double *sd = SD + (size_t)j * 2 * N;
                 sd[(mo * 2 + 0) * ntth::HALF + mp] = ylo + yhi;
                 sd[(mo * 2 + 1) * ntth::HALF + mp] = ylo - yhi;
-                if constexpr (j + 1 < LIMBS) {
-#pragma unroll
-                    for (int r = 0; r < 2 * L; r++) {
-                        bc[r][0] = bn[r][0];
-                        bc[r][1] = bn[r][1];
-                    }
-                }
-            });
+            };
+            double bn[2 * L][2];
+            load_limb(bn, 1);
+            sched_fence();
+            one_limb(b0, 0);
+            if constexpr (LIMBS == 3) {
+                load_limb(b0, 2);
+                sched_fence();
+            }
+            one_limb(bn, 1);
+            if constexpr (LIMBS == 3) one_limb(b0, 2);
         }
         __syncthreads();
         if (wave < 4 * LIMBS) {

@@ -31,7 +31,7 @@ def main():
         eng.blind_rotate(d_small, d_ids, B, d_out, s)
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * 128)()
-    rc = tfhe.load_library().bmi_debug_phase_prof(buf)
+    rc = (tfhe.load_library().bmi_debug_phase_prof_unrolled if unroll == 2 else tfhe.load_library().bmi_debug_phase_prof)(buf)
     assert rc == 0, rc
     a = np.array(buf[:], dtype=np.float64).reshape(16, 8)
     WIDE_NAMES = ["decompose + forward tasks (both rounds)", "barrier after tasks", "MAC (both rounds)", "barrier after MAC", "sums + barrier", "inverse + update (waves 0-3)", "barrier after inverse", "loop head"]
