@@ -261,7 +261,28 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # threads of the CPU baseline = the host cores this process may actually use (affinity mask, cgroup CPU quota),
+        # not the machine's core count: an over-subscribed OpenMP team would make the baseline look worse than it is
+        def host_cores():
+            cores = len(os.sched_getaffinity(0))
+            quota = None
+            for qf, pf in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+                try:
+                    if pf is None:
+                        q, per = open(qf).read().split()
+                        quota = None if q == "max" else float(q) / float(per)
+                    else:
+                        q, per = float(open(qf).read()), float(open(pf).read())
+                        quota = None if q <= 0 else q / per
+                    break
+                except Exception:
+                    continue
+            usable = cores if quota is None else max(1, min(cores, int(quota + 0.999)))
+            return usable, {"cpu_count": os.cpu_count(), "affinity": cores, "cgroup_quota_cores": quota}
+        usable, host_info = host_cores()
         from oracle import tfhe_oracle as to
+        if "OMP_NUM_THREADS" not in os.environ:
+            to.set_num_threads(usable)
         sk_small, sk_big, bsk, ksk = eng.export_keys()
         tvs = np.stack([eng.lut_get(ident), eng.lut_get(rlut)])
         threads = to.num_threads()
@@ -281,7 +302,7 @@ def main():
             pick = np.linspace(0, sample - 1, min(sample, max(4, threads // 8))).astype(int)
             self_check = bool(np.array_equal(slow.pbs(ct[pick], tvs, lut_sel[pick].astype(np.uint32)), ref[pick]))
             slow.close()
-        res["cpu_baseline"] = {"value": sample / cpu_s, "unit": "PBS/s", "cores": threads, "kind": "port",
+        res["cpu_baseline"] = {"value": sample / cpu_s, "unit": "PBS/s", "cores": threads, "host": host_info, "kind": "port",
                                "ms_per_pbs_per_thread": cpu_s / sample * threads * 1e3,
                                "sample": f"first {sample} ciphertexts of the same batch, same keys/LUTs, oracle/tfhe_oracle.c "
                                          + ("fast path (exact f64 arithmetic mod 2^49-720895, vectorised 32 x 32 four-step transforms, no "

@@ -738,10 +738,10 @@ __global__ void __launch_bounds__(128) k_bsk_to_wide49(const u64 *__restrict__ s
     const double *te = lds + TW_WORDS + N, *to = te + SCRATCH_WORDS;
     constexpr double INV2 = f49::centred_c((f49::Q + 1) / 2);   // 1/2 mod q
     double *o = wide_polys + (size_t)poly * W_N;
-    for (int p = threadIdx.x; p < N; p += blockDim.x) {
-        o[p] = f49::red(f49::mul(te[p] + to[p], INV2));
-        o[N + p] = f49::red(f49::mul(te[p] - to[p], INV2));
-    }
+    // A[p], A[p + 1024] side by side: the kernel requests them as ONE 16-byte word (47-50 B per cycle into a compute unit
+    // against 29 with 8-byte requests, tools/microbench/cu_intake.hip)
+    for (int p = threadIdx.x; p < N; p += blockDim.x)
+        reinterpret_cast<double2 *>(o)[p] = make_double2(f49::red(f49::mul(te[p] + to[p], INV2)), f49::red(f49::mul(te[p] - to[p], INV2)));
 }
 
 template <int L = 3, int BG = 15>
@@ -786,7 +786,8 @@ __global__ void __launch_bounds__(W_THREADS)
         auto round = [&](auto R0_, auto NR_) {
             constexpr int R0 = R0_, NR = NR_;
             double b[4][NR][2];            // key words of this thread's four (output, slot) items
-            // One CU takes its key words in at ~20 B per cycle (131 KB in the first round), and a wavefront cannot run
+            // One CU takes its key words in at ~29 B per cycle with 8-byte requests, ~48 with 16-byte ones (131 KB in the first
+            // round; the (A[p], A[p + 1024]) pairs are stored side by side for that), and a wavefront cannot run
             // ahead of a load it has not been able to issue: the rows are requested in stages between the pieces of
             // the task instead of all up front (BMI_WIDE_STAGE: 0 = all first, 1 = two stages, 2 = four).
             auto load_rows = [&](auto RA_, auto RB_) {
@@ -795,9 +796,9 @@ __global__ void __launch_bounds__(W_THREADS)
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const int idx = tid + W_THREADS * q, o = idx >> 10, p = idx & (N - 1);
-                        const double *row = bi + (size_t)((R0 + r) * 2 + o) * W_N;
-                        b[q][r][0] = row[p];
-                        b[q][r][1] = row[N + p];
+                        const double2 w = reinterpret_cast<const double2 *>(bi + (size_t)((R0 + r) * 2 + o) * W_N)[p];
+                        b[q][r][0] = w.x;
+                        b[q][r][1] = w.y;
                     }
                 });
             };

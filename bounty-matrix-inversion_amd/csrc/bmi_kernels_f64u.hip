@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(L2_THREADS)
     double *RP = SD + 2 * N + BMI_AT_WORDS;          // psi^x, x in [0, 2N)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < ntth::HT_WORDS; i += L2_THREADS) lds[i] = g_tw_h[i];
-    for (int i = tid; i < 2 * N; i += L2_THREADS) RP[i] = g_root_pow[i];
+    for (int i = tid; i < 2 * N; i += L2_THREADS) RP[i ^ ((i >> 5) & 31)] = g_root_pow[i];
     const uint32_t ct = blockIdx.x;
     const u64 *lwe = small_cts + (size_t)ct * (n + 1);
     for (uint32_t i = tid; i <= n; i += L2_THREADS) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 1);
@@ -138,7 +138,11 @@ __global__ void __launch_bounds__(L2_THREADS)
                     ylo += f49::mul(alo[r], kw[r][0]);
                     yhi += f49::mul(ahi[r], kw[r][1]);
                 }
-                const double w = RP[(root_e * c) & (2 * N - 1)];        // psi^(e c); at the root -psi^e: (-1)^c times it
+                // psi^(e c); at the root -psi^e: (-1)^c times it.  The table is stored at x ^ (bits 5..9 of x): the exponents of
+                // a wavefront, odd multiples of c, share their low bits when c is even - without the fold they would meet in a
+                // few LDS banks (SQ_LDS_BANK_CONFLICT: 30 % of this kernel's LDS cycles, rocprofv3 --pmc)
+                const uint32_t xe = (root_e * c) & (2 * N - 1);
+                const double w = RP[xe ^ ((xe >> 5) & 31)];
                 const double wh = (c & 1) ? -w : w;
                 slo += f49::mul(f49::red(ylo), w - 1.0);
                 shi += f49::mul(f49::red(yhi), wh - 1.0);

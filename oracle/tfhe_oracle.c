@@ -698,6 +698,14 @@ void ora_lincomb(uint32_t width, const u64 *in, const uint32_t *row_ptr, const u
     }
 }
 
+/* size of the OpenMP team of the batch entry points (bench.py: the host cores the process may actually use) */
+void ora_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 int ora_num_threads(void) {
     int n = 1;
 #ifdef _OPENMP

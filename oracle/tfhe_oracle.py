@@ -293,3 +293,7 @@ def lincomb(width, cts, row_ptr, idx, coef, const_body):
 
 def num_threads():
     return int(lib().ora_num_threads())
+
+
+def set_num_threads(n):
+    lib().ora_set_num_threads(C.c_int(int(n)))
