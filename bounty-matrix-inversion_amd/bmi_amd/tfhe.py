@@ -264,13 +264,16 @@ class Engine:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return self.keygen(seed)
         rank = dist.get_rank(group)
+        unrolled = getattr(self, "unroll", 1) == 2     # the unrolled bootstrap key travels with the set
         if rank == src:
             self.keygen(seed)
-            parts = list(self.export_keys())
+            parts = list(self.export_keys()) + ([self.export_bsk_unrolled()] if unrolled else [])
         else:
             P, rows = self.P, (self.P.k + 1) * self.P.bs_levels
             parts = [np.zeros(P.n, np.uint64), np.zeros(P.k * P.N, np.uint64), np.zeros((P.n, rows, P.k + 1, P.N), np.uint64),
                      np.zeros((P.k * P.N, P.ks_levels, P.n + 1), np.uint64)]
+            if unrolled:
+                parts.append(np.zeros(self.unrolled_key_shape(), np.uint64))
         on_gpu = dist.get_backend(group) == "nccl"
         for a in parts:
             t = torch.from_numpy(a.view(np.int64))
@@ -280,7 +283,9 @@ class Engine:
             if on_gpu:
                 a.view(np.int64)[...] = t.cpu().numpy()
         if rank != src:
-            self.import_keys(*parts)
+            self.import_keys(*parts[:4])
+            if unrolled:
+                self.import_bsk_unrolled(parts[4])
 
     def export_keys(self, secret=True):
         """(sk_small, sk_big, bsk, ksk), standard domain; secret=False returns (None, None, bsk, ksk) and also works on
@@ -409,6 +414,7 @@ class Engine:
         """49-bit field, N = 1024: 1 = CGGI's blind rotation (default), 2 = two LWE coefficients per step with an unrolled
         bootstrap key (generated by the next keygen, or at once from the secret keys already held); include/bmi_tfhe.h"""
         self._ck(self.lib.bmi_set_bsk_unroll(self.h, int(factor)), "bmi_set_bsk_unroll")
+        self.unroll = int(factor)
 
     def unrolled_key_shape(self):
         P = self.P

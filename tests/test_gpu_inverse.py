@@ -334,7 +334,7 @@ def test_csprng_keygen_and_encryption(eng):
         e.close()
 
 
-def _two_rank_worker(rank, world, port, out_dir, tag):
+def _two_rank_worker(rank, world, port, out_dir, tag, unroll=False):
     """one of two processes sharing cuda:0 (the GPU box has one GPU): gloo stands in for RCCL, which refuses two ranks
     on one device; the level split, the padded store regions and the gather are the code the N-GPU run uses."""
     import torch.distributed as dist
@@ -344,7 +344,9 @@ def _two_rank_worker(rank, world, port, out_dir, tag):
     from bmi_amd.main import EncryptedMatrixInversion
     c = next(x for x in load("inverse.json") if x["tag"] == tag)
     import torch
-    eng = tfhe.Engine()
+    eng = tfhe.Engine(tfhe.default_params(q_bits=49, glwe_noise=2.0 ** -41) if unroll else None)
+    if unroll:
+        eng.set_bsk_unroll(2)                            # the unrolled bootstrap key travels with the broadcast key set
     eng.keygen_shared()                                  # CSPRNG keys made on rank 0, broadcast to the other rank
     emi = EncryptedMatrixInversion(2, None, 2, c["len"], c["ints"], False, False, engine=eng, shard_threshold=48)
     M = np.array(c["M"]).reshape(2, 2)
@@ -361,7 +363,8 @@ def _two_rank_worker(rank, world, port, out_dir, tag):
     eng.close()
 
 
-def test_two_rank_sharded_encrypted_inverse(tmp_path):
+@pytest.mark.parametrize("unroll", [False, True], ids=["plain_key", "unrolled_key"])
+def test_two_rank_sharded_encrypted_inverse(tmp_path, unroll):
     """SURVEY 8e on the inverse itself: levels >= 48 wide are split over two ranks, narrower ones replicated;
     both ranks must decrypt the reference's digits."""
     import socket
@@ -372,7 +375,7 @@ def test_two_rank_sharded_encrypted_inverse(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), tag), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), tag, unroll), nprocs=2, join=True)
     for r in range(2):
         assert np.load(tmp_path / f"out{r}.npy").tolist() == c["out"], r
     sharded, total, world = np.load(tmp_path / "meta0.npy")
