@@ -457,10 +457,12 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
         if (hipMemcpy(c->d_tw_half, th.data(), th.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(half-transform twiddles) failed");
     }
-    if (c->f64() && !c->wide() && !c->quad()) {   // psi^x for the unrolled blind rotation (X^c at the root psi^e is psi^(e c))
-        std::vector<u64> rp(2 * c->N);
+    if (c->f64() && !c->quad()) {   // psi^x for the unrolled blind rotation (X^c at the root psi^e is psi^(e c))
+        // N = 1024: psi = psi_2048, x in [0, 2048).  N = 2048: psi = psi_4096, x in [0, 2048) (the upper half is the negative)
+        std::vector<u64> rp(2048);
+        const u64 psi = c->wide() ? c->f.pow(f49::GEN, (c->f.q - 1) / 4096) : (u64)nttf::PSI_U;
         rp[0] = 1;
-        for (uint32_t x = 1; x < 2 * c->N; x++) rp[x] = c->f.mul(rp[x - 1], nttf::PSI_U);
+        for (uint32_t x = 1; x < 2048; x++) rp[x] = c->f.mul(rp[x - 1], psi);
         const std::vector<double> rpd = to_centred_doubles(rp);
         if (hipMalloc(&c->d_root_pow, rpd.size() * 8) != hipSuccess) return bail("hipMalloc(root powers) failed");
         if (hipMemcpy(c->d_root_pow, rpd.data(), rpd.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
@@ -676,7 +678,8 @@ int upload_bsk3(bmi_ctx *c) {
         return fail(c, -2, "hipMalloc(unrolled key) failed");
     }
     HIP_OK(c, hipMemcpy(d_tmp, c->bsk3_std.data(), words * 8, hipMemcpyHostToDevice));
-    const int rc = bmi49::launch_bsk_to_lat(d_tmp, c->d_bsk3_lat, c->d_tw_half, (uint32_t)(words / c->N), true, c->stream);
+    const int rc = c->wide() ? bmi49::launch_bsk_to_wide(d_tmp, c->d_bsk3_lat, (const double *)c->d_tw, c->d_tw_wide, (uint32_t)(words / c->N), c->stream)
+                             : bmi49::launch_bsk_to_lat(d_tmp, c->d_bsk3_lat, c->d_tw_half, (uint32_t)(words / c->N), true, c->stream);
     if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat (unrolled key) launch failed"); }
     HIP_OK(c, hipStreamSynchronize(c->stream));
     HIP_OK(c, hipFree(d_tmp));
@@ -930,8 +933,10 @@ int bmi_set_bsk_precision(bmi_ctx *c, uint32_t bits) {
 int bmi_set_bsk_unroll(bmi_ctx *c, uint32_t factor) {
     if (!c) return -1;
     if (factor != 1 && factor != 2) return fail(c, -1, "the unrolling factor is 1 or 2");
-    if (factor == 2 && !(c->f64() && !c->wide() && !c->quad()))
-        return fail(c, -1, "bootstrap-key unrolling has a HIP kernel for the 49-bit field at N = 1024 only");
+    if (factor == 2 && !(c->f64() && !c->quad()))
+        return fail(c, -1, "bootstrap-key unrolling has HIP kernels for the 49-bit field at N = 1024 and N = 2048 only");
+    if (factor == 2 && c->wide() && c->P.bs_levels > 2)
+        return fail(c, -1, "at N = 2048 the unrolled kernel exists for l <= 2 (at l = 3 it would not fit the registers: the plain kernel is faster)");
     c->unroll = factor;
     if (factor == 2 && c->have_keys && !c->have_bsk3) {
         if (!c->have_secret) return 0;   // evaluation-only context: the key arrives through bmi_import_bsk_unrolled
@@ -952,8 +957,8 @@ int bmi_set_bsk_unroll(bmi_ctx *c, uint32_t factor) {
 
 int bmi_import_bsk_unrolled(bmi_ctx *c, const uint64_t *bsk3) {
     if (!c || !bsk3) return -1;
-    if (!(c->f64() && !c->wide() && !c->quad()))
-        return fail(c, -1, "bootstrap-key unrolling has a HIP kernel for the 49-bit field at N = 1024 only");
+    if (!(c->f64() && !c->quad()))
+        return fail(c, -1, "bootstrap-key unrolling has HIP kernels for the 49-bit field at N = 1024 and N = 2048 only");
     if (!c->have_keys) return fail(c, -1, "no keys: import or generate the key set first");
     const size_t words = c->bsk3_words();
     for (size_t i = 0; i < words; i++)
@@ -1085,6 +1090,12 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     if (c->f64()) {
         const double *luts = (const double *)c->d_luts, *bsk = (const double *)c->d_bsk, *tw = (const double *)c->d_tw;
         hipStream_t st = (hipStream_t)stream;
+        if (c->wide() && c->unroll == 2) {   // N = 2048 with the unrolled key
+            if (!c->have_bsk3) return fail(c, -1, "unrolling selected but the context holds no unrolled key: generate keys after bmi_set_bsk_unroll, or bmi_import_bsk_unrolled");
+            rc = bmi49::launch_blind_rotate_wide_u(d_small, d_lut_ids, luts, c->d_bsk3_lat, tw, c->d_tw_wide, c->d_root_pow, d_out, count,
+                                                   c->P.n, c->P.bs_levels, c->P.bs_base_log, st);
+            return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+        }
         if (c->wide() || c->quad()) {   // N = 2048 / 4096: one kernel for every batch size
             rc = c->quad() ? bmi49::launch_blind_rotate_quad(d_small, d_lut_ids, luts, c->d_bsk_lat, tw, c->d_tw_wide, d_out, count, c->P.n, st)
                            : bmi49::launch_blind_rotate_wide(d_small, d_lut_ids, luts, c->d_bsk_lat, tw, c->d_tw_wide, d_out, count, c->P.n,

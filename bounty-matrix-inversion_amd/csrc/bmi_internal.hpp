@@ -113,6 +113,10 @@ int launch_bsk_to_wide(const u64 *std_polys, double *wide_polys, const double *g
 int launch_blind_rotate_wide(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk_wide,
                              const double *g_tw, const double *g_tw_wide, u64 *out, uint32_t count, uint32_t n,
                              uint32_t levels, uint32_t base_log, hipStream_t s);
+// N = 2048 with the unrolled key: bsk3_wide = launch_bsk_to_wide of the unrolled key, g_root_pow = psi_4096^x for x in [0, 2048)
+int launch_blind_rotate_wide_u(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk3_wide,
+                               const double *g_tw, const double *g_tw_wide, const double *g_root_pow, u64 *out, uint32_t count,
+                               uint32_t n, uint32_t levels, uint32_t base_log, hipStream_t s);
 // latency kernel, two wavefronts per transform (ntt_half_f64.hpp): own key copy in slot order, own twiddle tables
 // paired: A_lo[p], A_hi[p] side by side (one 16-byte request per slot; the unrolled kernel's layout), else [A_lo 512][A_hi 512]
 int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, bool paired, hipStream_t s);

@@ -909,6 +909,214 @@ __global__ void __launch_bounds__(W_THREADS)
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// N = 2048 with the UNROLLED bootstrap key (bmi_set_bsk_unroll(ctx, 2); scheme in bmi_kernels_f64u.hip): the structure of
+// k_blind_rotate_wide49 with one step per PAIR of LWE coefficients.  The forward tasks decompose ACC itself (no rotation) and
+// run once per pair; per round of GGSW rows the multiply phase walks the three keys of the pair (the next key's rows are
+// requested while this one is multiplied), reduces each key's partial sum and scales it by  psi^(e c_j) - 1  (psi = psi_4096,
+// e = 2 kk + 1 the root of the slot, + 2048 for the upper half: a sign; 2,048 root powers in LDS) before it joins the single
+// accumulator pair of the item - three accumulator pairs per item would not fit the registers next to two keys' rows.
+constexpr int WU_LDS_WORDS = W_LDS_WORDS + W_N;
+static_assert(WU_LDS_WORDS <= BMI_LDS_WORDS_MAX, "WU_LDS_WORDS exceeds the 160 KB of LDS");
+
+template <int L = 3, int BG = 15>
+__global__ void __launch_bounds__(W_THREADS)
+    k_blind_rotate_wide49u(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
+                           const double *__restrict__ luts, const double *__restrict__ bsk3_wide,
+                           const double *__restrict__ g_tw, const double *__restrict__ g_tw_wide,
+                           const double *__restrict__ g_root_pow, u64 *__restrict__ out, uint32_t count, uint32_t n) {
+    extern __shared__ double lds[];
+    double *acc = lds + TW_WORDS + 2 * N;            // [2 components][2 parities][1024]
+    double *tiles = acc + 2 * W_N;                   // [8][SCRATCH_WORDS]; rows 0-3 also carry the sums to the inverse
+    uint16_t *at = reinterpret_cast<uint16_t *>(tiles + 8 * SCRATCH_WORDS);
+    double *RP = tiles + 8 * SCRATCH_WORDS + BMI_AT_WORDS;   // psi_4096^x, x in [0, 2048); psi^(x + 2048) = -psi^x
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < TW_WORDS; i += W_THREADS) lds[i] = g_tw[i];
+    for (int i = tid; i < 2 * N; i += W_THREADS) lds[W_T + i] = g_tw_wide[i];
+    for (int i = tid; i < W_N; i += W_THREADS) RP[i ^ ((i >> 5) & 31)] = g_root_pow[i];   // folded against bank conflicts
+    const uint32_t ct = blockIdx.x;
+    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
+    for (uint32_t i = tid; i <= n; i += W_THREADS) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 2);
+    __syncthreads();
+    {
+        const double *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * W_N;
+        const uint32_t bt = at[n];
+        for (uint32_t nn = tid; nn < (uint32_t)W_N; nn += W_THREADS) {
+            const uint32_t e = (nn + bt) & (2 * W_N - 1);
+            const double v = tv[e & (W_N - 1)];
+            acc[(nn & 1) * N + (nn >> 1)] = 0.0;
+            acc[W_N + (nn & 1) * N + (nn >> 1)] = (e & W_N) ? -v : v;
+        }
+    }
+    __syncthreads();
+    // root exponents of this thread's four (output, slot) items: slot p = V * 64 + l of the wave transform holds the value at
+    // psi_4096^(2 kk + 1), kk = (l >> 2) + 16 (4 (V >> 2) + (l & 3)) + 256 (V & 3) (the table T of the even / odd combination)
+    uint32_t root_e[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t p = (tid + W_THREADS * q) & (N - 1), l = p & 63, V = p >> 6;
+        root_e[q] = 2 * ((l >> 2) + 16 * (4 * (V >> 2) + (l & 3)) + 256 * (V & 3)) + 1;
+    }
+    const uint32_t pairs = (n + 1) >> 1;
+
+    for (uint32_t ip = 0; ip < pairs; ip++) {
+        const uint32_t a1 = at[2 * ip], a2 = (2 * ip + 1 < n) ? at[2 * ip + 1] : 0u;
+        if ((a1 | a2) == 0) continue;  // uniform over the workgroup
+        const uint32_t cj[3] = {(a1 + a2) & (2 * W_N - 1), a1, a2};
+        const double *bi = bsk3_wide + (size_t)ip * 3 * 4 * L * W_N;   // [3 keys][2 L rows][2 outputs][1024 slots][A, A + 1024]
+        double ylo[4], yhi[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) ylo[q] = yhi[q] = 0.0;
+        // one round: GGSW rows R0 .. R0 + NR - 1 (row = 3 * input polynomial + level), 2 NR half-transform tasks
+        auto round = [&](auto R0_, auto NR_) {
+            constexpr int R0 = R0_, NR = NR_;
+            double b[4][NR][2];   // key 0's words of this thread's four (output, slot) items
+            auto load_rows = [&](double (&dst)[4][NR][2], int key, auto RA_, auto RB_) {
+                static_for<RA_, RB_>([&](auto R) {
+                    constexpr int r = R;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int idx = tid + W_THREADS * q, o = idx >> 10, p = idx & (N - 1);
+                        const double2 w = reinterpret_cast<const double2 *>(bi + ((size_t)key * 4 * L + (R0 + r) * 2 + o) * W_N)[p];
+                        dst[q][r][0] = w.x;
+                        dst[q][r][1] = w.y;
+                    }
+                });
+            };
+            using IC0 = std::integral_constant<int, 0>;
+            using ICN = std::integral_constant<int, NR>;
+            constexpr int S1 = NR / 4, S2 = NR / 2, S3 = (3 * NR + 3) / 4;   // key 0's rows are requested in four stages (BMI_WIDE_STAGE 2)
+            if (wave < 2 * NR) {
+                load_rows(b, 0, IC0(), std::integral_constant<int, S1>());
+                pin();
+                const int row = R0 + (wave >> 1), c = row / L, lev = row % L, h = wave & 1;
+                const double *ac = acc + c * W_N + h * N;
+                double x[16];
+                prio<3>();
+                static_for<0, 16>([&](auto J) { x[J] = Dec<L, BG>::digit(round_half_up(ac[lane + 64 * J], Dec<L, BG>::SC), lev); });
+                pin();
+                load_rows(b, 0, std::integral_constant<int, S1>(), std::integral_constant<int, S2>());
+                pin();
+                double *tile = tiles + wave * SCRATCH_WORDS;
+                prio<2>();
+                forward(
+                    x, lane, lds, tile,
+                    [&]() {
+                        prio<1>();
+                        load_rows(b, 0, std::integral_constant<int, S2>(), std::integral_constant<int, S3>());
+                    },
+                    [&]() {
+                        prio<0>();
+                        load_rows(b, 0, std::integral_constant<int, S3>(), ICN());
+                    });
+                if (h) static_for<0, 16>([&](auto V) { x[V] = f49::mul(x[V], lds[W_T + V * 64 + lane]); });
+                wave_sync();
+                static_for<0, 16>([&](auto V) { tile[V * 64 + lane] = f49::red(x[V]); });
+            } else {
+                load_rows(b, 0, IC0(), ICN());
+            }
+            __syncthreads();
+            // key 0's rows are all here (b); the rows of keys 1 and 2 arrive in chunks of two, the next chunk requested while
+            // this one is multiplied (two keys' worth of rows next to b do not fit the registers: 544 bytes of spills per lane)
+            constexpr int CR = 2, NCH = NR / CR, NS = 2 * NCH;   // chunk s = (key 1 + s / NCH, rows of chunk s % NCH)
+            double ck[2][4][CR][2];
+            auto load_chunk = [&](auto S) {
+                constexpr int sidx = S, key = 1 + sidx / NCH, ch = sidx % NCH;
+#pragma unroll
+                for (int r = 0; r < CR; r++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int idx = tid + W_THREADS * q, o = idx >> 10, p = idx & (N - 1);
+                        const double2 w = reinterpret_cast<const double2 *>(bi + ((size_t)key * 4 * L + (R0 + ch * CR + r) * 2 + o) * W_N)[p];
+                        ck[sidx & 1][q][r][0] = w.x;
+                        ck[sidx & 1][q][r][1] = w.y;
+                    }
+            };
+            auto scale = [&](double (&plo)[4], double (&phi)[4], uint32_t c) {   // key's partial sums * (psi^(e c) - 1) -> accumulators
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t xe = root_e[q] * c;                         // exponent mod 4096: bit 11 is a sign
+                    const uint32_t xi = xe & (W_N - 1);
+                    double w = RP[xi ^ ((xi >> 5) & 31)];
+                    w = (xe & W_N) ? -w : w;
+                    const double wh = (c & 1) ? -w : w;                        // the root of the upper half is -psi^e
+                    ylo[q] += f49::mul(f49::red(plo[q]), w - 1.0);
+                    yhi[q] += f49::mul(f49::red(phi[q]), wh - 1.0);
+                }
+            };
+            load_chunk(std::integral_constant<int, 0>());
+            {
+                double plo[4], phi[4];   // lazy sums of NR <= four products
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int p = (tid + W_THREADS * q) & (N - 1);
+                    plo[q] = phi[q] = 0.0;
+#pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        const double e = tiles[(2 * r) * SCRATCH_WORDS + p], od = tiles[(2 * r + 1) * SCRATCH_WORDS + p];
+                        plo[q] += f49::mul(e + od, b[q][r][0]);
+                        phi[q] += f49::mul(e - od, b[q][r][1]);
+                    }
+                }
+                scale(plo, phi, cj[0]);
+            }
+            double plo[4], phi[4];
+            static_for<0, NS>([&](auto S) {
+                constexpr int sidx = S, key = 1 + sidx / NCH, ch = sidx % NCH;
+                if constexpr (sidx + 1 < NS) load_chunk(std::integral_constant<int, sidx + 1>());
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int p = (tid + W_THREADS * q) & (N - 1);
+                    if constexpr (ch == 0) plo[q] = phi[q] = 0.0;
+#pragma unroll
+                    for (int r = 0; r < CR; r++) {
+                        const int rr = ch * CR + r;
+                        const double e = tiles[(2 * rr) * SCRATCH_WORDS + p], od = tiles[(2 * rr + 1) * SCRATCH_WORDS + p];
+                        plo[q] += f49::mul(e + od, ck[sidx & 1][q][r][0]);
+                        phi[q] += f49::mul(e - od, ck[sidx & 1][q][r][1]);
+                    }
+                }
+                if constexpr (ch == NCH - 1) scale(plo, phi, cj[key]);
+            });
+            __syncthreads();   // the tiles are rewritten by the next round / the sums below
+        };
+        // 2 L <= four GGSW rows: one round (eight half-transform tasks, one per wavefront)
+        static_assert(L <= 2, "see above");
+        round(std::integral_constant<int, 0>(), std::integral_constant<int, 2 * L>());
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int idx = tid + W_THREADS * q, o = idx >> 10, p = idx & (N - 1);
+            const double lo = f49::red(ylo[q]), hi = f49::red(yhi[q]);
+            tiles[(o * 2 + 0) * SCRATCH_WORDS + p] = f49::red(lo + hi);   // inverse() takes |.| <= 0.51 q
+            tiles[(o * 2 + 1) * SCRATCH_WORDS + p] = lo - hi;             // reduced by the multiplication with T^-1
+        }
+        __syncthreads();
+        if (wave < 4) {
+            const int o = wave >> 1, h = wave & 1;
+            double *tile = tiles + wave * SCRATCH_WORDS;   // row (o, h): read into registers, then the transpose scratch
+            double x[16];
+            static_for<0, 16>([&](auto V) { x[V] = tile[V * 64 + lane]; });
+            if (h) static_for<0, 16>([&](auto V) { x[V] = f49::mul(x[V], lds[W_T + N + V * 64 + lane]); });
+            wave_sync();
+            inverse(x, lane, lds, tile);
+            double *ao = acc + o * W_N + h * N;
+            static_for<0, 16>([&](auto J) { ao[lane + 64 * J] = f49::red(ao[lane + 64 * J] + x[J]); });
+        }
+        __syncthreads();
+    }
+    u64 *o = out + (size_t)ct * (W_N + 1);
+    for (uint32_t nn = tid; nn < (uint32_t)W_N; nn += W_THREADS) {
+        const double a0 = acc[(nn & 1) * N + (nn >> 1)];
+        if (nn == 0) {
+            o[0] = f49::to_u(a0);
+            o[W_N] = f49::to_u(acc[W_N]);
+        } else {
+            o[W_N - nn] = f49::to_u(-a0);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
 // Third parameter set, N = 4096: the same construction one level deeper.  a is split by index mod 4 into four
 // 1024-coefficient parts a_j; with psi = psi_8192 (psi^4 is the 2048th root of the wave transform) and S_j = NTT1024(a_j):
 //     A[kk + 1024 t] = sum_j i^(t j) T_j[kk] S_j[kk],   T_j = psi^((2 kk + 1) j),   i = psi^2048 (i^2 = -1),
@@ -1263,6 +1471,36 @@ int launch_blind_rotate_wide(const u64 *small_cts, const uint32_t *lut_ids, cons
     if (count == 0) return 0;
     launch10_t f = pick_wide(levels, base_log);
     return f ? f(small_cts, lut_ids, luts, bsk_wide, g_tw, g_tw_wide, out, count, n, s) : (int)hipErrorInvalidValue;
+}
+
+template <int L, int BG>
+struct LaunchWideU {
+    static int go(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk3_wide, const double *g_tw,
+                  const double *g_tw_wide, const double *g_root_pow, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+        static std::atomic<uint64_t> configured{0};
+        const size_t lds = (size_t)WU_LDS_WORDS * sizeof(double);
+        auto kern = k_blind_rotate_wide49u<L, BG>;
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
+        hipLaunchKernelGGL(kern, dim3(count), dim3(W_THREADS), lds, s, small_cts, lut_ids, luts, bsk3_wide, g_tw, g_tw_wide,
+                           g_root_pow, out, count, n);
+        BMI49_LAUNCH_CHECK();
+        return 0;
+    }
+};
+typedef int (*launch11_t)(const u64 *, const uint32_t *, const double *, const double *, const double *, const double *,
+                          const double *, u64 *, uint32_t, uint32_t, hipStream_t);
+static launch11_t pick_wide_u(uint32_t levels, uint32_t base_log) {
+    if (levels == 2 && base_log == 15) return LaunchWideU<2, 15>::go;
+    if (levels == 1 && base_log == 23) return LaunchWideU<1, 23>::go;
+    return nullptr;
+}
+
+int launch_blind_rotate_wide_u(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk3_wide,
+                               const double *g_tw, const double *g_tw_wide, const double *g_root_pow, u64 *out, uint32_t count,
+                               uint32_t n, uint32_t levels, uint32_t base_log, hipStream_t s) {
+    if (count == 0) return 0;
+    launch11_t f = pick_wide_u(levels, base_log);
+    return f ? f(small_cts, lut_ids, luts, bsk3_wide, g_tw, g_tw_wide, g_root_pow, out, count, n, s) : (int)hipErrorInvalidValue;
 }
 
 int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, bool paired, hipStream_t s) {

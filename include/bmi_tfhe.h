@@ -193,11 +193,13 @@ int bmi_set_kernel_variant(bmi_ctx *ctx, int variant);
  * noise to valid LWE samples; generating the key on the grid directly would instead round its own noise away.) */
 int bmi_set_bsk_precision(bmi_ctx *ctx, uint32_t bits);
 
-/* 49-bit field at N = 1024: bootstrap-key unrolling (Zhou et al. 2018, Bourse et al. 2018; unrolling factor 2).
+/* 49-bit field at N = 1024, and at N = 2048 with l <= 2 (the secure128 shape): bootstrap-key unrolling (Zhou et al. 2018,
+ * Bourse et al. 2018; unrolling factor 2).
  * factor 1 (default): the blind rotation of CGGI, one LWE coefficient per step.  factor 2: a step absorbs two coefficients,
  *   ACC <- ACC + sum_{j<3} (X^(c_j) - 1) (K_j [.] ACC),  c = (a + a', a, a'),  K = GGSW(s s'), GGSW(s (1 - s')), GGSW((1 - s) s'),
  * with one decomposition and one set of forward transforms per step (half as many as the plain rotation; the factors X^c - 1
- * are applied in the transform domain).  Every batch size then runs k_blind_rotate_lat2u_49 (one workgroup per ciphertext).
+ * are applied in the transform domain).  Every batch size then runs k_blind_rotate_lat2u_49 (N = 1024) or
+ * k_blind_rotate_wide49u (N = 2048), one workgroup per ciphertext.
  * The unrolled key (1.5 x the plain key's size) is generated by the next keygen call, or at once when the context already
  * holds secret keys; an evaluation-only context receives it through bmi_import_bsk_unrolled.  Layout:
  * [ceil(n/2)][3][(k+1) l][(k+1)][N] words, standard domain (an odd n is completed by a zero key bit).  Price: the key-noise

@@ -23,7 +23,7 @@ def _oracle(eng, bsk3=None):
     from oracle import tfhe_oracle as to
     to.set_field(49)
     sk_small, sk_big, bsk, ksk = eng.export_keys()
-    P = to.default_params(q_bits=49, n=eng.P.n, bs_levels=eng.P.bs_levels, bs_base_log=eng.P.bs_base_log)
+    P = to.default_params(q_bits=49, n=eng.P.n, log_N=eng.P.log_N, bs_levels=eng.P.bs_levels, bs_base_log=eng.P.bs_base_log)
     ctx = to.Ctx(P, bsk, ksk)
     ctx.set_bsk_unrolled(eng.export_bsk_unrolled() if bsk3 is None else bsk3)
     return to, P, ctx, sk_small, sk_big
@@ -86,8 +86,9 @@ def test_unrolled_blind_rotation_extreme_inputs(eng):
     ctx.close()
 
 
-@pytest.mark.parametrize("kw", [dict(n=629), dict(n=1024), dict(bs_levels=2), dict(bs_levels=1, bs_base_log=23), dict(n=1)],
-                         ids=["odd_n", "n1024", "l2", "l1", "n1"])
+@pytest.mark.parametrize("kw", [dict(n=629), dict(n=1024), dict(bs_levels=2), dict(bs_levels=1, bs_base_log=23), dict(n=1),
+                                dict(log_N=11, bs_levels=2), dict(log_N=11, bs_levels=2, n=741), dict(log_N=11, bs_levels=1, bs_base_log=23)],
+                         ids=["odd_n", "n1024", "l2", "l1", "n1", "N2048_l2", "N2048_l2_odd_n", "N2048_l1"])
 def test_unrolled_other_shapes_bit_exact(kw):
     e = _engine(seed=77, **kw)
     try:
@@ -105,6 +106,17 @@ def test_unrolled_other_shapes_bit_exact(kw):
         ctx.close()
     finally:
         e.close()
+
+
+def test_unrolling_is_refused_where_no_kernel_exists():
+    from bmi_amd import tfhe
+    for kw in (dict(q_bits=49, log_N=11), dict(q_bits=49, log_N=12), dict(q_bits=65), dict(q_bits=64)):
+        e = tfhe.Engine(tfhe.default_params(**kw))
+        try:
+            with pytest.raises(tfhe.BmiError):
+                e.set_bsk_unroll(2)
+        finally:
+            e.close()
 
 
 def test_unrolled_key_under_csprng_and_on_an_evaluation_only_context():
@@ -213,3 +225,74 @@ def test_encrypted_inverse_with_the_unrolled_key_matches_reference_golden(tag, c
             print(f"\nunrolled key, {tag}: evaluate {wall:.2f} s, {emi.circuit.summary()['depth']} levels, {wall / emi.circuit.summary()['depth'] * 1e3:.2f} ms per level")
     finally:
         emi.engine.close()
+
+
+def test_secure128_preset_with_the_unrolled_key(capsys):
+    """The 128-bit-secure preset (n 742, N 2048, l = 2) on the unrolled key: bit-exact against the oracle's unrolled mode under
+    CSPRNG keys, output noise on the 3 x formula and still far below the keyswitch noise it feeds (the look-up margin is set by
+    the latter), latency beside the plain kernel's, and the encrypted 2x2 inverse decrypting to the reference's digits."""
+    import json, os
+    from bmi_amd import tfhe
+    from bmi_amd.main import EncryptedMatrixInversion
+    from oracle import tfhe_oracle as to
+    P = tfhe.preset_params("secure128")
+    e = tfhe.Engine(P)
+    plain = tfhe.Engine(P)
+    try:
+        e.set_bsk_unroll(2)
+        e.keygen()
+        plain.keygen()
+        to.set_field(49)
+        OP = to.Params(**{f: getattr(P, f) for f, _ in tfhe.Params._fields_})
+        sk_small, sk_big, bsk, ksk = e.export_keys()
+        ctx = to.Ctx(OP, bsk, ksk)
+        ctx.set_bsk_unrolled(e.export_bsk_unrolled())
+        rng = np.random.default_rng(43)
+        dl = e.delta_log()
+        table = rng.integers(-8, 8, 16)
+        lid = e.lut_register(table, 4, dl)
+        msgs = np.concatenate([np.arange(-8, 8)] * 64)                    # 1,024 ciphertexts
+        ct = e.encrypt(msgs, dl)
+        out = e.pbs_host(ct, np.full(msgs.size, lid, np.uint32))
+        assert np.array_equal(e.decrypt(out, dl), table[msgs + 8])
+        pick = rng.choice(msgs.size, 5, replace=False)
+        assert np.array_equal(out[pick], ctx.pbs(ct[pick], e.lut_get(lid)[None, :], np.zeros(5, np.uint32), unrolled=True))
+        Q = e.modulus
+        want_m = table[msgs + 8]
+        oerr = np.array([((int(x) - (int(m) << dl)) + Q // 2) % Q - Q // 2 for x, m in zip(e.phase(out), want_m)], dtype=np.float64) / Q
+        Bg = 2.0 ** P.bs_base_log
+        key_term = P.n * P.bs_levels * 2 * P.N * (Bg * Bg + 2) / 12 * P.glwe_noise ** 2
+        dec_term = P.n * (1 + P.N / 2) / (12 * Bg ** (2 * P.bs_levels))
+        ratio = float(np.var(oerr)) / (3 * key_term + dec_term / 2)
+        B = 2.0 ** P.ks_base_log
+        ks_var = P.N * P.ks_levels * (B * B + 2) / 12.0 * P.lwe_noise ** 2      # keyswitch noise (measured at this value in test_gpu_parity)
+        assert 0.8 < ratio < 1.25 and np.var(oerr) * 75 ** 2 < ks_var / 4        # x75: the widest linear combination of the circuits
+        t = {}
+        for name, en in (("unrolled", e), ("plain", plain)):
+            l2 = en.lut_register(table, 4, dl)
+            c2 = en.encrypt(msgs[:256], dl)
+            small = en.keyswitch_host(c2)
+            for cnt in (1, 256):
+                ids = np.full(cnt, l2, np.uint32)
+                en.blind_rotate_host(small[:cnt], ids)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    en.blind_rotate_host(small[:cnt], ids)
+                t[(name, cnt)] = (time.perf_counter() - t0) / 3 * 1e3
+        with open(os.path.join(os.path.dirname(__file__), "golden", "inverse.json")) as f:
+            c = next(x for x in json.load(f) if x["tag"] == "baseline_n2_len20_ints8")
+        emi = EncryptedMatrixInversion(2, None, 2, c["len"], c["ints"], False, False, engine=e)
+        q, s = emi.quantize(np.array(c["M"]).reshape(2, 2))
+        enc = emi.encrypt(q, s)
+        emi.evaluate(enc)
+        t0 = time.time()
+        res = emi.evaluate(enc)
+        wall = time.time() - t0
+        assert emi.decrypt(res).tolist() == c["out"]
+        with capsys.disabled():
+            print(f"\nsecure128 + unrolled key: output log2 std {0.5 * np.log2(np.var(oerr)):.2f} (variance / formula {ratio:.3f}); blind rotation ms "
+                  + ", ".join(f"{k[0]} x{k[1]}: {v:.2f}" for k, v in t.items()) + f"; encrypted 2x2 inverse {wall:.2f} s")
+        ctx.close()
+    finally:
+        e.close()
+        plain.close()

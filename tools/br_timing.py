@@ -13,7 +13,7 @@ def main():
     batches = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,64,4096").split(",")]
     variants = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1").split(",")]
     qb = int(sys.argv[3]) if len(sys.argv) > 3 else None
-    kw = {k[5:].lower(): int(v) for k, v in os.environ.items() if k.startswith("BMIP_")}   # e.g. BMIP_BS_LEVELS=2
+    kw = {{"log_n": "log_N"}.get(k[5:].lower(), k[5:].lower()): int(v) for k, v in os.environ.items() if k.startswith("BMIP_")}   # e.g. BMIP_BS_LEVELS=2, BMIP_LOG_N=11
     eng = tfhe.Engine(tfhe.default_params(q_bits=qb, **kw))
     if os.environ.get('BMI_BSK_PRECISION'): eng.set_bsk_precision(int(os.environ['BMI_BSK_PRECISION']))
     unroll = int(os.environ.get('BMI_UNROLL', '1'))   # 2: the unrolled blind rotation (one kernel for every variant / batch)
@@ -33,9 +33,9 @@ def main():
         small = eng.keyswitch_host(ct)
         d_small = torch.from_numpy(small.view(np.int64)).to(dev)
         d_ids = torch.full((B,), lid, dtype=torch.int32, device=dev)
-        d_out = torch.empty((B, 1025), dtype=torch.int64, device=dev)
+        d_out = torch.empty((B, eng.P.N + 1), dtype=torch.int64, device=dev)
         d_in = torch.from_numpy(ct.view(np.int64)).to(dev)
-        d_ks = torch.empty((B, 631), dtype=torch.int64, device=dev)
+        d_ks = torch.empty((B, eng.P.n + 1), dtype=torch.int64, device=dev)
         nchk = min(B, 4)
         want = octx.blind_rotate(small[:nchk], tv, np.zeros(nchk, np.uint32), unrolled=unroll == 2)
         for v in variants:
