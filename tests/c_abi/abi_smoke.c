@@ -60,6 +60,24 @@ int main(void) {
     CHECK(bmi_keygen_insecure_deterministic(ctx, 42) == 0 && bmi_encrypt(ctx, msgs, 5, DL, ct) == 0, "seeded keygen");
     CHECK(bmi_keygen_insecure_deterministic(ctx, 42) == 0 && bmi_encrypt(ctx, msgs, 5, DL, ct2) == 0, "seeded keygen again");
     CHECK(memcmp(ct, ct2, 5 * big * 8) == 0, "seeded path is deterministic");
+    {
+        /* bootstrap-key unrolling: the unrolled key is derived from the secret keys the context holds; same look-ups, other
+         * ciphertext bits; export / import round trip; refused where no kernel exists */
+        CHECK(bmi_set_bsk_unroll(ctx, 3) < 0, "unrolling factor 3 rejected");
+        CHECK(bmi_export_bsk_unrolled(ctx, out) < 0, "no unrolled key before bmi_set_bsk_unroll");
+        CHECK(bmi_set_bsk_unroll(ctx, 2) == 0, "unroll 2");
+        CHECK(bmi_lut_register(ctx, table, 4, DL, &lut) == 0, "lut");
+        for (int i = 0; i < 5; i++) ids[i] = lut;
+        CHECK(bmi_pbs_batch_host(ctx, ct, ids, 5, ct2) == 0 && bmi_decrypt(ctx, ct2, 5, DL, dec) == 0, "unrolled pbs");
+        for (int i = 0; i < 5; i++) CHECK(dec[i] == table[msgs[i] + 8], "LUT value (unrolled key)");
+        const size_t words3 = (size_t)((P.n + 1) / 2) * 3 * (P.k + 1) * P.bs_levels * (P.k + 1) * (1u << P.log_N);
+        uint64_t *bsk3 = (uint64_t *)malloc(words3 * 8);
+        CHECK(bsk3 && bmi_export_bsk_unrolled(ctx, bsk3) == 0 && bmi_import_bsk_unrolled(ctx, bsk3) == 0, "unrolled key export / import");
+        CHECK(bmi_pbs_batch_host(ctx, ct, ids, 5, out) == 0 && memcmp(out, ct2, 5 * big * 8) == 0, "same key, same ciphertexts");
+        CHECK(bmi_set_bsk_unroll(ctx, 1) == 0 && bmi_pbs_batch_host(ctx, ct, ids, 5, out) == 0 && memcmp(out, ct2, 5 * big * 8) != 0,
+              "back to the plain blind rotation");
+        free(bsk3);
+    }
     bmi_ctx_destroy(ctx);
 
     /* named presets; the 2^64 torus (Concrete's modulus) end to end; the compiler passes (context-free, CPU) */
@@ -68,6 +86,7 @@ int main(void) {
     CHECK(bmi_preset_params("no such set", &S) < 0, "unknown preset rejected");
     CHECK(bmi_preset_params("north_star_torus64", &S) == 0 && S.q_bits == BMI_Q_TORUS64, "torus preset");
     CHECK(bmi_ctx_create(&S, 0, &ctx) == 0, "torus context");
+    CHECK(bmi_set_bsk_unroll(ctx, 2) < 0, "no unrolled kernel on the torus");
     CHECK(bmi_keygen(ctx) == 0, "torus keygen");
     CHECK(bmi_lut_register(ctx, table, 4, 59, &lut) == 0, "torus lut");
     for (int i = 0; i < 5; i++) ids[i] = lut;
