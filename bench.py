@@ -402,6 +402,11 @@ def main():
                                                  "keeps the output noise of the default set; `achieved` / `frac` use the PLAIN key's bytes per PBS")
             except Exception as e:
                 res["unrolled_key_49"] = {"error": repr(e)}
+            # the same inverses, found next to the plain-key ones (the wall-clocks to quote for EncryptedMatrixInversion(unroll=True))
+            if isinstance(res["unrolled_key_49"].get("encrypted_inverse_wall_clock"), dict):
+                res["config"]["encrypted_inverse_wall_clock_unrolled_key"] = {
+                    k: {f: v.get(f) for f in ("len", "ints", "evaluate_s", "end_to_end_s", "ms_per_level", "pbs", "depth", "matches_plaintext_circuit")}
+                    for k, v in res["unrolled_key_49"]["encrypted_inverse_wall_clock"].items()}
 
     if not args.no_inverse and rank == 0 and world == 1:
         try:
