@@ -411,7 +411,7 @@ class Engine:
         self._ck(self.lib.bmi_set_bsk_precision(self.h, int(bits)), "bmi_set_bsk_precision")
 
     def set_bsk_unroll(self, factor):
-        """49-bit field, N = 1024: 1 = CGGI's blind rotation (default), 2 = two LWE coefficients per step with an unrolled
+        """49-bit field, N = 1024 (or N = 2048 with l <= 2): 1 = CGGI's blind rotation (default), 2 = two LWE coefficients per step with an unrolled
         bootstrap key (generated by the next keygen, or at once from the secret keys already held); include/bmi_tfhe.h"""
         self._ck(self.lib.bmi_set_bsk_unroll(self.h, int(factor)), "bmi_set_bsk_unroll")
         self.unroll = int(factor)
