@@ -342,6 +342,8 @@ class Engine:
         arrays = {"bsk": bsk, "ksk": ksk, "params": np.array([float(getattr(self.P, f)) for f in self._PARAM_FIELDS])}
         if secret:
             arrays.update(sk_small=sk_small, sk_big=sk_big)
+        if getattr(self, "unroll", 1) == 2:          # the unrolled bootstrap key travels with the set
+            arrays["bsk_unrolled"] = self.export_bsk_unrolled()
         with open(path, "wb") as f:
             np.savez(f, **arrays)
 
@@ -357,6 +359,11 @@ class Engine:
                 raise BmiError(f"key file parameters {theirs} differ from this context's {mine}")
             has_secret = "sk_small" in z.files
             self.import_keys(z["sk_small"] if has_secret else None, z["sk_big"] if has_secret else None, z["bsk"], z["ksk"])
+            if "bsk_unrolled" in z.files:            # written by a context in unrolled mode: this one switches to it too
+                self.set_bsk_unroll(2)
+                self.import_bsk_unrolled(z["bsk_unrolled"])
+            elif getattr(self, "unroll", 1) == 2 and has_secret:
+                self.set_bsk_unroll(2)               # no unrolled key in the file: derived from the secret keys just loaded
         return has_secret
 
     def key_bytes(self):

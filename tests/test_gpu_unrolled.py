@@ -151,6 +151,35 @@ def test_unrolled_key_under_csprng_and_on_an_evaluation_only_context():
         ev.close()
 
 
+def test_key_files_carry_the_unrolled_key(eng, tmp_path):
+    """Engine.save_keys / load_keys: an evaluation-only key file written in unrolled mode makes the loading (server) context
+    reproduce the writer's ciphertexts; a full key file without the unrolled key lets an unrolled-mode context derive its own"""
+    from bmi_amd import tfhe
+    rng = np.random.default_rng(17)
+    dl = eng.delta_log()
+    table = rng.integers(-8, 8, 16)
+    msgs = rng.integers(-8, 8, 7)
+    ct = eng.encrypt(msgs, dl)
+    got = eng.pbs_host(ct, np.full(7, eng.lut_register(table, 4, dl), np.uint32))
+    eng.save_keys(tmp_path / "eval_unrolled.npz", secret=False)
+    server = tfhe.Engine(tfhe.default_params(q_bits=49))
+    plain = tfhe.Engine(tfhe.default_params(q_bits=49))
+    client2 = tfhe.Engine(tfhe.default_params(q_bits=49))
+    try:
+        assert server.load_keys(tmp_path / "eval_unrolled.npz") is False
+        assert np.array_equal(server.pbs_host(ct, np.full(7, server.lut_register(table, 4, dl), np.uint32)), got)
+        plain.keygen(SEED)                                  # the same secret keys, plain mode: its key file has no unrolled key
+        plain.save_keys(tmp_path / "full_plain.npz")
+        client2.set_bsk_unroll(2)
+        assert client2.load_keys(tmp_path / "full_plain.npz") is True
+        out = client2.pbs_host(ct, np.full(7, client2.lut_register(table, 4, dl), np.uint32))
+        assert list(client2.decrypt(out, dl)) == [int(table[m + 8]) for m in msgs]
+    finally:
+        server.close()
+        plain.close()
+        client2.close()
+
+
 def test_unrolled_output_noise_on_the_formula_and_timing(eng, capsys):
     """4,096 bootstraps: output variance = 3 x the key-noise term of the CGGI value (+ the unchanged decomposition term);
     prints the per-bootstrap latency of the unrolled kernel next to the plain latency kernel's"""
