@@ -203,7 +203,9 @@ int bmi_set_bsk_precision(bmi_ctx *ctx, uint32_t bits);
  * The unrolled key (1.5 x the plain key's size) is generated by the next keygen call, or at once when the context already
  * holds secret keys; an evaluation-only context receives it through bmi_import_bsk_unrolled.  Layout:
  * [ceil(n/2)][3][(k+1) l][(k+1)][N] words, standard domain (an odd n is completed by a zero key bit).  Price: the key-noise
- * term of the output variance triples (three products per pair of coefficients, each scaled by X^c - 1); results are
+ * term of the output variance triples (three products per pair of coefficients, each scaled by X^c - 1) - size the GLWE noise
+ * for it: 2^-41 keeps the margin of the default (3, 2^15) set; a one-level (1, 2^23) decomposition needs about 2^-42 or less for
+ * 4-bit look-ups.  Results are
  * bit-exact against oracle/tfhe_oracle.c ora_blind_rotate_extract_unrolled on the same keys. */
 int bmi_set_bsk_unroll(bmi_ctx *ctx, uint32_t factor);
 int bmi_import_bsk_unrolled(bmi_ctx *ctx, const uint64_t *bsk3);

@@ -86,8 +86,11 @@ def test_unrolled_blind_rotation_extreme_inputs(eng):
     ctx.close()
 
 
-@pytest.mark.parametrize("kw", [dict(n=629), dict(n=1024), dict(bs_levels=2), dict(bs_levels=1, bs_base_log=23), dict(n=1),
-                                dict(log_N=11, bs_levels=2), dict(log_N=11, bs_levels=2, n=741), dict(log_N=11, bs_levels=1, bs_base_log=23)],
+# (l, Bg) = (1, 2^23): a 23-bit digit multiplies the key noise by 2^22 / sqrt(12); with three products per step the default
+# 2^-40 would leave 4-bit look-ups at 2.6 - 3.6 sigma, so those cases run at key noise 2^-46 (the bits are compared either way)
+@pytest.mark.parametrize("kw", [dict(n=629), dict(n=1024), dict(bs_levels=2), dict(bs_levels=1, bs_base_log=23, glwe_noise=2.0 ** -46), dict(n=1),
+                                dict(log_N=11, bs_levels=2), dict(log_N=11, bs_levels=2, n=741),
+                                dict(log_N=11, bs_levels=1, bs_base_log=23, glwe_noise=2.0 ** -46)],
                          ids=["odd_n", "n1024", "l2", "l1", "n1", "N2048_l2", "N2048_l2_odd_n", "N2048_l1"])
 def test_unrolled_other_shapes_bit_exact(kw):
     e = _engine(seed=77, **kw)

@@ -14,11 +14,14 @@ def main():
     budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
     log_N = int(sys.argv[3]) if len(sys.argv) > 3 else 10
     kw = {k[5:].lower(): int(v) for k, v in os.environ.items() if k.startswith("BMIP_")}   # e.g. BMIP_BS_LEVELS=2
-    eng = tfhe.Engine(tfhe.default_params(q_bits=qb, log_N=log_N, **kw)); eng.keygen(77)
+    unroll = int(os.environ.get("BMI_UNROLL", "1"))     # 2: the unrolled blind rotation (one kernel for every variant / batch size)
+    eng = tfhe.Engine(tfhe.default_params(q_bits=qb, log_N=log_N, **kw)); eng.set_bsk_unroll(unroll); eng.keygen(77)
     dl = eng.delta_log()
     _, _, bsk, ksk = eng.export_keys()
     to.set_field(qb)
     octx = to.Ctx(to.default_params(q_bits=qb, log_N=log_N, **kw), bsk, ksk)
+    if unroll == 2:
+        octx.set_bsk_unrolled(eng.export_bsk_unrolled())
     lb3 = (eng.P.bs_levels, eng.P.bs_base_log) == (3, 15)
     all_variants = (0, 1, 2, 3, 4) if (lb3 or qb == 65) else (0, 2, 3)     # variants 1 / 4 of the 49-bit field exist for (3, 2^15) only
     rng = np.random.default_rng(2024)
@@ -46,11 +49,11 @@ def main():
                 runs += 1
             eng.set_kernel_variant(0)
             pick = rng.choice(B, min(B, 3), replace=False)
-            assert np.array_equal(ref[pick], octx.pbs(ct[pick], tv, np.zeros(pick.size, np.uint32))), ("oracle", B)
+            assert np.array_equal(ref[pick], octx.pbs(ct[pick], tv, np.zeros(pick.size, np.uint32), unrolled=unroll == 2)), ("oracle", B)
             checked += pick.size
             if time.time() - t0 > budget:
                 break
         print(json.dumps({"elapsed_s": round(time.time() - t0, 1), "kernel_runs": runs, "oracle_checked": checked}), flush=True)
-    print("stress ok", json.dumps({"q_bits": qb, "log_N": log_N, **kw}))
+    print("stress ok", json.dumps({"q_bits": qb, "log_N": log_N, "unroll": unroll, **kw}))
 
 main()
