@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Many random matrices through the encrypted inverse on the GPU, each compared with the plaintext evaluation of the same
 compiled program (identical integers expected) and with numpy's inverse: an empirical look at the look-up failure rate
-(every 4-bit look-up sits at >= 5.6 sigma).  usage: gpu_random_inverses.py [n] [count] [q_bits]"""
+(every 4-bit look-up sits at >= 5.6 sigma).  usage: gpu_random_inverses.py [n] [count] [q_bits] [unroll]
+(unroll = 2: the unrolled bootstrap key at key noise 2^-41, what EncryptedMatrixInversion(unroll=True) runs)"""
 import json, os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "bounty-matrix-inversion_amd"))
@@ -14,7 +15,10 @@ def main():
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     qb = int(sys.argv[3]) if len(sys.argv) > 3 else 49
     ln, ints = {2: (20, 8), 3: (30, 12), 4: (40, 16)}[n]
-    eng = tfhe.Engine(tfhe.default_params(q_bits=qb)); eng.keygen()          # CSPRNG keys
+    unroll = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    eng = tfhe.Engine(tfhe.default_params(q_bits=qb, **({"glwe_noise": 2.0 ** -41} if unroll == 2 else {})))
+    eng.set_bsk_unroll(unroll)
+    eng.keygen()          # CSPRNG keys
     emi = EncryptedMatrixInversion(n, None, 2, ln, ints, False, False, engine=eng)
     rng = np.random.default_rng(4242 + n)
     wrong = skipped = 0; pbs = emi.program.n_nodes; worst = 0.0; t0 = time.time()
@@ -33,7 +37,7 @@ def main():
     done = count - skipped
     print(json.dumps({"n": n, "q_bits": qb, "matrices": done, "mismatching_the_plaintext_circuit": wrong, "lookups_total": done * pbs,
                       "lookups_per_inverse": pbs, "worst_abs_err_vs_numpy_among_matching": worst, "seconds": round(time.time() - t0, 1),
-                      "keys": "CSPRNG"}))
+                      "keys": "CSPRNG", "unroll": unroll}))
     eng.close()
     return 1 if wrong else 0
 
