@@ -21,6 +21,7 @@ namespace {
 // Phase timing (debug build only: make prof; tools/phase_prof.py with unroll = 2)
 #ifdef BMI_PHASE_PROF
 __device__ unsigned long long g_phase_u[128];
+__device__ unsigned long long g_wg_times_u[1024][2];   // [workgroup][start, end] in ticks of the 100 MHz real-time counter
 #define PH_DECL() unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = clock64()
 #define PH_MARK(k)                               \
     do {                                         \
@@ -53,6 +54,9 @@ __global__ void __launch_bounds__(L2_THREADS)
                             const double *__restrict__ luts, const double *__restrict__ bsk3_lat,
                             const double *__restrict__ g_tw_h, const double *__restrict__ g_root_pow,
                             u64 *__restrict__ out, uint32_t count, uint32_t n) {
+#ifdef BMI_PHASE_PROF
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_times_u[blockIdx.x][0] = wall_clock64();
+#endif
     extern __shared__ double lds[];
     double *acc = lds + ntth::HT_WORDS;              // [2 components][2 parities][512], centred (<= q/2 + 2)
     double *tiles = acc + 2 * N;                     // [12][HSCRATCH]
@@ -182,6 +186,7 @@ __global__ void __launch_bounds__(L2_THREADS)
 #ifdef BMI_PHASE_PROF
     if (blockIdx.x == 0 && lane == 0)
         for (int k_ = 0; k_ < 8; k_++) g_phase_u[wave * 8 + k_] = ph_[k_];
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_times_u[blockIdx.x][1] = wall_clock64();
 #endif
     u64 *o = out + (size_t)ct * (N + 1);
     {
@@ -201,6 +206,9 @@ __global__ void __launch_bounds__(L2_THREADS)
 #ifdef BMI_PHASE_PROF
 extern "C" int bmi_debug_phase_prof_unrolled(unsigned long long *out64) {
     return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase_u), sizeof(unsigned long long) * 128);
+}
+extern "C" int bmi_debug_wg_times_unrolled(unsigned long long *out2048) {
+    return (int)hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_wg_times_u), sizeof(unsigned long long) * 2048);
 }
 #endif
 
