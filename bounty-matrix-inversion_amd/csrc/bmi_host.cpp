@@ -610,6 +610,21 @@ void gen_ggsw_rows(bmi_ctx *c, uint64_t seed, u64 mask_stream, u64 noise_stream,
     });
 }
 
+// the unrolled bootstrap key of the secret keys held: per pair (s, s') = (s_2i, s_2i+1) the GGSW encryptions of s s', s (1 - s'),
+// (1 - s) s'; an odd n is completed by s_n = 0 (host copy only; upload_bsk3 sends it to the device)
+void gen_bsk3(bmi_ctx *c, uint64_t seed) {
+    const uint32_t n = c->P.n;
+    std::vector<u64> msg((size_t)c->pairs() * 3);
+    for (uint32_t i = 0; i < c->pairs(); i++) {
+        const u64 s1 = c->sk_small[2 * i], s2 = 2 * i + 1 < n ? c->sk_small[2 * i + 1] : 0;
+        msg[3 * i] = s1 & s2;
+        msg[3 * i + 1] = s1 & (s2 ^ 1);
+        msg[3 * i + 2] = (s1 ^ 1) & s2;
+    }
+    c->bsk3_std.assign(c->bsk3_words(), 0);
+    gen_ggsw_rows(c, seed, S_BSK3_MASK, S_BSK3_NOISE, msg, c->bsk3_std.data());
+}
+
 // evaluation keys for the secret keys held in c->sk_small / c->sk_big, deterministic in `seed`
 int gen_eval_keys(bmi_ctx *c, uint64_t seed) {
     HIP_OK(c, hipSetDevice(c->device));
@@ -624,17 +639,7 @@ int gen_eval_keys(bmi_ctx *c, uint64_t seed) {
     // body's noise, std 2^20, is then rounded to the grid too and vanishes in 95 % of the words: not an LWE sample any more.)
     gen_ggsw_rows(c, seed, S_BSK_MASK, S_BSK_NOISE, c->sk_small, c->bsk_std.data());
     c->have_bsk3 = false;
-    if (c->unroll == 2) {   // unrolled key: GGSW(s s'), GGSW(s (1 - s')), GGSW((1 - s) s') per pair; an odd n is completed by s_n = 0
-        std::vector<u64> msg((size_t)c->pairs() * 3);
-        for (uint32_t i = 0; i < c->pairs(); i++) {
-            const u64 s1 = c->sk_small[2 * i], s2 = 2 * i + 1 < n ? c->sk_small[2 * i + 1] : 0;
-            msg[3 * i] = s1 & s2;
-            msg[3 * i + 1] = s1 & (s2 ^ 1);
-            msg[3 * i + 2] = (s1 ^ 1) & s2;
-        }
-        c->bsk3_std.assign(c->bsk3_words(), 0);
-        gen_ggsw_rows(c, seed, S_BSK3_MASK, S_BSK3_NOISE, msg, c->bsk3_std.data());
-    }
+    if (c->unroll == 2) gen_bsk3(c, seed);
     // --- keyswitch key
     c->ksk.assign((size_t)k * N * lk * (n + 1), 0);
     {
@@ -941,15 +946,7 @@ int bmi_set_bsk_unroll(bmi_ctx *c, uint32_t factor) {
     if (factor == 2 && c->have_keys && !c->have_bsk3) {
         if (!c->have_secret) return 0;   // evaluation-only context: the key arrives through bmi_import_bsk_unrolled
         // the unrolled key of the secret keys already held: fresh masks and noise (CSPRNG, or the seeded test streams)
-        std::vector<u64> msg((size_t)c->pairs() * 3);
-        for (uint32_t i = 0; i < c->pairs(); i++) {
-            const u64 s1 = c->sk_small[2 * i], s2 = 2 * i + 1 < c->P.n ? c->sk_small[2 * i + 1] : 0;
-            msg[3 * i] = s1 & s2;
-            msg[3 * i + 1] = s1 & (s2 ^ 1);
-            msg[3 * i + 2] = (s1 ^ 1) & s2;
-        }
-        c->bsk3_std.assign(c->bsk3_words(), 0);
-        gen_ggsw_rows(c, c->seed, S_BSK3_MASK, S_BSK3_NOISE, msg, c->bsk3_std.data());
+        gen_bsk3(c, c->seed);
         return upload_bsk3(c);
     }
     return 0;
