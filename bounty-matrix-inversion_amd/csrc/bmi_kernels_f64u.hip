@@ -154,7 +154,9 @@ __global__ void __launch_bounds__(L2_THREADS)
             // key 0 was requested before the forward phase; key 1 is requested now, key 2 as soon as key 0 has been consumed.
             // (Requesting more ahead was built and measured: the next pair's first key under the inverse phase or key 1 under
             // the forward phase need registers the forward tasks do not have - 76-80 bytes of spills per lane, 25 % slower;
-            // key 1 right before the barrier, or keys 1 and 2 together: no gain / 5 % slower.)
+            // key 1 right before the barrier, or keys 1 and 2 together: no gain / 5 % slower; a second copy of the step loop for
+            // the four wavefronts without a forward task, which then hold all three keys from the start of a step - 124
+            // registers, no spills, bit-exact: 1 % faster, not kept.)
             double bn[2 * L][2];
             load_key(bn, ip, 1);
             one_key(b, cj[0]);
