@@ -156,7 +156,8 @@ __global__ void __launch_bounds__(L2_THREADS)
             // the forward phase need registers the forward tasks do not have - 76-80 bytes of spills per lane, 25 % slower;
             // key 1 right before the barrier, or keys 1 and 2 together: no gain / 5 % slower; a second copy of the step loop for
             // the four wavefronts without a forward task, which then hold all three keys from the start of a step - 124
-            // registers, no spills, bit-exact: 1 % faster, not kept.)
+            // registers, no spills, bit-exact: 1 % faster, not kept; those wavefronts touching every line of keys 1 and 2
+            // under the forward phase so that the real requests hit the L2: 3 % SLOWER.)
             double bn[2 * L][2];
             load_key(bn, ip, 1);
             one_key(b, cj[0]);
