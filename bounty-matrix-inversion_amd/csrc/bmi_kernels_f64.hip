@@ -1039,8 +1039,8 @@ __global__ void __launch_bounds__(W_THREADS)
                     double w = RP[xi ^ ((xi >> 5) & 31)];
                     w = (xe & W_N) ? -w : w;
                     const double wh = (c & 1) ? -w : w;                        // the root of the upper half is -psi^e
-                    ylo[q] += f49::mul(f49::red(plo[q]), w - 1.0);
-                    yhi[q] += f49::mul(f49::red(phi[q]), wh - 1.0);
+                    ylo[q] += f49::mul(plo[q], w - 1.0);   // lazy sums of <= four reduced products go into the product as they are
+                    yhi[q] += f49::mul(phi[q], wh - 1.0);
                 }
             };
             load_chunk(std::integral_constant<int, 0>());

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(L2_THREADS)
             }
             double slo = 0.0, shi = 0.0;   // sums of three reduced products (<= 1.6 q)
             auto one_key = [&](const double (&kw)[2 * L][2], uint32_t c) {
-                double ylo = 0.0, yhi = 0.0;  // lazy sums of 2 L <= six products (<= 10.2 q)
+                double ylo = 0.0, yhi = 0.0;  // lazy sums of 2 L <= six reduced products (<= 3.1 q)
 #pragma unroll
                 for (int r = 0; r < 2 * L; r++) {
                     ylo += f49::mul(alo[r], kw[r][0]);
@@ -148,8 +148,8 @@ __global__ void __launch_bounds__(L2_THREADS)
                 const uint32_t xe = (root_e * c) & (2 * N - 1);
                 const double w = RP[xe ^ ((xe >> 5) & 31)];
                 const double wh = (c & 1) ? -w : w;
-                slo += f49::mul(f49::red(ylo), w - 1.0);
-                shi += f49::mul(f49::red(yhi), wh - 1.0);
+                slo += f49::mul(ylo, w - 1.0);   // the lazy sum goes into the product as it is (|.| <= 3.1 q: exact, like e + od above)
+                shi += f49::mul(yhi, wh - 1.0);
             };
             // key 0 was requested before the forward phase; key 1 is requested now, key 2 as soon as key 0 has been consumed.
             // (Requesting more ahead was built and measured: the next pair's first key under the inverse phase or key 1 under
