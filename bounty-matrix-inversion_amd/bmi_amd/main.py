@@ -131,6 +131,9 @@ class EncryptedMatrixInversion:
         self.device = device
         self.shard_threshold = shard_threshold
         self.unroll = bool(unroll)
+        if self.unroll and engine is not None and getattr(engine, "unroll", 1) != 2:
+            raise ValueError("unroll=True with an engine that is not in unrolled mode: call engine.set_bsk_unroll(2) before its "
+                             "keygen, or let this object create the engine")
         self._exec = None
 
     # ---- key generation / engine -------------------------------------------------------------------
