@@ -75,6 +75,7 @@ _SIGS = {
     "bmi_set_kernel_variant": [C.c_void_p, C.c_int],
     "bmi_set_keyswitch_variant": [C.c_void_p, C.c_int],
     "bmi_set_bsk_precision": [C.c_void_p, C.c_uint32],
+    "bmi_get_bsk_precision": [C.c_void_p, C.POINTER(C.c_uint32)],
     "bmi_set_bsk_unroll": [C.c_void_p, C.c_uint32],
     "bmi_import_bsk_unrolled": [C.c_void_p, C.c_void_p],
     "bmi_export_bsk_unrolled": [C.c_void_p, C.c_void_p],
@@ -414,11 +415,19 @@ class Engine:
         self._ck(self.lib.bmi_set_kernel_variant(self.h, int(v)), "bmi_set_kernel_variant")
 
     def set_bsk_precision(self, bits):
-        """2^64 torus, before keygen: 64 = exact key (three limbs), 42 = key rounded to 42 bits (two limbs, 2/3 of the work)"""
+        """2^64 torus, before keygen: 64 = exact key (three limbs); 48 = key rounded to 48 bits (two limbs, 2/3 of the work; the
+        default at Bg = 2^10, the torus parameter set); 42 = rounded to 42 bits (two limbs at Bg = 2^15, noisier)"""
         self._ck(self.lib.bmi_set_bsk_precision(self.h, int(bits)), "bmi_set_bsk_precision")
 
+    @property
+    def bsk_precision(self):
+        """bits of precision the bootstrap key is stored at (64 = exact; the prime fields always)"""
+        v = C.c_uint32()
+        self._ck(self.lib.bmi_get_bsk_precision(self.h, C.byref(v)), "bmi_get_bsk_precision")
+        return v.value
+
     def set_bsk_unroll(self, factor):
-        """49-bit field, N = 1024 (or N = 2048 with l <= 2): 1 = CGGI's blind rotation (default), 2 = two LWE coefficients per step with an unrolled
+        """49-bit field, N = 1024 (or N = 2048 with l <= 2), or the 2^64 torus at its default set: 1 = CGGI's blind rotation (default), 2 = two LWE coefficients per step with an unrolled
         bootstrap key (generated by the next keygen, or at once from the secret keys already held); include/bmi_tfhe.h"""
         self._ck(self.lib.bmi_set_bsk_unroll(self.h, int(factor)), "bmi_set_bsk_unroll")
         self.unroll = int(factor)

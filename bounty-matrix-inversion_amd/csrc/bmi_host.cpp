@@ -21,6 +21,7 @@
 #include "ntt_wave.hpp"
 #include "ntt_half_f64.hpp"
 #include "ntt_wave_f64.hpp"
+#include "t64_common.hpp"
 
 using gl::i64;
 using gl::u64;
@@ -186,14 +187,15 @@ struct bmi_ctx {
     bool have_keys = false;
     bool have_secret = false;  // false for a context that imported evaluation keys only (no encrypt / decrypt)
     u64 seed = 0, enc_counter = 0;
-    int bsk_limbs = bmit::BSK_LIMBS;   // torus: 3 = exact 64-bit key words, 2 = key rounded to 42 bits (bmi_set_bsk_precision)
+    int bsk_prec = 64;   // torus: bits of precision the bootstrap key is stored at (64 = exact, 48, 42: t64_common.hpp; bmi_set_bsk_precision)
+    int bsk_limbs() const { return t64::limbs_of(bsk_prec); }
     bool secure_rng = false;       // true: keys / encryptions drawn from the CSPRNG below; false: test-only seeded streams
     ChaKey rng_secret, rng_public; // independent ChaCha20 keys from getrandom(): secrets + noise / public masks
     std::vector<u64> sk_small, sk_big, bsk_std, ksk;
     void *d_bsk = nullptr, *d_tw = nullptr, *d_luts = nullptr;  // u64 words (Goldilocks) or f64 words (49-bit field)
     double *d_tw_half = nullptr, *d_bsk_lat = nullptr;          // 49-bit field: tables and key copy of the split-transform latency kernel
     double *d_tw_wide = nullptr;                                // N = 2048: T / T^-1 of the even/odd combination (d_bsk_lat then holds the wide key copy)
-    // bootstrap-key unrolling (49-bit field, N = 1024; bmi_set_bsk_unroll): per pair of LWE coefficients the GGSW encryptions of
+    // bootstrap-key unrolling (49-bit field at N = 1024 / 2048, 2^64 torus; bmi_set_bsk_unroll): per pair of LWE coefficients the GGSW encryptions of
     // s s', s (1 - s'), (1 - s) s'; host copy in the standard domain, device copy in the slot order of the latency kernel
     uint32_t unroll = 1;
     std::vector<u64> bsk3_std;
@@ -354,6 +356,10 @@ std::vector<u64> build_twiddles_quad(const Fq &f) {
     return tw;
 }
 
+// precision a torus context stores its bootstrap key at unless bmi_set_bsk_precision says otherwise: 48 bits (two 24-bit limbs)
+// where the decomposition base leaves room for it (Bg <= 2^10: the default torus set), else the exact key (three 22-bit limbs)
+int default_bsk_precision(const bmi_params &P) { return P.bs_base_log <= 10 ? 48 : 64; }
+
 bool params_supported(const bmi_params &P, std::string &why) {
     if (P.q_bits == BMI_Q_TORUS64 && P.log_N != 10) { why = "the 2^64 torus has a HIP kernel for N = 1024 only"; return false; }
     if (P.log_N != 10 && !((P.log_N == 11 || P.log_N == 12) && P.q_bits == 49)) {
@@ -364,10 +370,11 @@ bool params_supported(const bmi_params &P, std::string &why) {
     const bool lb_default = P.bs_levels == 3 && P.bs_base_log == 15;
     const bool lb_f64 = lb_default || (P.bs_levels == 2 && P.bs_base_log == 15) || (P.bs_levels == 1 && P.bs_base_log == 23);
     // (2, 2^15) and (1, 2^23): the templated 49-bit kernels (N = 1024 wave-pair / latency kernels, N = 2048), and (2, 2^15) on the torus
-    const bool ok_lb = lb_default || (P.q_bits == 49 && P.log_N <= 11 && lb_f64) ||
-                       (P.q_bits == BMI_Q_TORUS64 && P.bs_levels == 2 && P.bs_base_log == 15);
+    const bool ok_lb = (lb_default && P.q_bits != BMI_Q_TORUS64) || (P.q_bits == 49 && P.log_N <= 11 && lb_f64) ||
+                       (P.q_bits == BMI_Q_TORUS64 && bmit::shape_supported(default_bsk_precision(P), P.bs_levels, P.bs_base_log));
     if (!ok_lb) {
-        why = "(l, Bg) must be (3, 2^15); the 49-bit field at N <= 2048 also takes (2, 2^15) and (1, 2^23), the 2^64 torus (2, 2^15)";
+        why = "(l, Bg) must be (3, 2^15); the 49-bit field at N <= 2048 also takes (2, 2^15) and (1, 2^23), the 2^64 torus (3 or 2, 2^10) "
+              "and (3 or 2, 2^15)";
         return false;
     }
     if (P.n == 0 || P.n > BMI_MAX_LWE_N) { why = "n must be in [1, 1024]"; return false; }
@@ -387,7 +394,10 @@ extern "C" {
 int bmi_default_params_for(uint32_t q_bits, bmi_params *out) {
     if (!out || (q_bits != 64 && q_bits != 49 && q_bits != BMI_Q_TORUS64)) return -1;
     // same shape for every modulus; the 49-bit modulus keeps the absolute bootstrap-key noise above the integer grid
-    *out = bmi_params{630, 10, 1, 3, 15, 8, 4, q_bits, std::ldexp(1.0, -25), std::ldexp(1.0, q_bits == 49 ? -40 : -44)};
+    // the torus set decomposes in base 2^10: the limb sums of its exact products then leave room for a two-limb key (48 bits of
+    // precision) in the plain AND the unrolled blind rotation, and the output noise is lower than at 2^15 (t64_common.hpp)
+    *out = bmi_params{630, 10, 1, 3, q_bits == BMI_Q_TORUS64 ? 10u : 15u, 8, 4, q_bits, std::ldexp(1.0, -25),
+                      std::ldexp(1.0, q_bits == 49 ? -40 : -44)};
     return 0;
 }
 
@@ -427,7 +437,10 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
     c->P = *params;
     if (c->P.q_bits == 0) c->P.q_bits = 64;
     if (c->P.q_bits == 49) c->f = Fq{f49::Q, 49};
-    if (c->P.q_bits == BMI_Q_TORUS64) c->f = Fq{0, 64, true};
+    if (c->P.q_bits == BMI_Q_TORUS64) {
+        c->f = Fq{0, 64, true};
+        c->bsk_prec = default_bsk_precision(c->P);
+    }
     c->device = device;
     c->N = 1u << params->log_N;
     c->big_n = params->k * c->N;
@@ -457,12 +470,13 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
         if (hipMemcpy(c->d_tw_half, th.data(), th.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(half-transform twiddles) failed");
     }
-    if (c->f64() && !c->quad()) {   // psi^x for the unrolled blind rotation (X^c at the root psi^e is psi^(e c))
+    if ((c->f64() && !c->quad()) || c->t64()) {   // psi^x for the unrolled blind rotation (X^c at the root psi^e is psi^(e c))
         // N = 1024: psi = psi_2048, x in [0, 2048).  N = 2048: psi = psi_4096, x in [0, 2048) (the upper half is the negative)
         std::vector<u64> rp(2048);
-        const u64 psi = c->wide() ? c->f.pow(f49::GEN, (c->f.q - 1) / 4096) : (u64)nttf::PSI_U;
+        const Fq fp{f49::Q, 49};   // the torus kernels transform mod the 49-bit prime as well
+        const u64 psi = c->wide() ? fp.pow(f49::GEN, (fp.q - 1) / 4096) : (u64)nttf::PSI_U;
         rp[0] = 1;
-        for (uint32_t x = 1; x < 2048; x++) rp[x] = c->f.mul(rp[x - 1], psi);
+        for (uint32_t x = 1; x < 2048; x++) rp[x] = fp.mul(rp[x - 1], psi);
         const std::vector<double> rpd = to_centred_doubles(rp);
         if (hipMalloc(&c->d_root_pow, rpd.size() * 8) != hipSuccess) return bail("hipMalloc(root powers) failed");
         if (hipMemcpy(c->d_root_pow, rpd.data(), rpd.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
@@ -676,15 +690,20 @@ int upload_bsk3(bmi_ctx *c) {
     HIP_OK(c, hipSetDevice(c->device));
     const size_t words = c->bsk3_words();
     if (c->bsk3_std.size() != words) return fail(c, -1, "no unrolled bootstrap key to upload");
+    // torus: the key stored at bsk_prec bits IS the key from here on (what bmi_export_bsk_unrolled returns)
+    if (c->t64() && c->bsk_prec != 64)
+        for (u64 &w : c->bsk3_std) w = t64::round_key_word(w, c->bsk_prec);
     u64 *d_tmp = nullptr;
     HIP_OK(c, hipMalloc(&d_tmp, words * 8));
-    if (!c->d_bsk3_lat && hipMalloc(&c->d_bsk3_lat, words * 8) != hipSuccess) {
+    const size_t lat_bytes = words * 8 * (c->t64() ? c->bsk_limbs() : 1);
+    if (!c->d_bsk3_lat && hipMalloc(&c->d_bsk3_lat, lat_bytes) != hipSuccess) {
         (void)hipFree(d_tmp);
         return fail(c, -2, "hipMalloc(unrolled key) failed");
     }
     HIP_OK(c, hipMemcpy(d_tmp, c->bsk3_std.data(), words * 8, hipMemcpyHostToDevice));
-    const int rc = c->wide() ? bmi49::launch_bsk_to_wide(d_tmp, c->d_bsk3_lat, (const double *)c->d_tw, c->d_tw_wide, (uint32_t)(words / c->N), c->stream)
-                             : bmi49::launch_bsk_to_lat(d_tmp, c->d_bsk3_lat, c->d_tw_half, (uint32_t)(words / c->N), true, c->stream);
+    const int rc = c->t64() ? bmit::launch_bsk_to_lat(d_tmp, c->d_bsk3_lat, c->d_tw_half, (uint32_t)(words / c->N), c->bsk_prec, c->stream)
+                   : c->wide() ? bmi49::launch_bsk_to_wide(d_tmp, c->d_bsk3_lat, (const double *)c->d_tw, c->d_tw_wide, (uint32_t)(words / c->N), c->stream)
+                               : bmi49::launch_bsk_to_lat(d_tmp, c->d_bsk3_lat, c->d_tw_half, (uint32_t)(words / c->N), true, c->stream);
     if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat (unrolled key) launch failed"); }
     HIP_OK(c, hipStreamSynchronize(c->stream));
     HIP_OK(c, hipFree(d_tmp));
@@ -698,10 +717,10 @@ int upload_eval_keys(bmi_ctx *c) {
     const bmi_params &P = c->P;
     const uint32_t n = P.n, N = c->N, k = P.k, lk = P.ks_levels;
     // --- upload: bootstrap key -> NTT domain on the GPU; keyswitch key with padded rows
-    if (c->t64() && c->bsk_limbs == 2) {
-        // key stored at 42 bits of precision: every word rounded (half up, as a signed integer) to a multiple of 2^22.  The
-        // rounded key IS the key from here on (bmi_export_keys returns it), so every consumer agrees on it.
-        for (u64 &w : c->bsk_std) w = (u64)((((long long)w + (1ll << 21)) >> 22)) << 22;
+    if (c->t64() && c->bsk_prec != 64) {
+        // key stored at 48 / 42 bits of precision: every word rounded (half up, as a signed integer) to a multiple of 2^16 / 2^22.
+        // The rounded key IS the key from here on (bmi_export_keys returns it), so every consumer agrees on it.
+        for (u64 &w : c->bsk_std) w = t64::round_key_word(w, c->bsk_prec);
     }
     const size_t bsk_words = c->bsk_std.size();
     if (!c->d_bsk && !c->wide() && !c->quad() && !c->t64()) HIP_OK(c, hipMalloc(&c->d_bsk, bsk_words * 8));
@@ -711,20 +730,20 @@ int upload_eval_keys(bmi_ctx *c) {
     int rc = 0;
     if (c->t64()) {  // 2^64 torus: bsk_limbs transform-domain limb polynomials per key polynomial
         if (c->d_bsk) { (void)hipFree(c->d_bsk); c->d_bsk = nullptr; }
-        if (hipMalloc(&c->d_bsk, bsk_words * 8 * c->bsk_limbs) != hipSuccess) {
+        if (hipMalloc(&c->d_bsk, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) {
             (void)hipFree(d_tmp);
             return fail(c, -2, "hipMalloc(torus limb key) failed");
         }
         rc = bmit::launch_bsk_to_limbs(d_tmp, (double *)c->d_bsk, (const double *)c->d_tw, (uint32_t)(bsk_words / N),
-                                       c->bsk_limbs, c->stream);
+                                       c->bsk_prec, c->stream);
         if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_limbs launch failed"); }
         // second copy for the latency kernel, per limb in the slot order of the two-wave half transform
         if (c->d_bsk_lat) { (void)hipFree(c->d_bsk_lat); c->d_bsk_lat = nullptr; }
-        if (hipMalloc(&c->d_bsk_lat, bsk_words * 8 * c->bsk_limbs) != hipSuccess) {
+        if (hipMalloc(&c->d_bsk_lat, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) {
             (void)hipFree(d_tmp);
             return fail(c, -2, "hipMalloc(torus latency-kernel key) failed");
         }
-        rc = bmit::launch_bsk_to_lat(d_tmp, c->d_bsk_lat, c->d_tw_half, (uint32_t)(bsk_words / N), c->bsk_limbs, c->stream);
+        rc = bmit::launch_bsk_to_lat(d_tmp, c->d_bsk_lat, c->d_tw_half, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
         if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat (torus) launch failed"); }
     } else if (c->wide() || c->quad()) {  // N = 2048 / 4096: one key copy, in the slot order of k_blind_rotate_wide49 / quad49
         if (!c->d_bsk_lat && hipMalloc(&c->d_bsk_lat, bsk_words * 8) != hipSuccess) {
@@ -826,7 +845,7 @@ int bmi_export_keys(const bmi_ctx *c, uint64_t *sk_small, uint64_t *sk_big, uint
 
 int bmi_key_bytes(const bmi_ctx *c, uint64_t *bsk_bytes, uint64_t *ksk_bytes) {
     if (!c) return -1;
-    if (bsk_bytes) *bsk_bytes = (u64)c->P.n * c->rows * (c->P.k + 1) * c->N * 8 * (c->t64() ? c->bsk_limbs : 1);
+    if (bsk_bytes) *bsk_bytes = (u64)c->P.n * c->rows * (c->P.k + 1) * c->N * 8 * (c->t64() ? c->bsk_limbs() : 1);
     if (ksk_bytes) *ksk_bytes = (u64)c->big_n * c->P.ks_levels * (c->P.n + 1) * 8;
     return 0;
 }
@@ -929,17 +948,31 @@ int bmi_lut_get(const bmi_ctx *c, uint32_t lut_id, uint64_t *test_vector) {
 int bmi_set_bsk_precision(bmi_ctx *c, uint32_t bits) {
     if (!c) return -1;
     if (!c->t64()) return fail(c, -1, "the bootstrap-key precision option exists on the 2^64 torus only");
-    if (bits != 64 && bits != 42) return fail(c, -1, "bootstrap-key precision must be 64 (exact) or 42 bits");
+    if (!t64::precision_ok((int)bits)) return fail(c, -1, "bootstrap-key precision must be 64 (exact), 48 or 42 bits");
     if (c->have_keys) return fail(c, -1, "set the bootstrap-key precision before generating or importing keys");
-    c->bsk_limbs = bits == 64 ? 3 : 2;
+    if (!bmit::shape_supported((int)bits, c->P.bs_levels, c->P.bs_base_log))
+        return fail(c, -1, "no kernel for this precision at this decomposition: base 2^10 takes 48 (default) or 64 bits, base 2^15 takes 64 "
+                           "(default) or 42 bits (a limb sum must stay below p/2: t64_common.hpp)");
+    if (c->unroll == 2 && !bmit::shape_supported_unrolled((int)bits, c->P.bs_levels, c->P.bs_base_log))
+        return fail(c, -1, "the unrolled torus kernel takes the 48-bit key at base 2^10 only");
+    c->bsk_prec = (int)bits;
+    return 0;
+}
+
+int bmi_get_bsk_precision(const bmi_ctx *c, uint32_t *bits) {
+    if (!c || !bits) return -1;
+    *bits = c->t64() ? (uint32_t)c->bsk_prec : 64u;
     return 0;
 }
 
 int bmi_set_bsk_unroll(bmi_ctx *c, uint32_t factor) {
     if (!c) return -1;
     if (factor != 1 && factor != 2) return fail(c, -1, "the unrolling factor is 1 or 2");
-    if (factor == 2 && !(c->f64() && !c->quad()))
-        return fail(c, -1, "bootstrap-key unrolling has HIP kernels for the 49-bit field at N = 1024 and N = 2048 only");
+    if (factor == 2 && !((c->f64() && !c->quad()) || c->t64()))
+        return fail(c, -1, "bootstrap-key unrolling has HIP kernels for the 49-bit field at N = 1024 and N = 2048 and for the 2^64 torus only");
+    if (factor == 2 && c->t64() && !bmit::shape_supported_unrolled(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log))
+        return fail(c, -1, "on the 2^64 torus the unrolled kernel takes the 48-bit key at base 2^10 (the default torus set): the limb sums of "
+                           "its three scaled products must stay below p/2");
     if (factor == 2 && c->wide() && c->P.bs_levels > 2)
         return fail(c, -1, "at N = 2048 the unrolled kernel exists for l <= 2 (at l = 3 it would not fit the registers: the plain kernel is faster)");
     c->unroll = factor;
@@ -954,8 +987,8 @@ int bmi_set_bsk_unroll(bmi_ctx *c, uint32_t factor) {
 
 int bmi_import_bsk_unrolled(bmi_ctx *c, const uint64_t *bsk3) {
     if (!c || !bsk3) return -1;
-    if (!(c->f64() && !c->quad()))
-        return fail(c, -1, "bootstrap-key unrolling has HIP kernels for the 49-bit field at N = 1024 and N = 2048 only");
+    if (!((c->f64() && !c->quad()) || c->t64()))
+        return fail(c, -1, "bootstrap-key unrolling has HIP kernels for the 49-bit field at N = 1024 and N = 2048 and for the 2^64 torus only");
     if (!c->have_keys) return fail(c, -1, "no keys: import or generate the key set first");
     const size_t words = c->bsk3_words();
     for (size_t i = 0; i < words; i++)
@@ -1073,14 +1106,20 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     const bool latency = c->variant == 2 || (c->variant == 0 && count <= c->lat_threshold);
     int rc;
     if (c->t64()) {   // 2^64 torus: latency kernel (one workgroup per ciphertext) for small batches, wave pairs beyond
+        if (c->unroll == 2) {   // unrolled key: one kernel (one workgroup per ciphertext) for every batch size
+            if (!c->have_bsk3) return fail(c, -1, "unrolling selected but the context holds no unrolled key: generate keys after bmi_set_bsk_unroll, or bmi_import_bsk_unrolled");
+            rc = bmit::launch_blind_rotate_lat2u(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk3_lat, c->d_tw_half, c->d_root_pow, d_out,
+                                                 count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
+            return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+        }
         const bool lat_t = c->variant == 2 || c->variant == 4 || (c->variant == 0 && count <= c->lat_threshold);
         if (lat_t) {
             rc = bmit::launch_blind_rotate_lat(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_lat, c->d_tw_half, d_out,
-                                               count, c->P.n, c->bsk_limbs, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
+                                               count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }
         rc = bmit::launch_blind_rotate(d_small, d_lut_ids, (const u64 *)c->d_luts, (const double *)c->d_bsk,
-                                       (const double *)c->d_tw, d_out, count, c->P.n, c->bsk_limbs, c->P.bs_levels, c->P.bs_base_log,
+                                       (const double *)c->d_tw, d_out, count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log,
                                        (hipStream_t)stream);
         return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
     }

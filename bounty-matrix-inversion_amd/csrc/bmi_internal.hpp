@@ -149,24 +149,32 @@ int launch_lincomb(const u64 *store, const uint32_t *row_ptr, const uint32_t *id
                    const u64 *const_body, u64 *out, uint32_t count, uint32_t width, hipStream_t s);
 }  // namespace bmi49
 
-// The 2^64 torus (bmi_kernels_t64.hip): ciphertexts, test polynomials and keyswitch key are plain u64 words; the
-// bootstrap key is LIMBS transform-domain f64 limb polynomials per key polynomial ([poly][limb][N]).
+// The 2^64 torus (bmi_kernels_t64.hip, bmi_kernels_t64u.hip): ciphertexts, test polynomials and keyswitch key are plain u64
+// words; the bootstrap key is LIMBS transform-domain f64 limb polynomials per key polynomial ([poly][limb][N]); the limb
+// scheme follows from the precision `prec` (64, 48 or 42 bits) the key is stored at (t64_common.hpp).
 namespace bmit {
 using gl::i64;
 using gl::u64;
-constexpr int BSK_LIMBS = 3;        // balanced 22-bit limbs of a 64-bit key word (2 limbs of 21 bits for a key rounded to 42 bits)
 constexpr uint32_t KS_LIMBS = 9;    // balanced base-256 limbs of a keyswitch-key word
-int launch_bsk_to_limbs(const u64 *std_polys, double *limb_polys, const double *g_tw, uint32_t n_polys, int limbs,
+// (precision, levels, base log) combinations with instantiated kernels
+bool shape_supported(int prec, uint32_t levels, uint32_t base_log);
+bool shape_supported_unrolled(int prec, uint32_t levels, uint32_t base_log);
+int launch_bsk_to_limbs(const u64 *std_polys, double *limb_polys, const double *g_tw, uint32_t n_polys, int prec,
                         hipStream_t s);
 int launch_blind_rotate(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_limbs,
-                        const double *g_tw, u64 *out, uint32_t count, uint32_t n, int limbs, uint32_t levels,
-                        uint32_t base_log, hipStream_t s);   // (levels, base log) = (3, 15) or (2, 15)
+                        const double *g_tw, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
+                        uint32_t base_log, hipStream_t s);
 // latency form (one workgroup of 16 wavefronts per ciphertext): own key copy, per limb in the slot order of the two-wave
-// half transform ([poly][limb][A_lo 512, A_hi 512]); tables of ntt_half_f64.hpp
-int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, int limbs, hipStream_t s);
+// half transform ([poly][limb][512 slots][A_lo, A_hi]); tables of ntt_half_f64.hpp
+int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, int prec, hipStream_t s);
 int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_lat,
-                            const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, int limbs, uint32_t levels,
+                            const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
                             uint32_t base_log, hipStream_t s);
+// the same with the unrolled key (two LWE coefficients per step; bmi_kernels_t64u.hip): bsk3_lat = launch_bsk_to_lat of the
+// unrolled key [ceil(n/2)][3 keys] GGSW copies, g_root_pow = psi^x (mod 2^49 - 720895) for x in [0, 2N) as centred doubles
+int launch_blind_rotate_lat2u(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk3_lat,
+                              const double *g_tw_h, const double *g_root_pow, u64 *out, uint32_t count, uint32_t n, int prec,
+                              uint32_t levels, uint32_t base_log, hipStream_t s);
 int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
                      uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,
                      hipStream_t s);

@@ -5,9 +5,10 @@
 //   * the six digit polynomials of a CMUX are small (|d| <= 2^14) and are transformed once, mod p = 2^49 - 720895, with
 //     the f64 wave transform of ntt_wave_f64.hpp (the machinery of the 49-bit field kernels);
 //   * every 64-bit bootstrap-key word k (read as a signed integer) is split once, at key upload, into LIMBS balanced
-//     limbs of T64_LIMB_BITS bits, k = sum_j k_j 2^(22 j), and each limb polynomial is stored in the transform domain;
+//     limbs, k = 2^PRE sum_j k_j 2^(BITS j) (t64_common.hpp: the scheme follows from the precision the key is stored at),
+//     and each limb polynomial is stored in the transform domain;
 //   * per limb, the sum over the six GGSW rows of digit x limb is an integer of magnitude
-//     < 6 * 1024 * 2^14 * 2^21 = 2^47.585 < p / 2, so its centred residue mod p IS that integer (exact, no rounding);
+//     < 6 * 1024 * 2^(Bg-1) * 2^(BITS-1) < p / 2, so its centred residue mod p IS that integer (exact, no rounding);
 //   * the limb results are recombined with shifts and added to the accumulator mod 2^64.
 //
 // Cost against the 49-bit field kernel: the same 6 forward transforms, LIMBS x the multiply-accumulates, key bytes and
@@ -24,6 +25,7 @@
 #include "ks_mfma.hpp"
 #include "ntt_half_f64.hpp"
 #include "ntt_wave_f64.hpp"
+#include "t64_common.hpp"
 
 using f49::i64;
 using f49::u64;
@@ -40,42 +42,20 @@ namespace {
 #ifndef BMI_T64_PRIO
 #define BMI_T64_PRIO 1    // 1 = issue priority steps down through the forward transforms (3, 2, 1), 0 in the limb loop; 0 = none
 #endif
-// Limb schemes.  3 limbs of 22 bits cover the whole 64-bit key word (exact key).  2 limbs of 21 bits cover a key word
-// whose low 22 bits are zero: the key ROUNDED to 42 bits of precision (bmi_set_bsk_precision; the rounding is applied to
-// the standard-domain key itself at upload, so what is exported - and what the oracle bootstraps with - is the key
-// actually used; the rounding errors of a row's mask words are summed over the key's set bits, so the effective key noise
-// becomes 2^-39.3 instead of 2^-44 at the north-star set: the output noise of the 49-bit field's default, measured).
-template <int LIMBS> struct LimbScheme;
-template <> struct LimbScheme<3> { static constexpr int BITS = 22, PRE = 0; };
-template <> struct LimbScheme<2> { static constexpr int BITS = 21, PRE = 22; };
-__host__ __device__ __forceinline__ int limb_bits(int limbs) { return limbs == 3 ? 22 : 21; }
-__host__ __device__ __forceinline__ int limb_pre(int limbs) { return limbs == 3 ? 0 : 22; }
+using t64::f64_to_word;
+using t64::Scheme;
+using t64::word_to_f64;
 constexpr int T64_CTS = 4;
 constexpr int T64_AT_WORDS = BMI_AT_WORDS;
 constexpr int T64_LDS_WORDS = TW_WORDS + 2 * T64_CTS * (SCRATCH_WORDS + N) + T64_CTS * T64_AT_WORDS + 4 * T64_CTS;
 static_assert(T64_LDS_WORDS <= BMI_LDS_WORDS_MAX, "T64_LDS_WORDS exceeds the 160 KB of LDS");
 
-__device__ __forceinline__ uint32_t modswitch_t64(u64 a) {   // round(a * 2N / 2^64) mod 2N, ties up
-    return (uint32_t)(((a >> (63 - (LOG_N + 1))) + 1) >> 1) & (2 * N - 1);
-}
-
-// balanced limb j of a signed 64-bit word: k = 2^pre sum_j limb_j 2^(bits j), limb_j in [-2^(bits-1), 2^(bits-1)) (the last
-// one takes the rest)
-__host__ __device__ __forceinline__ i64 limb_of(i64 k, int j, int limbs) {
-    const int bits = limb_bits(limbs);
-    const i64 B = (i64)1 << bits, H = B >> 1;
-    k >>= limb_pre(limbs);
-    for (int t = 0; t < j; t++) {
-        const i64 d = ((k + H) & (B - 1)) - H;
-        k = (k - d) >> bits;
-    }
-    if (j == limbs - 1) return k;
-    return ((k + H) & (B - 1)) - H;
-}
+__device__ __forceinline__ uint32_t modswitch_t64(u64 a) { return t64::modswitch<LOG_N + 1>(a); }
 
 // standard-domain GGSW polynomials (u64 torus words) -> LIMBS transform-domain limb polynomials each, lane layout
 __global__ void __launch_bounds__(256) k_bsk_to_limbs_t64(const u64 *__restrict__ std_polys, double *__restrict__ limb_polys,
-                                                          const double *__restrict__ g_tw, uint32_t n_polys, int limbs) {
+                                                          const double *__restrict__ g_tw, uint32_t n_polys, int prec) {
+    const int limbs = t64::limbs_of(prec);
     __shared__ double lds[TW_WORDS + 4 * SCRATCH_WORDS];
     for (int i = threadIdx.x; i < TW_WORDS; i += blockDim.x) lds[i] = g_tw[i];
     __syncthreads();
@@ -86,7 +66,7 @@ __global__ void __launch_bounds__(256) k_bsk_to_limbs_t64(const u64 *__restrict_
     const int j = (int)(item % limbs);
     double *scratch = lds + TW_WORDS + wave * SCRATCH_WORDS;
     double x[16];
-    static_for<0, 16>([&](auto J) { x[J] = (double)limb_of((i64)std_polys[(size_t)poly * N + lane + 64 * J], j, limbs); });
+    static_for<0, 16>([&](auto J) { x[J] = (double)t64::limb_of((i64)std_polys[(size_t)poly * N + lane + 64 * J], j, prec); });
     forward(x, lane, lds, scratch);
     static_for<0, 16>([&](auto V) { limb_polys[(size_t)item * N + eval_offset(lane, V)] = f49::red(x[V]); });
 }
@@ -116,25 +96,14 @@ __device__ __forceinline__ void pin() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// exact integer |v| < 2^52 held in a double -> two's complement 64-bit word
-__device__ __forceinline__ u64 f64_to_word(double v) {
-    const double hi = __builtin_floor(v * 0x1p-32);
-    const double lo = __builtin_fma(-0x1p32, hi, v);          // in [0, 2^32)
-    return ((u64)(uint32_t)(int32_t)hi << 32) | (u64)(uint32_t)lo;
-}
-// signed integer |t| < 2^52 held in an int64 -> double (exact)
-__device__ __forceinline__ double word_to_f64(i64 t) {
-    return __builtin_fma((double)(int32_t)(t >> 32), 0x1p32, (double)(uint32_t)t);
-}
-
-template <int LIMBS, int L = 3, int BG = 15>
+template <int PREC, int L = 3, int BG = 15>
 __global__ void __launch_bounds__(128 * T64_CTS)
     k_blind_rotate_t64(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids, const u64 *__restrict__ luts,
                        const double *__restrict__ bsk, const double *__restrict__ g_tw, u64 *__restrict__ out,
                        uint32_t count, uint32_t n) {
     constexpr int CTS = T64_CTS;
     // exactness of a limb's sum: 2 L N terms of |digit| <= 2^(BG-1) times |limb| <= 2^(T64_LIMB_BITS-1) must stay below p/2
-    constexpr int LB = LimbScheme<LIMBS>::BITS, PRE = LimbScheme<LIMBS>::PRE;
+    constexpr int LIMBS = Scheme<PREC>::LIMBS, LB = Scheme<PREC>::BITS, PRE = Scheme<PREC>::PRE;
     static_assert(2.0 * L * N * (double)(1ull << (BG - 1)) * (double)(1ull << (LB - 1)) < f49::P / 2, "limb sums must stay below p/2");
     static_assert(PRE + LIMBS * LB >= 64 && L * BG < 63, "limbs must cover the 64-bit word");
     extern __shared__ double lds[];
@@ -191,8 +160,7 @@ __global__ void __launch_bounds__(128 * T64_CTS)
             static_for<0, 16>([&](auto J) {
                 const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
                 const u64 v = (e & N) ? (u64)0 - vr[J] : vr[J];
-                const i64 t = (i64)(v - vs[J]) >> (64 - L * BG - 1);                    // L BG + 1 signed bits
-                r[J] = __builtin_floor(__builtin_fma(word_to_f64(t), 0.5, 0.5));         // round half up to L BG bits
+                r[J] = t64::rounded_top<L, BG>(v - vs[J]);                               // round half up to L BG bits
             });
         }
         double X[L][16];   // the L digit polynomials, transform domain, live across the limb loop
@@ -297,7 +265,7 @@ __global__ void __launch_bounds__(128 * T64_CTS)
 //      then per limb the multiply-accumulate against the key (own copy in slot order, k_bsk_to_lat_t64) and the sums /
 //      differences for the inverse halves; the next limb's key words are requested while this one is multiplied
 //   C  wavefronts 0 .. 11 = (limb, o, parity): inverse half transform, conversion of the exact integers to words,
-//      shift by 22 j and ONE LDS atomic add per coefficient into the accumulator (three limbs meet in a slot)
+//      shift into place and ONE LDS atomic add per coefficient into the accumulator (the limbs of a coefficient meet in a slot)
 constexpr int LT_THREADS = 1024;
 constexpr int LT_LDS_WORDS = ntth::HT_WORDS + 2 * N + 12 * ntth::HSCRATCH + 3 * 2 * N + BMI_AT_WORDS;   // sized for 3 limbs
 static_assert(LT_LDS_WORDS <= BMI_LDS_WORDS_MAX, "LT_LDS_WORDS exceeds the 160 KB of LDS");
@@ -305,7 +273,8 @@ static_assert(LT_LDS_WORDS <= BMI_LDS_WORDS_MAX, "LT_LDS_WORDS exceeds the 160 K
 // standard-domain GGSW polynomials -> per limb, the slot-order pair (A_lo, A_hi) of the two-wave half transform:
 // out[((poly * limbs) + j) * N + p] = E + O', out[... + 512 + p] = E - O'
 __global__ void __launch_bounds__(256) k_bsk_to_lat_t64(const u64 *__restrict__ std_polys, double *__restrict__ lat_polys,
-                                                        const double *__restrict__ g_tw_h, uint32_t n_polys, int limbs) {
+                                                        const double *__restrict__ g_tw_h, uint32_t n_polys, int prec) {
+    const int limbs = t64::limbs_of(prec);
     __shared__ double lds[ntth::HT_WORDS + 4 * ntth::HSCRATCH];
     for (int i = threadIdx.x; i < ntth::HT_WORDS; i += blockDim.x) lds[i] = g_tw_h[i];
     __syncthreads();
@@ -319,7 +288,7 @@ __global__ void __launch_bounds__(256) k_bsk_to_lat_t64(const u64 *__restrict__ 
     if (ok) {
         double x[8];
         static_for<0, 8>([&](auto J) {
-            x[J] = (double)limb_of((i64)std_polys[(size_t)poly * N + 2 * (lane + 64 * J) + h], j, limbs);
+            x[J] = (double)t64::limb_of((i64)std_polys[(size_t)poly * N + 2 * (lane + 64 * J) + h], j, prec);
         });
         if (h) ntth::forward_half<true>(x, lane, lds, tile);
         else ntth::forward_half<false>(x, lane, lds, tile);
@@ -340,12 +309,12 @@ __global__ void __launch_bounds__(256) k_bsk_to_lat_t64(const u64 *__restrict__ 
     }
 }
 
-template <int L, int LIMBS = 3>
+template <int L, int PREC = 64, int BG = 15>
 __global__ void __launch_bounds__(LT_THREADS)
     k_blind_rotate_lat_t64(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids, const u64 *__restrict__ luts,
                            const double *__restrict__ bsk_lat, const double *__restrict__ g_tw_h, u64 *__restrict__ out,
                            uint32_t count, uint32_t n) {
-    constexpr int BG = 15, LB = LimbScheme<LIMBS>::BITS, PRE = LimbScheme<LIMBS>::PRE;
+    constexpr int LIMBS = Scheme<PREC>::LIMBS, LB = Scheme<PREC>::BITS, PRE = Scheme<PREC>::PRE;
     static_assert(2.0 * L * N * (double)(1ull << (BG - 1)) * (double)(1ull << (LB - 1)) < f49::P / 2, "limb sums must stay below p/2");
     extern __shared__ double lds[];
     u64 *acc = reinterpret_cast<u64 *>(lds + ntth::HT_WORDS);   // [2 components][2 parities][512] words mod 2^64
@@ -398,8 +367,7 @@ __global__ void __launch_bounds__(LT_THREADS)
                 const uint32_t n2 = e & (N - 1);
                 u64 v = ac[(n2 & 1) * ntth::HALF + (n2 >> 1)];
                 v = (e & N) ? (u64)0 - v : v;
-                const i64 t = (i64)(v - ac[h * ntth::HALF + m]) >> (64 - L * BG - 1);
-                double r = __builtin_floor(__builtin_fma(word_to_f64(t), 0.5, 0.5));   // round half up to L BG bits
+                double r = t64::rounded_top<L, BG>(v - ac[h * ntth::HALF + m]);        // round half up to L BG bits
                 double d = r;                                                          // digit `lev`, balanced [-2^14, 2^14)
 #pragma unroll
                 for (int s = L - 1; s > 0; s--) {
@@ -518,21 +486,21 @@ namespace bmit {
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)
 
-int launch_bsk_to_limbs(const u64 *std_polys, double *limb_polys, const double *g_tw, uint32_t n_polys, int limbs,
+int launch_bsk_to_limbs(const u64 *std_polys, double *limb_polys, const double *g_tw, uint32_t n_polys, int prec,
                         hipStream_t s) {
-    if (limbs != 3 && limbs != 2) return (int)hipErrorInvalidValue;
-    const uint32_t items = n_polys * (uint32_t)limbs;
-    hipLaunchKernelGGL(k_bsk_to_limbs_t64, dim3((items + 3) / 4), dim3(256), 0, s, std_polys, limb_polys, g_tw, n_polys, limbs);
+    if (!t64::precision_ok(prec)) return (int)hipErrorInvalidValue;
+    const uint32_t items = n_polys * (uint32_t)t64::limbs_of(prec);
+    hipLaunchKernelGGL(k_bsk_to_limbs_t64, dim3((items + 3) / 4), dim3(256), 0, s, std_polys, limb_polys, g_tw, n_polys, prec);
     BMIT_LAUNCH_CHECK();
     return 0;
 }
 
-template <int L, int LIMBS>
+template <int PREC, int L, int BG>
 static int launch_t64(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_limbs,
                       const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
     static std::atomic<uint64_t> configured{0};
     const size_t lds = (size_t)T64_LDS_WORDS * sizeof(double);
-    auto kern = k_blind_rotate_t64<LIMBS, L, 15>;
+    auto kern = k_blind_rotate_t64<PREC, L, BG>;
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
     hipLaunchKernelGGL(kern, dim3((count + T64_CTS - 1) / T64_CTS), dim3(128 * T64_CTS), lds, s, small_cts, lut_ids, luts,
                        bsk_limbs, g_tw, out, count, n);
@@ -540,32 +508,42 @@ static int launch_t64(const u64 *small_cts, const uint32_t *lut_ids, const u64 *
     return 0;
 }
 
+// the instantiated (precision, levels, base log) combinations; bmi_host.cpp params_supported / bmi_set_bsk_precision admit
+// exactly these
+#define BMIT_FOR_EACH_SHAPE(X) X(64, 3, 15) X(64, 2, 15) X(42, 3, 15) X(42, 2, 15) X(48, 3, 10) X(48, 2, 10) X(64, 3, 10)
+
+bool shape_supported(int prec, uint32_t levels, uint32_t base_log) {
+#define BMIT_SHAPE_OK(P, L, B) if (prec == P && levels == L && base_log == B) return true;
+    BMIT_FOR_EACH_SHAPE(BMIT_SHAPE_OK)
+#undef BMIT_SHAPE_OK
+    return false;
+}
+
 int launch_blind_rotate(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_limbs,
-                        const double *g_tw, u64 *out, uint32_t count, uint32_t n, int limbs, uint32_t levels,
+                        const double *g_tw, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
                         uint32_t base_log, hipStream_t s) {
     if (count == 0) return 0;
-    if ((limbs != 3 && limbs != 2) || base_log != 15) return (int)hipErrorInvalidValue;
-    if (levels == 3 && limbs == 3) return launch_t64<3, 3>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
-    if (levels == 2 && limbs == 3) return launch_t64<2, 3>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
-    if (levels == 3 && limbs == 2) return launch_t64<3, 2>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
-    if (levels == 2 && limbs == 2) return launch_t64<2, 2>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
+#define BMIT_GO(P, L, B) \
+    if (prec == P && levels == L && base_log == B) return launch_t64<P, L, B>(small_cts, lut_ids, luts, bsk_limbs, g_tw, out, count, n, s);
+    BMIT_FOR_EACH_SHAPE(BMIT_GO)
+#undef BMIT_GO
     return (int)hipErrorInvalidValue;
 }
 
-int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, int limbs, hipStream_t s) {
-    if (limbs != 3 && limbs != 2) return (int)hipErrorInvalidValue;
-    const uint32_t items = n_polys * (uint32_t)limbs;
-    hipLaunchKernelGGL(k_bsk_to_lat_t64, dim3((items + 1) / 2), dim3(256), 0, s, std_polys, lat_polys, g_tw_h, n_polys, limbs);
+int launch_bsk_to_lat(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, int prec, hipStream_t s) {
+    if (!t64::precision_ok(prec)) return (int)hipErrorInvalidValue;
+    const uint32_t items = n_polys * (uint32_t)t64::limbs_of(prec);
+    hipLaunchKernelGGL(k_bsk_to_lat_t64, dim3((items + 1) / 2), dim3(256), 0, s, std_polys, lat_polys, g_tw_h, n_polys, prec);
     BMIT_LAUNCH_CHECK();
     return 0;
 }
 
-template <int L, int LIMBS>
+template <int PREC, int L, int BG>
 static int launch_lat_t64(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_lat,
                           const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
     static std::atomic<uint64_t> configured{0};
     const size_t lds = (size_t)LT_LDS_WORDS * sizeof(double);
-    auto kern = k_blind_rotate_lat_t64<L, LIMBS>;
+    auto kern = k_blind_rotate_lat_t64<L, PREC, BG>;
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
     hipLaunchKernelGGL(kern, dim3(count), dim3(LT_THREADS), lds, s, small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n);
     BMIT_LAUNCH_CHECK();
@@ -573,14 +551,13 @@ static int launch_lat_t64(const u64 *small_cts, const uint32_t *lut_ids, const u
 }
 
 int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_lat,
-                            const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, int limbs, uint32_t levels,
+                            const double *g_tw_h, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
                             uint32_t base_log, hipStream_t s) {
     if (count == 0) return 0;
-    if (base_log != 15 || (limbs != 3 && limbs != 2)) return (int)hipErrorInvalidValue;
-    if (levels == 3 && limbs == 3) return launch_lat_t64<3, 3>(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s);
-    if (levels == 2 && limbs == 3) return launch_lat_t64<2, 3>(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s);
-    if (levels == 3 && limbs == 2) return launch_lat_t64<3, 2>(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s);
-    if (levels == 2 && limbs == 2) return launch_lat_t64<2, 2>(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s);
+#define BMIT_GO(P, L, B) \
+    if (prec == P && levels == L && base_log == B) return launch_lat_t64<P, L, B>(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s);
+    BMIT_FOR_EACH_SHAPE(BMIT_GO)
+#undef BMIT_GO
     return (int)hipErrorInvalidValue;
 }
 

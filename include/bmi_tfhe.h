@@ -47,7 +47,7 @@ typedef struct {
     uint32_t log_N;       /* log2 polynomial size (10) */
     uint32_t k;           /* GLWE dimension (1) */
     uint32_t bs_levels;   /* l: bootstrap decomposition levels (3; (2, 15) and (1, 23) on the 49-bit field at N <= 2048, */
-    uint32_t bs_base_log; /* bootstrap decomposition base log (15)                          (2, 15) on the 2^64 torus) */
+    uint32_t bs_base_log; /* bootstrap decomposition base log (15; 10 on the 2^64 torus)   (3 | 2, 10 | 15) on the torus) */
     uint32_t ks_levels;   /* keyswitch levels (8) */
     uint32_t ks_base_log; /* keyswitch base log (4) */
     uint32_t q_bits;      /* ciphertext modulus: 64 -> q = 2^64 - 2^32 + 1 (Goldilocks, integer kernels);
@@ -65,7 +65,8 @@ int bmi_default_params_for(uint32_t q_bits, bmi_params *out);
 
 /* Named parameter sets:
  *   "north_star"            BASELINE.json's shape (n 630, N 1024, k 1, l 3) on the 49-bit field - bmi_default_params
- *   "north_star_torus64"    the same on the 2^64 torus;  "north_star_goldilocks": on 2^64 - 2^32 + 1
+ *   "north_star_torus64"    the same shape on the 2^64 torus with Bg = 2^10 (two-limb key at 48 bits of precision, see
+ *                           bmi_set_bsk_precision);  "north_star_goldilocks": (l 3, Bg 2^15) on 2^64 - 2^32 + 1
  *   "secure128"             n 742, N 2048, k 1, l 2 x 15 bits, keyswitch 8 x 2 bits, 49-bit field, LWE noise 7.07e-6
  *                           (2^-17.1), GLWE noise 2^-44.  Security: the (dimension, noise / q) pairs are those of TFHE-rs'
  *                           published 128-bit set PARAM_MESSAGE_2_CARRY_2_KS_PBS (lwe_dimension 742, lwe std 7.07e-6;
@@ -181,20 +182,27 @@ int bmi_sync(bmi_ctx *ctx, void *stream);
  * 4 = the one-wavefront-per-transform latency kernel (2 is the two-wavefronts-per-transform one on the 49-bit field). */
 int bmi_set_kernel_variant(bmi_ctx *ctx, int variant);
 
-/* 2^64 torus only, before keygen / import: precision the bootstrap key is stored at.  64 (default): exact - every key
- * word is split into three 22-bit limbs.  42: every key word (generated here or imported) is rounded to a multiple of
- * 2^22 and split into two 21-bit limbs: 2/3 of the multiply-accumulates and inverse transforms of a CMUX (65-67 k PBS/s
- * against 51 k, 4.85 ms latency against 6.1).  The rounded key is the context's key from then on (bmi_export_keys
- * returns it; results are bit-exact against an oracle given that key).  Its price is noise: the rounding errors of a
- * row's mask words are summed over the ~N/2 set bits of the GLWE key when the row is used, so the effective key noise is
- * 2^-39.3 (from 2^-44 at the north-star set) and the bootstrap output noise 2^-15.15 (from 2^-19.85), both measured on the
- * formula (tests/test_gpu_parity.py).  A throughput option for flat PBS batches; circuits whose linear combinations amplify
- * the output noise (the encrypted inverse: L2 weight up to 75) should keep the exact key.  (The rounding only ever adds
- * noise to valid LWE samples; generating the key on the grid directly would instead round its own noise away.) */
+/* 2^64 torus only, before keygen / import: precision the bootstrap key is stored at.  No transform exists mod 2^64, so the
+ * external product is computed exactly over the integers from limbs of every key word (csrc/t64_common.hpp); the number of
+ * limbs follows from the precision:
+ *   64  exact key, three 22-bit limbs.  Default at Bg = 2^15 (51 k PBS/s, 5.5 ms per bootstrap).
+ *   48  every key word (generated here or imported) rounded to a multiple of 2^16, two 24-bit limbs: 2/3 of the
+ *       multiply-accumulates and inverse transforms.  Needs Bg <= 2^10 (a limb's sum must stay below p/2).  DEFAULT of the
+ *       torus parameter set ("north_star_torus64": l = 3, Bg = 2^10): the rounding errors of a row (2^15 / sqrt 3 per word,
+ *       summed over the ~N/2 set bits of the GLWE key: 2^18.7) stay under the key noise 2^20, and the finer base more than
+ *       pays for them - bootstrap output noise 2^-22.6 against 2^-19.85 of (Bg = 2^15, exact key), measured on the formula
+ *       (tests/test_gpu_parity.py).  The only precision the unrolled torus kernel takes (bmi_set_bsk_unroll).
+ *   42  round 2's option at Bg = 2^15: multiples of 2^22, two 21-bit limbs; effective key noise 2^-39.3, output noise
+ *       2^-15.15 - a throughput option for flat PBS batches, too noisy for the encrypted inverse.
+ * The rounded key is the context's key from then on (bmi_export_keys / bmi_export_bsk_unrolled return it; results are
+ * bit-exact against an oracle given that key; oracle/tfhe_oracle.c ora_round_key states the rule).  The rounding only ever
+ * adds noise to valid LWE samples; generating the key on the grid directly would instead round its own noise away. */
 int bmi_set_bsk_precision(bmi_ctx *ctx, uint32_t bits);
+/* the precision in force (64 on the prime fields) */
+int bmi_get_bsk_precision(const bmi_ctx *ctx, uint32_t *bits);
 
-/* 49-bit field at N = 1024, and at N = 2048 with l <= 2 (the secure128 shape): bootstrap-key unrolling (Zhou et al. 2018,
- * Bourse et al. 2018; unrolling factor 2).
+/* 49-bit field at N = 1024, and at N = 2048 with l <= 2 (the secure128 shape), and the 2^64 torus at its default set (Bg = 2^10,
+ * 48-bit key; k_blind_rotate_lat2u_t64): bootstrap-key unrolling (Zhou et al. 2018, Bourse et al. 2018; unrolling factor 2).
  * factor 1 (default): the blind rotation of CGGI, one LWE coefficient per step.  factor 2: a step absorbs two coefficients,
  *   ACC <- ACC + sum_{j<3} (X^(c_j) - 1) (K_j [.] ACC),  c = (a + a', a, a'),  K = GGSW(s s'), GGSW(s (1 - s')), GGSW((1 - s) s'),
  * with one decomposition and one set of forward transforms per step (half as many as the plain rotation; the factors X^c - 1

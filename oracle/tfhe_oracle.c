@@ -394,6 +394,20 @@ void ora_keygen_bsk_unrolled(const ora_params *P, u64 seed, const u64 *sk_small,
     free(msg);
 }
 
+/* 2^64 torus: a bootstrap key STORED AT `precision` BITS (64 = exact; the library's torus sets keep 48, or 42): every key
+ * word, read as a signed integer, is rounded half up to a multiple of 2^(64 - precision) - the same rounding rule as the
+ * decomposition's.  The rounded key is the key: it is what the library exports and what every consumer bootstraps with (the
+ * rounding only adds a uniform error of variance 2^(2 (64 - precision)) / 12 to valid GLWE samples). */
+void ora_round_key(u64 *key, size_t words, uint32_t precision) {
+    if (precision >= 64) return;
+    uint32_t drop = 64 - precision;
+    for (size_t i = 0; i < words; i++) {
+        i64 c = (i64)key[i];
+        i64 r = (c >> drop) + ((c >> (drop - 1)) & 1); /* round half up, no 64-bit overflow */
+        key[i] = (u64)r << drop;
+    }
+}
+
 /* LWE encryption of torus values under a binary key of dimension dim; ciphertext i
  * uses mask indices [(first+i)*(dim+1), ...) of stream ST_ENC_MASK. */
 void ora_lwe_encrypt(const u64 *key, uint32_t dim, double noise, u64 seed, u64 first, const u64 *torus, uint32_t count, u64 *out) {

@@ -49,7 +49,23 @@ def default_params(**kw):
     d.update(kw)
     if d["q_bits"] == 49 and "glwe_noise" not in kw:
         d["glwe_noise"] = 2.0 ** -40   # 49-bit modulus: keep the absolute noise above the integer grid
+    if d["q_bits"] == TORUS64 and "bs_base_log" not in kw:
+        d["bs_base_log"] = 10          # the torus set decomposes in base 2^10 (two-limb key at 48 bits of precision)
     return Params(**d)
+
+
+def default_bsk_precision(P):
+    """bits of precision the library stores a torus bootstrap key at by default (bmi_set_bsk_precision): 48 where the
+    decomposition base leaves room for two 24-bit limbs (Bg <= 2^10), else the exact key; other moduli: exact"""
+    return 48 if (P.q_bits == TORUS64 and P.bs_base_log <= 10) else 64
+
+
+def round_key(key, precision):
+    """a torus bootstrap key (plain or unrolled) stored at `precision` bits: words rounded half up, as signed integers, to
+    multiples of 2^(64 - precision) (ora_round_key); returns a new array"""
+    out = u64(key).copy()
+    lib().ora_round_key(_p(out), C.c_size_t(out.size), C.c_uint32(int(precision)))
+    return out
 
 
 def set_field(q_bits):

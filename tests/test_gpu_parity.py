@@ -80,7 +80,12 @@ def test_keygen_matches_oracle_keygen(eng, ora):
     K = to.keygen(P, SEED)
     assert np.array_equal(K.sk_small, sk_small) and np.array_equal(K.sk_big, sk_big)
     assert np.array_equal(K.ksk, ksk)
-    assert np.array_equal(K.bsk, bsk)
+    # the default torus set stores its bootstrap key at 48 bits of precision: the library's key is the oracle's, rounded by the
+    # oracle's own statement of the rule (ora_round_key); 64 bits (every other set) is the identity
+    assert eng.bsk_precision == to.default_bsk_precision(P) == (48 if eng.q_bits == 65 else 64)
+    assert np.array_equal(to.round_key(K.bsk, eng.bsk_precision), bsk)
+    if eng.bsk_precision != 64:
+        assert not np.array_equal(K.bsk, bsk) and not (bsk & np.uint64((1 << (64 - eng.bsk_precision)) - 1)).any()
 
 
 def test_encrypt_decrypt_roundtrip_and_oracle_phase(eng, ora):
@@ -275,19 +280,37 @@ def test_pbs_device_pointers_and_noise_budget(eng, ora):
     assert np.max(np.abs(err)) < 2.0 ** (dl - 9)  # half a box is 2^(dl-1)
 
 
-def cggi_output_variance(P, log_q):
+def cggi_output_variance(P, log_q, hw_small=None, hw_big=None):
     """Analytic variance (relative to q^2) of the phase error after one blind rotation, binary keys (CGGI):
     n CMUXes, each adding  l (k+1) N (Bg^2 + 2) / 12 * sigma_bsk^2  (digits uniform in [-Bg/2, Bg/2) against fresh key noise)
-    +  (1 + k N / 2) / (12 Bg^(2l))  (the rounding of the decomposition, carried by the binary GLWE key)."""
+    +  (1 + k N / 2) / (12 Bg^(2l))  (the rounding of the decomposition, carried by the binary GLWE key).
+    The rounding term as printed in the literature is a worst case: the rounding error of a CMUX is multiplied by the key bit
+    its GGSW encrypts, so only the hw_small SET bits of the LWE key contribute, and it is carried by the hw_big set bits of the
+    GLWE key.  With the weights given, the exact expectation is returned (it matters where the rounding term is not
+    negligible: the torus set, Bg = 2^10); without them, the textbook worst case."""
     N, k, l, Bg = P.N, P.k, P.bs_levels, 2.0 ** P.bs_base_log
     key = l * (k + 1) * N * (Bg * Bg + 2) / 12.0 * P.glwe_noise ** 2
-    rnd = (1 + k * N / 2.0) * (1.0 / (12.0 * Bg ** (2 * l)) - 1.0 / (12.0 * 4.0 ** log_q))
-    return P.n * (key + rnd)
+    rnd = (1 + (k * N / 2.0 if hw_big is None else hw_big)) * (1.0 / (12.0 * Bg ** (2 * l)) - 1.0 / (12.0 * 4.0 ** log_q))
+    return P.n * key + (P.n if hw_small is None else hw_small) * rnd
+
+
+def effective_params(eng):
+    """the engine's parameters with the key noise a bootstrap actually sees: a torus key stored at p < 64 bits carries, per row,
+    the rounding error of the body and of the mask words the GLWE key selects (uniform on 2^(64 - p): variance 2^(2 (64 - p)) / 12
+    each), on top of its Gaussian noise"""
+    from bmi_amd import tfhe
+    P = tfhe.Params(**{f: getattr(eng.P, f) for f, _ in tfhe.Params._fields_})
+    prec = eng.bsk_precision
+    if prec != 64:
+        hw = int(eng.export_keys()[1].sum())
+        P.glwe_noise = float(np.sqrt(P.glwe_noise ** 2 + (1 + hw) * 4.0 ** (64 - prec) / 12 / 2.0 ** 128))
+    return P
 
 
 def test_pbs_output_noise_matches_the_cggi_formula(eng):
     """the output noise of one PBS, measured over 4,096 bootstraps per modulus, against the analytic
-    CGGI variance for (n 630, N 1024, k 1, l 3, Bg 2^15).  Exact arithmetic adds no error of its own, so the measured
+    CGGI variance for (n 630, N 1024, k 1, l 3, Bg 2^15; the torus set: Bg 2^10 and a key stored at 48 bits, whose rounding error
+    enters the formula as key noise - effective_params).  Exact arithmetic adds no error of its own, so the measured
     variance must sit AT the formula (within sampling + the formula's uniform-digit idealisation) on all three
     moduli - in particular the 49-bit field is not noisier than its parameters say (its key noise is 2^-40 by choice,
     the 64-bit moduli use 2^-44).  Also: mean error ~ 0, worst sample far inside half a box (2^-5 of the torus)."""
@@ -309,7 +332,8 @@ def test_pbs_output_noise_matches_the_cggi_formula(eng):
     assert np.array_equal(eng.decrypt(out, dl), want)
     Q = eng.modulus
     err = np.array([((int(x) - (int(m) << dl)) + Q // 2) % Q - Q // 2 for x, m in zip(eng.phase(out), want)], dtype=np.float64) / float(Q)
-    measured, analytic = float(np.var(err)), cggi_output_variance(eng.P, eng.log_q)
+    sk_small, sk_big = eng.export_keys()[:2]
+    measured, analytic = float(np.var(err)), cggi_output_variance(effective_params(eng), eng.log_q, int(sk_small.sum()), int(sk_big.sum()))
     ratio = measured / analytic
     print(f"q_bits {eng.q_bits}: log2 std measured {0.5 * np.log2(measured):.2f}, CGGI {0.5 * np.log2(analytic):.2f}, "
           f"variance ratio {ratio:.3f}, max |err| 2^{np.log2(np.abs(err).max()):.2f}")
@@ -328,7 +352,7 @@ def test_torus_key_at_42_bits_of_precision_bit_exact_and_noise():
     from bmi_amd import tfhe
     from oracle import tfhe_oracle as to
     to.set_field(65)
-    P = to.default_params(q_bits=65)
+    P = to.default_params(q_bits=65, bs_base_log=15)
     exact = to.keygen(P, SEED + 9)
     rng = np.random.default_rng(43)
     table = rng.integers(-8, 8, 16)
@@ -336,8 +360,11 @@ def test_torus_key_at_42_bits_of_precision_bit_exact_and_noise():
     msgs = rng.integers(-8, 8, B)
     Q = 1 << 64
     for mode in ("generated", "imported"):
-        e = tfhe.Engine(tfhe.default_params(q_bits=65))
+        e = tfhe.Engine(tfhe.default_params(q_bits=65, bs_base_log=15))
         try:
+            assert e.bsk_precision == 64                         # the default at base 2^15 is the exact key
+            with pytest.raises(tfhe.BmiError):
+                e.set_bsk_precision(48)                          # two 24-bit limbs need Bg <= 2^10
             e.set_bsk_precision(42)
             if mode == "generated":
                 e.keygen(SEED + 9)
@@ -363,7 +390,7 @@ def test_torus_key_at_42_bits_of_precision_bit_exact_and_noise():
             assert np.array_equal(e.decrypt(out, dl), table[msgs + 8])
             err = np.array([((int(x) - (int(m) << dl)) + Q // 2) % Q - Q // 2 for x, m in zip(e.phase(out), table[msgs + 8])], dtype=np.float64) / Q
             # effective key noise: the body's rounding error + those of the k N / 2 key-selected mask words
-            Pe = tfhe.default_params(q_bits=65)
+            Pe = tfhe.default_params(q_bits=65, bs_base_log=15)
             words = 1 + Pe.k * Pe.N / 2.0
             Pe.glwe_noise = float(np.sqrt(Pe.glwe_noise ** 2 + words * 2.0 ** 44 / 12 / 2.0 ** 128))
             ratio = float(np.var(err)) / cggi_output_variance(Pe, 64)
@@ -442,9 +469,13 @@ def test_secure128_preset_bit_exact_noise_and_margin():
                                        (49, dict(n=211, bs_levels=2, bs_base_log=15)),
                                        (49, dict(n=211, bs_levels=1, bs_base_log=23)),
                                        (65, dict(n=211, bs_levels=2, bs_base_log=15)),
-                                       (65, dict(n=1024))],
-                         ids=["goldilocks64-n97", "p49-n97", "p49-n639", "p49-n1024-max", "p49-l2", "p49-l1-Bg23", "torus64-l2",
-                              "torus64-n1024-max"])
+                                       (65, dict(n=1024)),
+                                       (65, dict(n=211, bs_base_log=15)),
+                                       (65, dict(n=211, bs_levels=2)),
+                                       (65, dict(n=211, _precision=64)),
+                                       (65, dict(n=211, bs_base_log=15, _precision=42))],
+                         ids=["goldilocks64-n97", "p49-n97", "p49-n639", "p49-n1024-max", "p49-l2", "p49-l1-Bg23", "torus64-l2-Bg15",
+                              "torus64-n1024-max", "torus64-Bg15-exact-key", "torus64-l2", "torus64-Bg10-exact-key", "torus64-Bg15-key42"])
 def test_other_parameter_shape_bit_exact(q_bits, kw):
     """n = 97 (98 output columns: a ragged column block in the matrix-core keyswitch) with a 5 x 6-bit keyswitch
     decomposition, n = 639 (640 columns exactly) with 4 x 7-bit digits (|d| <= 64, the int8 limit of the matrix-core
@@ -453,8 +484,12 @@ def test_other_parameter_shape_bit_exact(q_bits, kw):
     against the oracle, every 4-bit message through a random table; an empty batch is a no-op on every entry point."""
     from bmi_amd import tfhe
     from oracle import tfhe_oracle as to
+    kw = dict(kw)
+    precision = kw.pop("_precision", None)     # torus: a non-default precision of the stored bootstrap key
     e = tfhe.Engine(tfhe.default_params(q_bits=q_bits, **kw))
     try:
+        if precision:
+            e.set_bsk_precision(precision)
         e.keygen(SEED + 1)
         sk_small, sk_big, bsk, ksk = e.export_keys()
         to.set_field(q_bits)
@@ -691,8 +726,9 @@ def test_pbs_known_answer_digests_on_gpu():
     kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pbs_kat.json")))
     h = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint64).tobytes()).hexdigest()  # noqa: E731
     for case in kat["cases"]:
-        e = tfhe.Engine(tfhe.default_params(q_bits=case["q_bits"], log_N=case["log_N"]))
+        e = tfhe.Engine(tfhe.default_params(q_bits=case["q_bits"], log_N=case["log_N"], **case["params"]))
         try:
+            assert e.bsk_precision == case["bsk_precision"]
             e.keygen(kat["seed"])
             sk_small, sk_big, bsk, ksk = e.export_keys()
             assert (h(sk_big), h(bsk), h(ksk)) == (case["sk_big"], case["bsk"], case["ksk"]), case
@@ -707,6 +743,11 @@ def test_pbs_known_answer_digests_on_gpu():
             for variant in ((1, 2, 3, 4) if case["log_N"] == 10 else ()):
                 e.set_kernel_variant(variant)
                 assert h(e.pbs_host(ct, np.full(len(kat["msgs"]), lid, np.uint32))) == case["bootstrapped"], variant
+            if "bootstrapped_unrolled" in case:      # the unrolled key of the same secrets, made at once (bmi_set_bsk_unroll)
+                e.set_kernel_variant(0)
+                e.set_bsk_unroll(2)
+                assert h(e.export_bsk_unrolled()) == case["bsk_unrolled"]
+                assert h(e.pbs_host(ct, np.full(len(kat["msgs"]), lid, np.uint32))) == case["bootstrapped_unrolled"]
         finally:
             e.close()
 

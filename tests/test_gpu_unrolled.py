@@ -113,7 +113,7 @@ def test_unrolled_other_shapes_bit_exact(kw):
 
 def test_unrolling_is_refused_where_no_kernel_exists():
     from bmi_amd import tfhe
-    for kw in (dict(q_bits=49, log_N=11), dict(q_bits=49, log_N=12), dict(q_bits=65), dict(q_bits=64)):
+    for kw in (dict(q_bits=49, log_N=11), dict(q_bits=49, log_N=12), dict(q_bits=65, bs_base_log=15), dict(q_bits=64)):
         e = tfhe.Engine(tfhe.default_params(**kw))
         try:
             with pytest.raises(tfhe.BmiError):

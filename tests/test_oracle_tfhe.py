@@ -297,6 +297,41 @@ def test_torus_pbs_evaluates_every_lut_entry(torus, p):
     ctx.close()
 
 
+def test_torus_key_stored_at_48_bits_rule_noise_and_pbs(torus):
+    """The default torus set keeps its bootstrap key at 48 bits of precision (ora_round_key: words rounded half up, as signed
+    integers, to multiples of 2^16).  The rule against its unsigned restatement (what the library computes) on edge words; the
+    error it adds (uniform on the grid: variance 2^32 / 12); decrypt(PBS(enc m)) == LUT[m] for every m with the ROUNDED plain
+    and unrolled keys at the set's own decomposition (l 3, Bg 2^10)."""
+    P = to.default_params(n=15, log_N=8, q_bits=to.TORUS64, lwe_noise=2.0 ** -40)
+    assert P.bs_base_log == 10 and to.default_bsk_precision(P) == 48
+    assert to.default_bsk_precision(to.default_params(q_bits=to.TORUS64, bs_base_log=15)) == 64
+    edge = np.array([0, 1 << 15, (1 << 15) - 1, (3 << 15), 2 ** 64 - 1, 2 ** 64 - (1 << 15), 2 ** 64 - (1 << 15) - 1, 2 ** 63 - 1, 2 ** 63,
+                     2 ** 63 - (1 << 15)], dtype=np.uint64)
+    words = np.concatenate([edge, RNG.integers(0, 2 ** 63, 5000, dtype=np.uint64) * np.uint64(2) + RNG.integers(0, 2, 5000, dtype=np.uint64)])
+    for prec in (48, 42):
+        drop = 64 - prec
+        want = np.array([(((int(w) + (1 << (drop - 1))) >> drop) << drop) % (1 << 64) for w in words], dtype=np.uint64)
+        got = to.round_key(words, prec)
+        assert np.array_equal(got, want) and not (got & np.uint64((1 << drop) - 1)).any()
+        d = (got - words).astype(np.int64)[len(edge):].astype(np.float64)
+        assert np.abs(d).max() <= 2.0 ** (drop - 1) and abs(np.var(d) / (4.0 ** drop / 12) - 1) < 0.1
+    assert np.array_equal(to.round_key(words, 64), words)
+    K = to.keygen(P, 35)
+    bsk = to.round_key(K.bsk, 48)
+    ctx = to.Ctx(P, bsk, K.ksk)
+    ctx.set_bsk_unrolled(to.round_key(to.keygen_bsk_unrolled(P, 35, K.sk_small, K.sk_big), 48))
+    msgs = np.arange(-8, 8)
+    table = np.array([(5 * m * m + 3 * m + 2) % 16 - 8 for m in msgs], dtype=np.int64)
+    dl = 59
+    tv = to.make_test_vector(P.log_N, 4, table, dl)
+    ct = to.lwe_encrypt(K.sk_big, P.glwe_noise, 7, 0, to.encode(msgs, dl))
+    for unrolled in (False, True):
+        out = ctx.pbs(ct, tv[None, :], np.zeros(16, np.uint32), unrolled=unrolled)
+        assert list(to.decode(to.lwe_phase(K.sk_big, out), dl)) == list(table)
+        assert not (out & np.uint64(0xFFFF)).any()        # the accumulator stays on the key's grid
+    ctx.close()
+
+
 # ----------------------------------------------------------------------------------------------------------
 # The fast path (bench.py's CPU baseline): bit for bit the generic path.
 def test_fast_path_equals_generic_path(field49):
