@@ -21,9 +21,11 @@ no-reuse convention, against peak HBM bandwidth) for the dominant kernel (blind 
 duration is measured live with events on the launch stream; `alu` adds the vector-ALU view the path is
 really bound by.  `cpu_baseline` times the oracle's fast path (exact f64 arithmetic, vectorised 32 x 32
 transforms, OpenMP over the batch; bit-identical to the generic oracle, re-checked on a sample inside the run) on this
-box's host cores, on a bounded sample of the same ciphertexts (N=1, rank 0 only).  `roofline_q64_torus` /
-`roofline_q64_goldilocks` repeat the batch on the 2^64 torus (Concrete's modulus) and on the Goldilocks field;
-`config.output_noise` compares the timed outputs' noise with the analytic CGGI variance.
+box's host cores, on a bounded sample of the same ciphertexts (N=1, rank 0 only).  `torus64` / `torus64_unrolled_key` repeat the
+batch on the 2^64 torus, Concrete's own ciphertext modulus (top-level value_torus64 / frac_torus64 / value_torus64_unrolled ...);
+`unrolled_key_49` and `roofline_q64_goldilocks` on the unrolled 49-bit key and on the Goldilocks field;
+`config.output_noise` compares the timed outputs' noise with the analytic CGGI variance; `roofline.alu` states the fraction of
+the vector-ALU issue roof (static instruction counts x live rate / 1,024 SIMDs x sampled shader clock).
 """
 import argparse
 import json
@@ -41,6 +43,48 @@ import numpy as np  # noqa: E402
 BSK_BYTES_PER_PBS = 630 * 4 * 3 * 1024 * 8  # 61,931,520 (SURVEY.md §8d / BASELINE.md §3)
 MODMUL_PER_PBS = 33_546_240                # SURVEY.md §8d (radix-2 count, the reference figure)
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+class SclkSampler:
+    """Samples the shader clock from sysfs (pp_dpm_sclk: the line marked '*') while the timed kernels run; median of the samples.
+    Falls back to the spec maximum (2,400 MHz) when the file cannot be read - the fraction printed is then a lower bound."""
+
+    def __init__(self):
+        import glob
+        import threading
+        self.files = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.samples, self._stop = [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        best = 0.0
+        for f in self.files:
+            try:
+                for line in open(f).read().splitlines():
+                    if line.rstrip().endswith("*"):
+                        best = max(best, float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()))
+            except Exception:
+                pass
+        return best
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read()
+            if v > 0:
+                self.samples.append(v)
+            self._stop.wait(0.01)
+
+    def start(self):
+        self._t.start()
+
+    def stop(self):
+        self._stop.set()
+        self._t.join()
+
+    def result(self):
+        if self.samples:
+            return float(np.median(self.samples)), f"sysfs pp_dpm_sclk, median of {len(self.samples)} samples during the timed steps"
+        return 2400.0, "spec maximum (pp_dpm_sclk not readable here): the fraction is a lower bound"
 
 
 def free_port():
@@ -78,11 +122,15 @@ def rehearse_plumbing(args, rank, world):
     dist.barrier()
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # the ranks' parts of the whole-job batch, as main() cuts them (weak scaling: B * world ciphertexts, contiguous ranges)
+    from bmi_amd.shard import shard_range
+    ranges = [None] * world
+    dist.all_gather_object(ranges, list(shard_range(args.batch * world, rank, world)))
     if rank == 0:
         print(json.dumps({"metric": "PBS/sec per GPU + encrypted n x n inverse wall-clock (n=2,3,4)", "value": None,
                           "unit": "PBS/s", "n_gpus": world, "world_size_seen": dist.get_world_size(), "steps": args.steps,
                           "warmup": args.warmup, "rehearsal": "plumbing only: no PBS executed, nothing measured",
-                          "max_over_ranks_check": float(t.item())}))
+                          "max_over_ranks_check": float(t.item()), "batch_per_gpu": args.batch, "shard_ranges": ranges}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -182,11 +230,14 @@ def main():
         step()
     barrier()
     events = []
+    clock = SclkSampler()
+    clock.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(events)
     barrier()
     elapsed = time.perf_counter() - t0
+    clock.stop()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -199,25 +250,67 @@ def main():
     want = np.where(lut_sel == 0, msgs, rnd_table[msgs + 8])
     verified = bool(np.array_equal(dec, want))
 
-    KERNEL = {64: "k_blind_rotate_tp", 49: "k_blind_rotate_tpx49", 65: "k_blind_rotate_t64"}
+    KERNEL = {64: "k_blind_rotate_tp<2>", 49: "k_blind_rotate_tpx49<13, 3, 15>", 65: "k_blind_rotate_t64<48, 3, 10>"}
     ARITH = {64: "integers mod 2^64-2^32+1 in u64 (64-bit integer VALU)",
              49: "exact integers mod 2^49-720895 carried in f64 (FMA pairs); keyswitch: int8 matrix cores, int32 sums",
-             65: "ciphertexts mod 2^64 (Concrete's torus); exact external products: digit transforms mod 2^49-720895 in f64 "
-                 "against three 22-bit limbs of every key word, recombined mod 2^64; keyswitch: int8 matrix cores"}
+             65: "ciphertexts mod 2^64 (Concrete's torus), Bg 2^10; exact external products: digit transforms mod 2^49-720895 in f64 "
+                 "against two 24-bit limbs of every key word (key stored at 48 bits of precision), recombined mod 2^64; keyswitch: "
+                 "int8 matrix cores"}
     DTYPE = {64: "u64", 49: "f64", 65: "u64/f64"}
-    # output noise of the timed batch against the analytic CGGI variance (tests/test_gpu_parity.py holds it to +-15 %)
+
+    def key_weights(e):
+        sk_small, sk_big = e.export_keys()[:2]
+        pairs = sk_small[0::2].copy()
+        pairs[:sk_small[1::2].size] |= sk_small[1::2]
+        return int(sk_small.sum()), int(sk_big.sum()), int(pairs.sum())
+
+    # output noise of the timed batch against the analytic CGGI variance (tests/test_gpu_parity.py holds it to +-15 %).  The
+    # rounding term of a step is multiplied by the key bit its GGSW encrypts, so it is counted for the SET bits of the LWE key
+    # (unrolled: the pairs whose bits are not both zero, doubled by the factor X^c - 1); a torus key stored at p < 64 bits adds
+    # the rounding error of a row's body and key-selected mask words to the key noise
     def output_noise(e, outputs, expected, unrolled=False):
         Pp, Qm, dlx = e.P, e.modulus, e.delta_log()
         err = np.array([((int(x) - (int(m) << dlx)) + Qm // 2) % Qm - Qm // 2 for x, m in zip(e.phase(outputs), expected)],
                        dtype=np.float64) / float(Qm)
+        hw_small, hw_big, live_pairs = key_weights(e)
         Bg = 2.0 ** Pp.bs_base_log
-        key_term = Pp.n * Pp.bs_levels * (Pp.k + 1) * Pp.N * (Bg * Bg + 2) / 12.0 * Pp.glwe_noise ** 2
-        dec_term = Pp.n * (1 + Pp.k * Pp.N / 2.0) / (12.0 * Bg ** (2 * Pp.bs_levels))
-        # unrolled key: three products per pair of coefficients, each scaled by X^c - 1 (squared norm 2), half the decompositions
-        analytic = 3 * key_term + dec_term / 2 if unrolled else key_term + dec_term
+        prec = e.bsk_precision
+        sigma2 = Pp.glwe_noise ** 2 + ((1 + hw_big) * 4.0 ** (64 - prec) / 12 / 2.0 ** 128 if prec != 64 else 0.0)
+        key_term = Pp.n * Pp.bs_levels * (Pp.k + 1) * Pp.N * (Bg * Bg + 2) / 12.0 * sigma2
+        rnd = (1 + hw_big) / (12.0 * Bg ** (2 * Pp.bs_levels))
+        analytic = 3 * key_term + 2 * live_pairs * rnd if unrolled else key_term + hw_small * rnd
         return {"samples": int(err.size), "log2_std_measured": float(0.5 * np.log2(np.var(err))),
                 "log2_std_cggi_formula": float(0.5 * np.log2(analytic)), "variance_ratio": float(np.var(err) / analytic),
-                "log2_max_abs": float(np.log2(np.abs(err).max())), "log2_half_box": -6.0}
+                "log2_max_abs": float(np.log2(np.abs(err).max())), "log2_half_box": -6.0,
+                "bsk_precision_bits": int(prec)}
+
+    # shader clock while the timed kernels ran (sysfs, sampled by a thread during the timed region); the spec maximum if unreadable
+    sclk_mhz, sclk_src = clock.result()
+
+    # the vector-ALU roof (what the blind rotation is bound by): issue cycles of the kernel's vector instructions per second
+    # against 1,024 SIMDs x shader clock.  Issue cost per wave64 instruction on a SIMD-32: 2 cycles, f64 and 64-bit integer
+    # instructions 4 (MI355X_MICROARCH.md: `v_fma_f32` 2 cycles; f64 runs at half the f32 rate).  Instruction counts: static, one
+    # step of the kernel's main loop (tools/isa_count.py -> profiles/r03_isa_counts.json)
+    isa = {}
+    try:
+        isa = json.load(open(os.path.join(REPO, "profiles", "r03_isa_counts.json")))["kernels"]
+    except Exception:
+        pass
+
+    def alu_roof(kernel, kernel_ms, count, n_lwe, waves_per_ct=2, steps_per_ct=None):
+        c = isa.get(kernel)
+        if not c:
+            return {"bound": "valu issue", "error": f"no static instruction count for {kernel} in profiles/r03_isa_counts.json"}
+        steps = n_lwe if steps_per_ct is None else steps_per_ct
+        cyc_per_ct = float(c["valu_issue_cycles"]) * waves_per_ct * steps
+        achieved = cyc_per_ct * count / (kernel_ms * 1e-3)
+        peak = 1024 * sclk_mhz * 1e6
+        return {"bound": "valu issue (f64)", "achieved": achieved, "peak": peak, "unit": "SIMD issue cycles/s", "frac": achieved / peak,
+                "valu_instructions_per_step_per_wavefront": c["valu"], "of_them_f64": c["valu_f64"],
+                "valu_issue_cycles_per_step_per_wavefront": c["valu_issue_cycles"], "wavefronts_per_ciphertext": waves_per_ct,
+                "steps_per_ciphertext": steps, "sclk_mhz": sclk_mhz, "sclk_source": sclk_src,
+                "source": "static ISA count (profiles/r03_isa_counts.json) x live launch rate; peak = 256 CUs x 4 SIMDs x sclk",
+                "modmul_per_s": MODMUL_PER_PBS * count / (kernel_ms * 1e-3), "modmul_per_pbs": MODMUL_PER_PBS}
 
     total_pbs = B * world * args.steps
     value = total_pbs / elapsed
@@ -226,12 +319,15 @@ def main():
     tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath)).get("kernels", {}).get(KERNEL[eng.q_bits], {})
-            if tj.get("batch") == B:
-                traffic = tj.get("bytes_per_launch")
-                valu_busy = tj.get("valu_busy_frac")
+            for tj in json.load(open(tpath)).get("entries", []):
+                if tj.get("kernel") == KERNEL[eng.q_bits] and tj.get("batch") == B:
+                    traffic = tj.get("bytes_per_launch")
+                    valu_busy = tj.get("valu_busy_frac")
         except Exception:
             traffic = valu_busy = None
+    alu = alu_roof(KERNEL[eng.q_bits], br_ms, B, P.n)
+    alu["valu_busy_frac_profiled"] = valu_busy
+    alu["valu_busy_source"] = "profiled-static (waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, profiles/hbm_traffic.json)"
     res = {
         "metric": "PBS/sec per GPU + encrypted n x n inverse wall-clock (n=2,3,4)", "value": value, "unit": "PBS/s",
         "n_gpus": world, "world_size_seen": (dist.get_world_size() if dist is not None else 1),
@@ -239,25 +335,24 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE[eng.q_bits], "data": "synthetic",
         "config": {"workload": f"pbs_batch: B={B} LWE ciphertexts per GPU per step, TFHE n=630 N=1024 k=1 l=3 "
-                               f"(Bg=2^15, ks 8x4 bits), q_bits={eng.q_bits}, 4-bit signed messages, 2 LUTs (identity, random)",
+                               f"(Bg=2^{P.bs_base_log}, ks 8x4 bits), q_bits={eng.q_bits}, 4-bit signed messages, 2 LUTs (identity, random)",
                    "arithmetic": ARITH[eng.q_bits],
                    "keys": "bmi_keygen_insecure_deterministic(0x5EED): one key set replicated on every rank without an exchange",
                    "batch_per_gpu": B, "pbs_per_gpu_per_s": value / world, "verified_decrypt": verified,
                    "output_noise": output_noise(eng, out, want) if rank == 0 else None,
                    "derived_reference_pbs_per_s_64core_cpu": "35-69 (derived, BASELINE.md §1)"},
-        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+        "roofline": {"bound": "hbm", "physical_bound": "valu issue (f64): see `alu`", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "measured_hbm_frac": (None if traffic is None else traffic / (br_ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
                      "traffic_source": "profiled-static: rocprofv3 --pmc pass of this command, profiles/hbm_traffic.json "
                                        "(counters cannot be read from inside the process)",
                      "convention": "north star: bootstrap-key bytes per PBS (no reuse) x PBS per launch / launch time vs peak "
                                    "HBM; NOT a physical roof here - the key is shared by the batch and stays in L2/MALL "
-                                   "(measured traffic is ~1 % of it); the binding resource is under `alu`",
+                                   "(measured traffic is ~1 % of it); the binding resource is under `alu`, whose frac is a "
+                                   "fraction of a physical roof",
                      "kernel": KERNEL[eng.q_bits], "kernel_ms": br_ms,
                      "algorithmic_bytes_per_pbs": BSK_BYTES_PER_PBS,
-                     "alu": {"bound": "valu (f64 issue)" if eng.q_bits != 64 else "valu (64-bit integer issue)",
-                             "modmul_per_s": MODMUL_PER_PBS * B / (br_ms * 1e-3), "modmul_per_pbs": MODMUL_PER_PBS,
-                             "valu_busy_frac_profiled": valu_busy,
-                             "valu_busy_source": "profiled-static (2 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, same file)"}},
+                     "alu": alu},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -315,26 +410,29 @@ def main():
         octx.close()
 
     if rank == 0 and world == 1 and args.q_bits is None and not args.no_second_field:
-        # the same batch on the 2^64 torus and on the Goldilocks field: 1 warm-up + 3 timed steps each, kernel time by events;
-        # reported beside the headline, never `value`
-        def other_modulus(qb, key_bits=None, unroll=False):
-            e2 = tfhe.Engine(tfhe.default_params(q_bits=qb, **({"glwe_noise": 2.0 ** -41} if unroll else {})), device=dev_index)
+        # the same batch on the 2^64 torus (Concrete's own ciphertext modulus: a first-class result, also printed at the top level as
+        # value_torus64 / frac_torus64), with the unrolled keys, and on the Goldilocks field: 1 warm-up + 3 timed steps each, kernel
+        # time by events; reported beside the headline, never `value`
+        def leg(qb, unroll=False, inverses=False):
+            kw = {"glwe_noise": 2.0 ** -41} if (unroll and qb == 49) else {}
+            e2 = tfhe.Engine(tfhe.default_params(q_bits=qb, **kw), device=dev_index)
             try:
-                if key_bits:
-                    e2.set_bsk_precision(key_bits)
                 if unroll:
                     e2.set_bsk_unroll(2)
                 e2.keygen(0x5EED)
                 dl2 = e2.delta_log()
                 i2 = e2.lut_register(np.arange(-8, 8), 4, dl2)
                 r2 = e2.lut_register(rnd_table, 4, dl2)
-                d_in2 = torch.from_numpy(e2.encrypt(msgs, dl2).view(np.int64)).to(dev)
+                ct2 = e2.encrypt(msgs, dl2)
+                d_in2 = torch.from_numpy(ct2.view(np.int64)).to(dev)
                 d_ids2 = torch.from_numpy(np.where(lut_sel == 0, i2, r2).astype(np.int32)).to(dev)
                 d_small2 = torch.empty((B, P.small), dtype=torch.int64, device=dev)
                 d_out2 = torch.empty_like(d_in2)
                 e2.pbs(d_in2, d_ids2, B, d_out2, stream)
                 torch.cuda.synchronize()
                 ev = []
+                ck = SclkSampler()
+                ck.start()
                 t1 = time.perf_counter()
                 for _ in range(3):
                     e2.keyswitch(d_in2, B, d_small2, stream)
@@ -345,68 +443,99 @@ def main():
                     ev.append((a, b))
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t1) / 3
+                ck.stop()
                 kms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-                ok2 = bool(np.array_equal(e2.decrypt(d_out2.cpu().numpy().view(np.uint64), dl2), want))
-                gbs = BSK_BYTES_PER_PBS * B / (kms * 1e-3) / 1e9
                 out2 = d_out2.cpu().numpy().view(np.uint64)
+                ok2 = bool(np.array_equal(e2.decrypt(out2, dl2), want))
+                Pe = e2.P
+                plain_key_bytes = Pe.n * 4 * Pe.bs_levels * Pe.N * 8
+                gbs = plain_key_bytes * B / (kms * 1e-3) / 1e9
+                kname = ({49: "k_blind_rotate_lat2u_49<3, 15>", 65: "k_blind_rotate_lat2u_t64<3, 10, 48>"}[qb] if unroll else KERNEL[qb])
                 rep = {"q_bits": qb, "pbs_per_s": B / dt, "ms_per_step": dt * 1e3, "verified_decrypt": ok2,
+                       "bs_base_log": int(Pe.bs_base_log), "bsk_precision_bits": int(e2.bsk_precision),
                        "output_noise": output_noise(e2, out2, want, unrolled=unroll),
-                       "kernel": "k_blind_rotate_lat2u_49" if unroll else KERNEL[qb], "kernel_ms": kms, "achieved": gbs,
-                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "arithmetic": ARITH[qb]}
+                       "kernel": kname, "kernel_ms": kms, "achieved": gbs,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "arithmetic": ARITH[qb],
+                       "frac_convention": "north star: the PLAIN bootstrap key's bytes per PBS (61,931,520 B, no reuse) x PBS per launch / "
+                                          "launch time vs 8 TB/s - the figure BASELINE.json's target (1e5 PBS/s = 0.774) is stated in"}
                 if unroll:
-                    # latency of one bootstrap and of one full round of 256 (events around the kernel), the oracle's unrolled
-                    # blind rotation on a few ciphertexts of the batch, then the encrypted inverses on this engine
-                    for cnt in (1, 256):
+                    own = (Pe.n + 1) // 2 * 3 * 4 * Pe.bs_levels * Pe.N * 8
+                    rep["frac_own_key_bytes"] = own * B / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    rep["own_key_bytes_per_pbs"] = own
+                else:   # wave-pair kernels: static instruction count x live rate against the issue roof at the clock sampled here
+                    sm, ss = ck.result()
+                    c = isa.get(kname)
+                    if c:
+                        cyc = float(c["valu_issue_cycles"]) * 2 * Pe.n * B / (kms * 1e-3)
+                        rep["alu"] = {"bound": "valu issue (f64)", "achieved": cyc, "peak": 1024 * sm * 1e6, "frac": cyc / (1024 * sm * 1e6),
+                                      "unit": "SIMD issue cycles/s", "sclk_mhz": sm, "sclk_source": ss,
+                                      "valu_instructions_per_step_per_wavefront": c["valu"]}
+                # latency of one bootstrap and of one full round of 256 (events around the kernel)
+                for cnt in (1, 256):
+                    e2.blind_rotate(d_small2, d_ids2, cnt, d_out2, stream)
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(5):
                         e2.blind_rotate(d_small2, d_ids2, cnt, d_out2, stream)
-                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        a.record()
-                        for _ in range(5):
-                            e2.blind_rotate(d_small2, d_ids2, cnt, d_out2, stream)
-                        b.record()
-                        torch.cuda.synchronize()
-                        rep[f"latency_ms_{cnt}"] = a.elapsed_time(b) / 5
-                    if not args.no_cpu_baseline:
-                        from oracle import tfhe_oracle as to
-                        _, _, bsk_u, ksk_u = e2.export_keys()
-                        oc = to.Ctx(to.default_params(q_bits=49), bsk_u, ksk_u)
+                    b.record()
+                    torch.cuda.synchronize()
+                    rep[f"latency_ms_{cnt}"] = a.elapsed_time(b) / 5
+                if not args.no_cpu_baseline and (unroll or qb == 65):
+                    # the oracle's blind rotation (plain or unrolled mode) on a few ciphertexts of the batch: bit for bit
+                    from oracle import tfhe_oracle as to
+                    _, _, bsk_u, ksk_u = e2.export_keys()
+                    oc = to.Ctx(to.default_params(q_bits=qb), bsk_u, ksk_u)
+                    if unroll:
                         oc.set_bsk_unrolled(e2.export_bsk_unrolled())
-                        tv2 = np.stack([e2.lut_get(i2), e2.lut_get(r2)])
-                        pick = np.arange(0, B, max(1, B // 8))[:8]
-                        wantu = oc.pbs(d_in2[torch.from_numpy(pick).to(dev)].cpu().numpy().view(np.uint64), tv2, lut_sel[pick].astype(np.uint32), unrolled=True)
-                        rep["bit_exact_vs_oracle_unrolled"] = bool(np.array_equal(wantu, out2[pick]))
-                        oc.close()
-                        to.set_field(eng.q_bits)
-                    if not args.no_inverse:
-                        from bmi_amd import inverse_bench
-                        sizes = tuple(int(x) for x in args.inverse_sizes.split(",") if x)
-                        rep["encrypted_inverse_wall_clock"] = inverse_bench.run(e2, sizes)
+                    tv2 = np.stack([e2.lut_get(i2), e2.lut_get(r2)])
+                    pick = np.arange(0, B, max(1, B // 6))[:6]
+                    wantu = oc.pbs(ct2[pick], tv2, lut_sel[pick].astype(np.uint32), unrolled=unroll)
+                    rep["bit_exact_vs_oracle"] = bool(np.array_equal(wantu, out2[pick]))
+                    oc.close()
+                    to.set_field(eng.q_bits)
+                if inverses and not args.no_inverse:
+                    from bmi_amd import inverse_bench
+                    sizes = tuple(int(x) for x in args.inverse_sizes.split(",") if x)
+                    rep["encrypted_inverse_wall_clock"] = inverse_bench.run(e2, sizes)
                 return rep
             finally:
                 e2.close()
-        for name, qb, kb in (("roofline_q64_torus", 65, None), ("roofline_q64_torus_key42", 65, 42), ("roofline_q64_goldilocks", 64, None)):
-            if qb == eng.q_bits:
+
+        INV_FIELDS = ("len", "ints", "evaluate_s", "end_to_end_s", "ms_per_level", "pbs", "depth", "matches_plaintext_circuit")
+        legs = (("torus64", 65, False, False), ("torus64_unrolled_key", 65, True, True), ("unrolled_key_49", 49, True, True),
+                ("roofline_q64_goldilocks", 64, False, False))
+        for name, qb, un, inv in legs:
+            if qb == eng.q_bits and not un:
                 continue
             try:
-                res[name] = other_modulus(qb, kb)
-                if kb:
-                    res[name]["key"] = ("bootstrap key rounded to 42 bits of precision (two 21-bit limbs): effective key noise 2^-39.3, "
-                                        "output noise 2^-15.15 (the formula printed here is for the exact key); a throughput option")
+                res[name] = leg(qb, un, inv)
             except Exception as e:  # reported, never hidden
                 res[name] = {"q_bits": qb, "error": repr(e)}
-        if eng.q_bits == 49:
-            # bootstrap-key unrolling (bmi_set_bsk_unroll(ctx, 2)): two LWE coefficients per blind-rotation step, key noise
-            # 2^-41 so that the output noise stays at the default set's; an option, never `value`
-            try:
-                res["unrolled_key_49"] = other_modulus(49, unroll=True)
-                res["unrolled_key_49"]["key"] = ("unrolled bootstrap key, 1.5 x the plain key (92.9 MB); glwe_noise 2^-41 (plain default: 2^-40) "
-                                                 "keeps the output noise of the default set; `achieved` / `frac` use the PLAIN key's bytes per PBS")
-            except Exception as e:
-                res["unrolled_key_49"] = {"error": repr(e)}
-            # the same inverses, found next to the plain-key ones (the wall-clocks to quote for EncryptedMatrixInversion(unroll=True))
-            if isinstance(res["unrolled_key_49"].get("encrypted_inverse_wall_clock"), dict):
-                res["config"]["encrypted_inverse_wall_clock_unrolled_key"] = {
-                    k: {f: v.get(f) for f in ("len", "ints", "evaluate_s", "end_to_end_s", "ms_per_level", "pbs", "depth", "matches_plaintext_circuit")}
-                    for k, v in res["unrolled_key_49"]["encrypted_inverse_wall_clock"].items()}
+        if "kernel_ms" in res.get("torus64", {}):
+            res["torus64"]["key"] = ("the torus parameter set: (l, Bg) = (3, 2^10), bootstrap key stored at 48 bits of precision (two 24-bit "
+                                     "limbs, bmi_set_bsk_precision); CGGI's plain blind rotation")
+            # first-class torus results (Concrete's own ciphertext modulus)
+            res["value_torus64"] = res["torus64"]["pbs_per_s"]
+            res["frac_torus64"] = res["torus64"]["frac"]
+            res["alu_frac_torus64"] = res["torus64"].get("alu", {}).get("frac")
+            res["latency_ms_torus64"] = res["torus64"]["latency_ms_1"]
+        if "kernel_ms" in res.get("torus64_unrolled_key", {}):
+            res["torus64_unrolled_key"]["key"] = ("the same set with the unrolled bootstrap key (1.5 x the plain key), two LWE coefficients per "
+                                                  "step; key noise unchanged (2^-44): output noise 2^-22.7")
+            res["value_torus64_unrolled"] = res["torus64_unrolled_key"]["pbs_per_s"]
+            res["frac_torus64_unrolled"] = res["torus64_unrolled_key"]["frac"]
+            res["latency_ms_torus64_unrolled"] = res["torus64_unrolled_key"]["latency_ms_1"]
+            inv = res["torus64_unrolled_key"].get("encrypted_inverse_wall_clock")
+            if isinstance(inv, dict):
+                res["config"]["encrypted_inverse_wall_clock_torus64_unrolled_key"] = {k: {f: v.get(f) for f in INV_FIELDS} for k, v in inv.items()}
+                res["inverse_3x3_s_torus64"] = inv.get("3x3", {}).get("evaluate_s")
+        if "kernel_ms" in res.get("unrolled_key_49", {}):
+            res["unrolled_key_49"]["key"] = ("unrolled bootstrap key, 1.5 x the plain key (92.9 MB); glwe_noise 2^-41 (plain default: 2^-40) "
+                                             "keeps the output noise of the default set; `frac` uses the PLAIN key's bytes per PBS (north-star "
+                                             "convention), `frac_own_key_bytes` the unrolled key's")
+            inv = res["unrolled_key_49"].get("encrypted_inverse_wall_clock")
+            if isinstance(inv, dict):   # the wall-clocks to quote for EncryptedMatrixInversion(unroll=True)
+                res["config"]["encrypted_inverse_wall_clock_unrolled_key"] = {k: {f: v.get(f) for f in INV_FIELDS} for k, v in inv.items()}
 
     if not args.no_inverse and rank == 0 and world == 1:
         try:

@@ -242,52 +242,59 @@ def _comb3(v):
     return s2 if s2 else (s1 if s1 else s0)
 
 
+def _neg(c, v):
+    """[v < 0] for v in [-15, 15] in one look-up (Circuit.lut_neg); plain values pass through"""
+    return c.lut_neg(v) if isinstance(v, Lin) else int(int(v) < 0)
+
+
 def _wide_borrows(c, deltas):
-    """Borrow look-ahead for digit differences in {-1, 0, 1} with 5-bit look-ups (Circuit.lut_odd): the first
-    level reads sliding windows of FOUR positions (sign(8 d_i + 4 d_{i-1} + 2 d_{i-2} + d_{i-3})), later levels
-    combine THREE signals at a time (spans 4, 12, 36, ...).  A borrow BIT is not an odd function, so bits come from
-    ordinary look-ups: directly from a window of up to three positions, from a two-way combine as soon as two
-    signals reach position 0 together, or by converting a signal that already does.  33 positions: 4 levels
-    (window-3 + doubling: 5); 23 positions: 3 (4).  Returns bits[i] = borrow out of position i."""
+    """Borrow look-ahead for digit differences in {-1, 0, 1} with 5-bit look-ups: the first level reads sliding windows
+    of FOUR positions (sign(8 d_i + 4 d_{i-1} + 2 d_{i-2} + d_{i-3}), Circuit.lut_odd), later levels combine THREE
+    signals at a time (spans 4, 12, 36, ...).  A borrow BIT is [window or packed signals < 0], which Circuit.lut_neg
+    reads off the same 5-bit argument in the same level - so the bits of positions 0..3 come out of level 1, those below
+    12 out of level 2, below 36 out of level 3: a 33-digit subtraction has all its borrows after THREE levels (four with
+    a separate signal-to-bit conversion, five with window-3 + doubling).  Returns bits[i] = borrow out of position i."""
     m = len(deltas)
     S = [None] * m
     bits = [None] * m
     sign = lambda v: (v > 0) - (v < 0)  # noqa: E731
     for i in range(m):
-        if i <= 2:
-            w = deltas[i] * 4
-            if i >= 1:
-                w = w + deltas[i - 1] * 2
-            if i >= 2:
-                w = w + deltas[i - 2]
-            bits[i] = lut(c, w, lambda v: int(v < 0))     # narrow window reaching position 0: final
-            S[i] = lut(c, w, sign)
-        else:
-            w = deltas[i] * 8 + deltas[i - 1] * 4 + deltas[i - 2] * 2 + deltas[i - 3]
-            S[i] = c.lut_odd(w, sign) if isinstance(w, Lin) else sign(int(w))
+        w = deltas[i] * 8 if i >= 3 else deltas[i] * (1 << i)
+        for t in range(1, min(i, 3) + 1):
+            w = w + deltas[i - t] * (1 << ((3 if i >= 3 else i) - t))
+        if i <= 3:
+            bits[i] = _neg(c, w)                          # the window reaches position 0: final
+        if any(j < m for j in (i + 4, i + 8)) or i > 3:   # still an operand of a later combine
+            S[i] = (c.lut_odd(w, sign) if isinstance(w, Lin) else sign(int(w)))
     return _lookahead_bits(c, S, 4, bits)
 
 
 def _lookahead_bits(c, S, span, bits):
-    """Finishes a look-ahead: S[i] is the combined signal of positions max(0, i - span + 1) .. i; fills the missing
-    bits[i] = [combined signal of positions 0..i is 'generate'] with three-way signal combines (lut_odd) and
-    ordinary look-ups for the bits (see _wide_borrows)."""
+    """Finishes a look-ahead: S[i] is the combined signal of positions max(0, i - span + 1) .. i (None where it is never
+    read); fills the missing bits[i] = [combined signal of positions 0..i is 'generate'].  Per level: a position whose
+    two (three) packed signals reach position 0 gets its bit from that packed value directly (Circuit.lut_neg: negative
+    <=> the most significant non-propagating signal generates); the signals later positions still need are widened
+    three-way (Circuit.lut_odd), spans x 3 per level."""
     m = len(S)
     while any(b is None for b in bits):
-        newS = list(S)
+        newS = [None] * m
         for i in range(m):
             if bits[i] is None:
                 if i < span:                               # the signal already reaches position 0: convert
                     bits[i] = lut(c, S[i], lambda v: int(v == -1))
                 elif i < 2 * span:                         # two signals reach position 0 together
-                    bits[i] = lut2(c, S[i], S[i - span], lambda h, l: int(_comb(h, l) == -1))
-            if i >= span and any(bits[j] is None or j >= 2 * span for j in range(i, min(m, i + 2 * span + 1), span)):
-                # still an operand of a later combine: widen the signal (three-way where three exist)
+                    bits[i] = _neg(c, S[i] * 3 + S[i - span])
+                elif i < 3 * span:                         # three signals
+                    bits[i] = _neg(c, S[i] * 9 + S[i - span] * 3 + S[i - 2 * span])
+            # the signal of span 3 x span ending at i is read next level by positions i (if >= 3 span), i + 3 span, i + 6 span
+            if any(j < m and j >= 3 * span for j in (i, i + 3 * span, i + 6 * span)):
                 if i >= 2 * span:
                     packed = S[i] * 9 + S[i - span] * 3 + S[i - 2 * span]
                     newS[i] = c.lut_odd(packed, _comb3) if isinstance(packed, Lin) else _comb3(int(packed))
-                else:
+                elif i >= span:
                     newS[i] = lut2(c, S[i], S[i - span], _comb)
+                else:
+                    newS[i] = S[i]
         S = newS
         span *= 3
     return bits
@@ -408,7 +415,12 @@ def _division_radix(c, dividend, divisor, kbits):
     for j in range(3, R):
         if j not in mult:
             hi = 1 << (j.bit_length() - 1)
-            mult[j] = _add_binary(c, mult[hi], mult[j - hi])       # j D < 2^w: no carry out
+            if j == R - 1 and kbits >= 3:
+                # (R - 1) D = R D - D: ONE subtraction of given operands (4 D + 3 D would have to wait for 3 D); R D = D followed
+                # by kbits zeros is exactly w digits
+                mult[j] = base_p_subtraction(c, divisor + [0] * kbits, mult[1], 2)
+            else:
+                mult[j] = _add_binary(c, mult[hi], mult[j - hi])       # j D < 2^w: no carry out
     quo = [0] * n
     rem = [0] * m  # m digits, MSD first
 
@@ -452,7 +464,9 @@ def _division_radix(c, dividend, divisor, kbits):
 
 @reference_signature
 def is_greater_or_equal(c, a, b):
-    """reference base_p_arrays.py:245-260: 1 - (borrow out of a - b), by borrow look-ahead (log depth)."""
+    """reference base_p_arrays.py:245-260: 1 - (borrow out of a - b), by a tree over look-ahead signals: windows of four
+    digit differences first (binary operands), three signals per look-up after that, and the last look-up returns the
+    borrow bit itself (Circuit.lut_neg on the packed signals): 36 digits in three levels."""
     m = min(len(a), len(b))
     deltas = [a[-k] - b[-k] for k in range(1, m + 1)]
     if all(not isinstance(d, Lin) for d in deltas):
@@ -460,32 +474,42 @@ def is_greater_or_equal(c, a, b):
         for d in deltas:
             borrow = int(d - borrow < 0)
         return 1 - borrow
-    sig = [lut(c, d, _sign3) for d in deltas]
-    # tree reduction of the combined signal (most significant wins unless it propagates)
-    first = lut(c, deltas[0], lambda v: int(v < 0))
-    if m == 1:
-        return 1 - first
-    while len(sig) > 2:
+    sign = lambda v: (v > 0) - (v < 0)  # noqa: E731
+    if WIDE_LOOKAHEAD and all(-1 <= lo_of(d) and hi_of(d) <= 1 for d in deltas):
+        packed = []
+        for g in range(0, m, 4):
+            w = 0
+            for t, d in enumerate(deltas[g:g + 4]):
+                w = w + d * (1 << t)
+            packed.append(w)
+        if len(packed) == 1:
+            return 1 - _neg(c, packed[0])
+        sig = [(c.lut_odd(w, sign) if isinstance(w, Lin) else sign(int(w))) for w in packed]
+    else:
+        if m == 1:
+            return 1 - lut(c, deltas[0], lambda v: int(v < 0))
+        sig = [lut(c, d, _sign3) for d in deltas]
+    while len(sig) > 3:
         nxt = []
-        if WIDE_LOOKAHEAD:   # three signals per look-up (Circuit.lut_odd): depth log3 instead of log2
-            for i in range(0, len(sig), 3):
-                grp = sig[i:i + 3]
+        for i in range(0, len(sig), 3):
+            grp = sig[i:i + 3]
+            if len(grp) == 3 and WIDE_LOOKAHEAD:
+                v = grp[2] * 9 + grp[1] * 3 + grp[0]
+                nxt.append(c.lut_odd(v, _comb3) if isinstance(v, Lin) else _comb3(int(v)))
+            elif len(grp) >= 2:
+                nxt.append(lut2(c, grp[1], grp[0], _comb))
                 if len(grp) == 3:
-                    packed = grp[2] * 9 + grp[1] * 3 + grp[0]
-                    nxt.append(c.lut_odd(packed, _comb3) if isinstance(packed, Lin) else _comb3(int(packed)))
-                elif len(grp) == 2:
-                    nxt.append(lut2(c, grp[1], grp[0], _comb))
-                else:
-                    nxt.append(grp[0])
-        else:
-            for i in range(0, len(sig) - 1, 2):
-                nxt.append(lut2(c, sig[i + 1], sig[i], _comb))
-            if len(sig) % 2:
-                nxt.append(sig[-1])
+                    nxt.append(grp[2])
+            else:
+                nxt.append(grp[0])
         sig = nxt
-    if len(sig) == 1:   # a three-way level left one signal: convert it
+    if len(sig) == 1:
         return 1 - lut(c, sig[0], lambda v: int(v == -1))
-    return 1 - lut2(c, sig[1], sig[0], lambda h, l: int(_comb(h, l) == -1))
+    if len(sig) == 2 or not WIDE_LOOKAHEAD:
+        if len(sig) == 3:
+            sig = [lut2(c, sig[1], sig[0], _comb), sig[2]]
+        return 1 - _neg(c, sig[1] * 3 + sig[0])
+    return 1 - _neg(c, sig[2] * 9 + sig[1] * 3 + sig[0])
 
 
 @reference_signature
@@ -667,6 +691,70 @@ def carry_propagate_signed(c, digits, p):
             d = d.assume(min(vals), max(vals))
         out[L - 1 - i] = d
     return out
+
+
+def signed_add_binary(c, a, na, b, nb):
+    """The reference's  QFloat += QFloat  (qfloat.py:798-834: digits * sign + digits * sign, then base_tidy :607-626 and tidy
+    :648-673) for base-2 operands in sign-magnitude form, WITHOUT walking the signed carry chain.
+
+    a, b: equal-length digit lists (MSD first), every digit in [0, 1] except the leading ones, which may reach 3 (from_float does
+    not reduce the leading digit, base_p_arrays.py:42-46); na, nb: sign bits (1 = negative; a zero-signed operand is passed as
+    all-zero digits).  Returns (digits, neg) with digits in [0, 1] and sign = 1 - 2 neg.
+
+    What the reference computes, case by case (d = s_a a + s_b b are the mixed-sign digits its truncating chain walks):
+      * equal signs s: every digit of d has the sign s, truncation toward zero is floor on magnitudes, so the chain is the plain
+        binary addition of the magnitudes with the carry out of the leading digit dropped; tidy returns that magnitude with the
+        sign s (+1 if the magnitude is zero).  A leading-digit sum of up to 7 keeps (a_L + b_L + carry) mod 2.
+      * opposite signs: the digits are in {-1, 0, 1} below the leading one, and a truncating chain that starts with carry 0 never
+        produces a carry from such digits (|d + 0| <= 1); the leading digit delta = a_L - b_L (|delta| <= 3) becomes
+        rho = delta - 2 trunc(delta / 2) in {-1, 0, 1} (its carry is dropped), and tidy returns |X|, sign s_a sign(X) for
+        X = A' - B' with A' = ([rho = 1], a body), B' = ([rho = -1], b body) - an ordinary binary subtraction.
+    So three carry / borrow look-aheads (A + B, A' - B', B' - A') run in parallel (three levels for up to 36 digits), one
+    packed three-way selection per digit picks the magnitude, and the sign follows two levels later: four levels per addition
+    of a chain instead of sixteen (sign products, carry-select chain, two subtractions, selection)."""
+    L = len(a)
+    assert L == len(b) and L >= 1
+    lead_wide = hi_of(a[0]) > 1 or hi_of(b[0]) > 1
+    if lead_wide:
+        body = _add_binary(c, [0] + list(a[1:]), [0] + list(b[1:]))          # leading digit of the result: the carry out of the body
+        SUM = [lut(c, a[0] + b[0] + body[0], lambda v: v & 1)] + body[1:]
+        rho = lambda v: ((v > 0) - (v < 0)) * (abs(v) & 1)  # noqa: E731
+        delta = a[0] - b[0]
+        A2 = [lut(c, delta, lambda v: int(rho(v) == 1))] + list(a[1:])
+        B2 = [lut(c, delta, lambda v: int(rho(v) == -1))] + list(b[1:])
+    else:
+        SUM = _add_binary(c, list(a), list(b))                                # carry out of the leading digit dropped
+        A2, B2 = list(a), list(b)
+    D1, lt = base_p_subtraction(c, A2, B2, 2, True)
+    D2, gt = base_p_subtraction(c, B2, A2, 2, True)
+    same = lut(c, na + nb, lambda v: int(v != 1))
+    w = same * 2 + lt                      # 0: opposite signs, A' >= B' -> D1;  1: opposite signs, A' < B' -> D2;  2, 3: equal signs -> SUM
+    digits = []
+    for x1, x2, xs in zip(D1, D2, SUM):
+        acc = lut2(c, w, x1, lambda s_, v: v if s_ == 0 else 0) + lut2(c, w, x2, lambda s_, v: v if s_ == 1 else 0) \
+            + lut2(c, w, xs, lambda s_, v: v if s_ >= 2 else 0)
+        digits.append(acc.assume(0, 1) if isinstance(acc, Lin) else acc)
+    # sign.  equal signs: negative iff s = -1 and the magnitude is not zero; opposite: negative iff s_a (A' - B') < 0
+    chunks, cur, n = [], 0, 0
+    for x in SUM:
+        if n == CAP:
+            chunks.append(cur)
+            cur, n = 0, 0
+        cur = cur + x
+        n += 1
+    chunks.append(cur)
+    flags = [lut(c, s, lambda v: int(v > 0)) for s in chunks]
+    while len(flags) > 3:                  # (not reached below 46 digits)
+        flags = [any_positive(c, flags[i:i + CAP]) for i in range(0, len(flags), CAP)]
+    nzsum = 0
+    for f in flags:
+        nzsum = nzsum + f
+    g_same = lut2(c, na, nzsum, lambda n_, z: int(n_ == 1 and z > 0))
+    g_diff = lut2(c, na, lt - gt, lambda n_, t: int((n_ == 0 and t == 1) or (n_ == 1 and t == -1)))
+    neg = c.select(same, g_same, g_diff) if isinstance(same, Lin) else (g_same if same else g_diff)
+    if isinstance(neg, Lin):
+        neg = neg.assume(0, 1)
+    return digits, neg
 
 
 # ------------------------------------------------------------------------------- tensorised twins

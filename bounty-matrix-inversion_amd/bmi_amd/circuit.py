@@ -159,9 +159,10 @@ def _fn_key(fn, depth=0):
     """Hashable identity of a look-up function by VALUE: code object + closure cells + defaults (plain scalars or nested
     functions of the same kind); None when anything else is captured.  Two lambdas created by the same line with the same
     captured numbers are the same function of v, so their tables can be shared without calling them 16 times each."""
-    code = getattr(fn, "__code__", None)
-    if code is None or depth > 3:
+    import types
+    if not isinstance(fn, types.FunctionType) or depth > 3:    # bound methods, partials, callables with state: no identity by value
         return None
+    code = fn.__code__
     cells = []
     for cell in fn.__closure__ or ():
         try:
@@ -177,10 +178,16 @@ def _fn_key(fn, depth=0):
             cells.append(k)
         else:
             return None
-    for v in fn.__defaults__ or ():
+    kwd = tuple(sorted((fn.__kwdefaults__ or {}).items()))
+    for v in tuple(fn.__defaults__ or ()) + tuple(x for _, x in kwd):
         if not isinstance(v, _SCALARS):
             return None
-    return (code, tuple(cells), fn.__defaults__)
+    key = (code, tuple(cells), fn.__defaults__, kwd)
+    try:
+        hash(key)            # a tuple cell may hold something unhashable: no memo then
+    except TypeError:
+        return None
+    return key
 
 
 class Circuit:
@@ -200,7 +207,9 @@ class Circuit:
         self.claims = []         # (snapshot, lo, hi) interval claims to be verified by simulate()
         self.outputs = []        # snapshots of output Lins
         self.stats = {"pbs": 0, "cse_hits": 0, "const_folds": 0}
-        self.wide_leaves = set()  # outputs of lut_odd(): their PBS input may use the whole torus
+        self.wide_leaves = set()  # outputs of lut_odd() / lut_neg(): their PBS input may use the whole torus
+        self.half_leaves = set()  # outputs of lut_neg(): the ciphertext carries (bit - 1/2) * Delta (see lut_neg)
+        self.half_luts = set()    # ... and their table (-+1) is registered at half the output scale
         self._table_memo = {}     # (function key, lo, hi) -> evaluated table data of lut()
 
     # ---- construction ----------------------------------------------------------------------------
@@ -345,6 +354,56 @@ class Circuit:
             self.stats["cse_hits"] += 1
         return Lin(self, {leaf: 1}, 0, olo, ohi)
 
+    def lut_neg(self, x):
+        """[x < 0] in {0, 1} for x anywhere in [-(2^msg_bits - 1), 2^msg_bits - 1], ONE PBS.
+
+        lut_odd() covers the whole torus only for functions with f(v - 16) = -f(v), which a bit is not.  But
+        [v < 0] - 1/2 is: +1/2 on [-16, 0), -1/2 on [0, 16) - the constant test polynomial of the classic sign bootstrap.  The
+        PBS therefore returns (bit - 1/2) Delta (a table of -+1 at HALF the output scale) and the missing Delta / 2 is a
+        constant, which every consumer's linear combination absorbs into its own constant (executor.py; Program keeps
+        which leaves are of this kind).  On the tracer's side the leaf simply has the value of the bit.  Same box width and
+        noise margin as any msg_bits-bit look-up (the decision boundaries are v = -1 | 0 and the wrap at +-16, where the
+        inputs +-15 are two boxes apart).  This turns 'signal, then convert the signal to a bit' (two look-up levels) into
+        one level wherever a borrow / carry / comparison bit comes out of a packed window or of packed look-ahead signals."""
+        if not isinstance(x, Lin):
+            return self.const(int(int(x) < 0))
+        if x.is_const:
+            self.stats["const_folds"] += 1
+            return self.const(int(x.const < 0))
+        half = 1 << (self.msg_bits - 1)
+        period = 1 << self.msg_bits
+        if x.lo < -(period - 1) or x.hi > period - 1:
+            raise RangeError(f"lut_neg input interval [{x.lo}, {x.hi}] outside [-{period - 1}, {period - 1}]")
+        if x.lo >= 0 or x.hi < 0:
+            self.stats["const_folds"] += 1
+            return self.const(int(x.hi < 0))
+        if -half <= x.lo and x.hi < half:
+            return self.lut(x, _LT0)  # fits the ordinary message space (and possibly a coarser one: wider boxes)
+        table = tuple([1] * half + [-1] * half)     # in half units: (bit - 1/2) * 2 on m = -half .. half - 1
+        key = (self.msg_bits, table)
+        li = self._lut_index.get(key)
+        if li is None:
+            li = len(self.luts)
+            self.luts.append(key)
+            self._lut_index[key] = li
+        self.half_luts.add(li)
+        snap = self._snapshot(x)
+        ck = (snap, li, "neg")
+        leaf = self._cse.get(ck)
+        if leaf is None:
+            leaf = len(self.leaf_level)
+            self.leaf_level.append(self.level_of(x) + 1)
+            self.leaf_lo.append(0)
+            self.leaf_hi.append(1)
+            self.nodes.append((snap[0], snap[1], li, leaf))
+            self._cse[ck] = leaf
+            self.wide_leaves.add(leaf)
+            self.half_leaves.add(leaf)
+            self.stats["pbs"] += 1
+        else:
+            self.stats["cse_hits"] += 1
+        return Lin(self, {leaf: 1}, 0, 0, 1)
+
     def lut2(self, x, y, fn):
         """Bivariate look-up f(x, y) as ONE PBS on the packed value (x - xlo) * ny + (y - ylo)."""
         if not isinstance(x, Lin):
@@ -398,7 +457,7 @@ class Circuit:
                 "luts": [[p, list(tab)] for p, tab in self.luts],
                 "outputs": [[[list(t) for t in terms], const] for terms, const in self.outputs],
                 "claims": [[[[list(t) for t in snap[0]], snap[1]], lo, hi] for snap, lo, hi in self.claims],
-                "wide_leaves": sorted(self.wide_leaves)}
+                "wide_leaves": sorted(self.wide_leaves), "half_leaves": sorted(self.half_leaves), "half_luts": sorted(self.half_luts)}
 
     @classmethod
     def from_dict(cls, d):
@@ -411,6 +470,8 @@ class Circuit:
         c.outputs = [(tuple(tuple(t) for t in terms), const) for terms, const in d["outputs"]]
         c.claims = [((tuple(tuple(t) for t in snap[0]), snap[1]), lo, hi) for snap, lo, hi in d["claims"]]
         c.wide_leaves = set(d["wide_leaves"])
+        c.half_leaves = set(d.get("half_leaves", ()))
+        c.half_luts = set(d.get("half_luts", ()))
         c.stats["pbs"] = len(c.nodes)
         return c
 
@@ -550,6 +611,8 @@ class Circuit:
                 out = -table[m + 2 * half_space + (1 << (p - 1))]
             else:
                 out = table[m + (1 << (p - 1))]
+            if leaf in self.half_leaves:        # lut_neg: the table holds (bit - 1/2) * 2
+                out = (out + 1) // 2
             if check and not (self.leaf_lo[leaf] <= out <= self.leaf_hi[leaf]):
                 raise RangeError("look-up output outside its interval")
             val[leaf] = out

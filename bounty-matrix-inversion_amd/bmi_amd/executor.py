@@ -10,7 +10,7 @@ Store rows are recycled: a leaf's row returns to the free list at the level of i
 at compile time), so the store holds the live set, not every look-up ever made (8x8 inverse: 2.6 M look-ups, a few
 hundred thousand rows).
 
-Several GPUs: every rank holds the keys (seeded keygen) and the whole store and walks the same level
+Several GPUs: every rank holds the same evaluation keys (Engine.keygen_shared, or seeded test keys; checked at construction) and the whole store and walks the same level
 list.  A level at least `shard_threshold` wide is split into contiguous row ranges (shard.shard_range on a padded
 width): each rank forms and bootstraps ITS rows only, one all-gather (RCCL) on the level buffer completes it
 everywhere, then every rank scatters the whole level into its store; this is the path's only exchange step.  Narrower
@@ -97,6 +97,19 @@ class Executor:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             self.dist, self.rank, self.world = dist, dist.get_rank(group), dist.get_world_size(group)
+            # every rank bootstraps its part of a split level with ITS evaluation keys: they must be one key set (seeded keygen on
+            # every rank, or Engine.keygen_shared / EncryptedMatrixInversion.keygen).  Independent keys would gather ciphertexts
+            # under different keys and decrypt to garbage without any error - refused here instead.
+            if hasattr(engine, "eval_key_fingerprint"):
+                fp = engine.eval_key_fingerprint()
+                on_gpu = dist.get_backend(group) == "nccl"
+                lo = torch.tensor([fp], dtype=torch.int64, device=self.dev if on_gpu else "cpu")
+                hi = lo.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+                if int(lo.item()) != int(hi.item()):
+                    raise RuntimeError("the ranks of this group hold different evaluation keys: generate one key set and share it "
+                                       "(Engine.keygen_shared, or EncryptedMatrixInversion.keygen under torch.distributed)")
         if shard_threshold is None:
             shard_threshold = Program_ROUND + 1
             if self.world > 1:
@@ -109,8 +122,11 @@ class Executor:
         self.row_of, self.n_rows = assign_rows(prog, recycle)
         self.delta_log = engine.delta_log(prog.msg_bits)
         q, dl = engine.modulus, self.delta_log
+        # a lut_neg table (-+1) is registered at half the output scale: its ciphertexts carry (bit - 1/2) Delta, and every
+        # consumer's constant below makes up for the missing Delta / 2 (Circuit.lut_neg, Program.half_unit_consts)
         lut_ids = np.asarray([engine.lut_register(prog.lut_tab[j, : 1 << int(prog.lut_p[j])].astype(np.int64),
-                                                  int(prog.lut_p[j]), dl) for j in range(prog.lut_p.size)], np.int32)
+                                                  int(prog.lut_p[j]), dl - 1 if prog.lut_half[j] else dl)
+                              for j in range(prog.lut_p.size)], np.int32)
         to_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.dev)  # noqa: E731
 
         # every level's rows in level order: one set of flat arrays for the whole program, sliced per level
@@ -120,9 +136,9 @@ class Executor:
         off = np.arange(tot) - np.repeat(np.cumsum(lens) - lens, lens) + np.repeat(starts, lens)
         self.d_idx = to_dev(self.row_of[prog.term_leaf[off]] if tot else [0], np.int32)
         self.d_coef = to_dev(prog.term_coef[off] if tot else [0], np.int64)
-        consts = prog.node_const[order]
+        consts = prog.half_unit_consts(prog.node_ptr, prog.term_leaf, prog.term_coef, prog.node_const)[order]   # units of Delta / 2
         uniq, inv = np.unique(consts, return_inverse=True)
-        self.d_const = to_dev(_torus(uniq, dl, q)[inv] if consts.size else [0], np.int64)
+        self.d_const = to_dev(_torus(uniq, dl - 1, q)[inv] if consts.size else [0], np.int64)
         self.d_ids = to_dev(lut_ids[prog.node_lut[order]] if order.size else [0], np.int32)
         self.d_rows = to_dev(self.row_of[n_in + order] if order.size else [0], np.int32)
         # row_ptr of all nodes in level order, absolute term offsets: a level (or a rank's part of it) is a slice
@@ -135,7 +151,7 @@ class Executor:
             pos += w
         self.out_csr = (to_dev(prog.out_ptr, np.int32), to_dev(self.row_of[prog.out_leaf] if prog.out_leaf.size else [0], np.int32),
                         to_dev(prog.out_coef if prog.out_coef.size else [0], np.int64),
-                        to_dev(_torus(prog.out_const, dl, q), np.int64))
+                        to_dev(_torus(prog.half_unit_consts(prog.out_ptr, prog.out_leaf, prog.out_coef, prog.out_const), dl - 1, q), np.int64))
         self.n_out = prog.n_outputs
         self.max_width = max((p for *_, p in self.levels), default=1)
         self.sharded_levels = sum(1 for w, *_ in self.levels if self.world > 1 and w >= self.shard_threshold)
@@ -169,6 +185,10 @@ class Executor:
                     eng.lincomb(self.store, self.d_rp[pos + lo:], self.d_idx, self.d_coef, self.d_const[pos + lo:], hi - lo, tmp[lo:], stream)
                     eng.pbs(tmp[lo:], self.d_ids[pos + lo:], hi - lo, lvl[lo:], stream)
                 if sharded:
+                    per = padded // self.world
+                    pad_from = max(hi, self.rank * per)       # this rank's gather region is [rank * per, (rank + 1) * per)
+                    if pad_from < (self.rank + 1) * per:      # rows past the level's width: they travel as zeros, never scattered
+                        lvl[pad_from: (self.rank + 1) * per].zero_()
                     self._all_gather_rows(lvl[:padded], padded // self.world)
                 eng.scatter_rows(lvl, width, self.store, self.d_rows[pos:], stream)
             rp, ix, cf, cs = self.out_csr

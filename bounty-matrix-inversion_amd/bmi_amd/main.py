@@ -166,8 +166,20 @@ class EncryptedMatrixInversion:
         return self.engine
 
     def keygen(self, seed=None):
-        """circuit.keygen() (main.py:177).  seed=None: CSPRNG keys; an integer: the test-only deterministic key set."""
-        self._engine().keygen(seed)
+        """circuit.keygen() (main.py:177).  seed=None: CSPRNG keys; an integer: the test-only deterministic key set.
+        With torch.distributed initialised on several ranks (the sharded executor) rank 0 generates the set and the others
+        receive its evaluation keys (Engine.keygen_shared): independent CSPRNG keys per rank would make the ranks' parts of a
+        level undecryptable garbage to each other.  Only rank 0 can then encrypt / decrypt."""
+        eng = self._engine()
+        try:
+            import torch.distributed as dist
+            shared = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        except Exception:
+            shared = False
+        if shared:
+            eng.keygen_shared(seed)
+        else:
+            eng.keygen(seed)
 
     def _executor(self):
         if self._exec is None:

@@ -25,7 +25,7 @@ import numpy as np
 
 from .circuit import Circuit, RangeError
 
-FORMAT = 3
+FORMAT = 4
 ROUND = Circuit.ROUND
 WIDE_ROUND = Circuit.WIDE_ROUND
 
@@ -41,7 +41,8 @@ def _tracer_fingerprint():
     """hash of the modules that define what a trace looks like: a cached program is only valid for the code that made it"""
     here = os.path.dirname(os.path.abspath(__file__))
     h = hashlib.sha256()
-    for name in ("circuit.py", "base_p_arrays.py", "qfloat.py", "qfloat_matrix_inversion.py", "program.py"):
+    # main.py too: it declares the inputs (order, intervals), picks the message width and the division radix of a configuration
+    for name in ("circuit.py", "base_p_arrays.py", "qfloat.py", "qfloat_matrix_inversion.py", "program.py", "main.py"):
         with open(os.path.join(here, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -133,7 +134,7 @@ def prune_nodes(n_in, node_ptr, term_leaf, out_leaf):
 
 class Program:
     ARRAYS = ("in_lo", "in_hi", "node_ptr", "term_leaf", "term_coef", "node_const", "node_lut", "node_level",
-              "node_wide", "node_lo", "node_hi", "lut_p", "lut_tab", "out_ptr", "out_leaf", "out_coef", "out_const",
+              "node_wide", "node_half", "node_lo", "node_hi", "lut_p", "lut_tab", "lut_half", "out_ptr", "out_leaf", "out_coef", "out_const",
               "claim_ptr", "claim_leaf", "claim_coef", "claim_const", "claim_lo", "claim_hi")
 
     def __init__(self, msg_bits, arrays, meta=None):
@@ -158,6 +159,16 @@ class Program:
     @property
     def n_outputs(self):
         return int(self.out_const.size)
+
+    def half_unit_consts(self, ptr, leaf, coef, const):
+        """Constants of the linear combinations (ptr, leaf, coef, const) in units of Delta / 2: a lut_neg leaf's ciphertext
+        carries (bit - 1/2) Delta, so a consumer reading it with coefficient c owes c Delta / 2 (Circuit.lut_neg)."""
+        ln = np.diff(ptr)
+        seg = np.repeat(np.arange(ln.size), ln)
+        is_half = np.zeros(self.n_inputs + self.n_nodes, bool)
+        is_half[self.n_inputs:] = self.node_half
+        owed = np.bincount(seg, weights=np.asarray(coef, np.int64) * is_half[leaf], minlength=ln.size).astype(np.int64)
+        return 2 * np.asarray(const, np.int64) + owed
 
     def level_order(self):
         """(order, counts): node indices sorted by level (stable), number of nodes per level 1..depth"""
@@ -238,6 +249,9 @@ class Program:
         wide = np.zeros(n_leaves, bool)
         if c.wide_leaves:
             wide[np.fromiter(c.wide_leaves, np.int64, len(c.wide_leaves))] = True
+        halfl = np.zeros(n_leaves, bool)        # Circuit.lut_neg leaves: the ciphertext carries (bit - 1/2) * Delta
+        if getattr(c, "half_leaves", None):
+            halfl[np.fromiter(c.half_leaves, np.int64, len(c.half_leaves))] = True
         width = 1 << c.msg_bits
         lut_tab = np.zeros((max(len(c.luts), 1), width), np.int16)
         for j, (p, tab) in enumerate(c.luts):
@@ -249,7 +263,8 @@ class Program:
         arrays = dict(
             in_lo=leaf_lo[:n_in].copy(), in_hi=leaf_hi[:n_in].copy(), node_ptr=k_ptr, term_leaf=k_leaf,
             term_coef=k_coef.astype(np.int32), node_const=node_const[keep], node_lut=lut_map[k_lut].astype(np.int32),
-            node_level=node_level, node_wide=wide[n_in + keep],
+            node_level=node_level, node_wide=wide[n_in + keep], node_half=halfl[n_in + keep],
+            lut_half=np.asarray([j in getattr(c, "half_luts", ()) for j in used_luts.tolist()], bool),
             node_lo=leaf_lo[n_in + keep].astype(np.int16), node_hi=leaf_hi[n_in + keep].astype(np.int16),
             lut_p=np.asarray([c.luts[j][0] for j in used_luts.tolist()], np.int8), lut_tab=lut_tab[used_luts],
             out_ptr=o_ptr, out_leaf=o_leaf, out_coef=o_coef, out_const=out_const,
@@ -332,6 +347,7 @@ class Program:
             mm = np.where(hi_wrap, m - 2 * half_space, np.where(lo_wrap, m + 2 * half_space, m))
             out = self.lut_tab[self.node_lut[nodes], mm + hp].astype(np.int64)
             out = np.where(hi_wrap | lo_wrap, -out, out)
+            out = np.where(self.node_half[nodes], (out + 1) // 2, out)      # lut_neg: the table holds (bit - 1/2) * 2
             if check and ((out < self.node_lo[nodes]) | (out > self.node_hi[nodes])).any():
                 raise RangeError("look-up output outside its interval")
             val[n_in + nodes] = out

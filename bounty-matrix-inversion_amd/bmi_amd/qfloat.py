@@ -186,6 +186,41 @@ class QFloat:
         if not is_base_tidy:
             self.base_tidy()
 
+    # ---- sign bookkeeping ---------------------------------------------------------------------------
+    # `_sign` is the reference's field (in {-1, 0, +1}; 0 = the value is zero whatever the digits say).  Beside it `_neg` is
+    # kept whenever the sign is KNOWN to be non-zero and available as a bit: _sign == 1 - 2 * _neg.  The outputs of tidy and
+    # of the fused addition have it, products / quotients of operands that have it keep it; a sign multiplied by a ternary
+    # SignedBinary loses it.  The fused addition (base_p_arrays.signed_add_binary) works on sign bits.
+    @property
+    def _sign(self):
+        return self._sgn
+
+    @_sign.setter
+    def _sign(self, v):
+        self._sgn = v
+        self._neg = int(v < 0) if (v is not None and not _is_enc(v) and v != 0) else None
+
+    def _set_neg(self, neg):
+        self._sgn = 1 - 2 * neg
+        self._neg = neg
+
+    @staticmethod
+    def _xor_neg(na, nb):
+        """sign bit of a product of two non-zero signs"""
+        if not _is_enc(na):
+            return nb if not na else 1 - nb
+        if not _is_enc(nb):
+            return na if not nb else 1 - na
+        return na.c.lut(na + nb, lambda v: int(v == 1))
+
+    @staticmethod
+    def _sign_product(x, y):
+        """(sign, neg) of the product of the signs of two QFloats (neg is None when either sign may be zero)"""
+        if x._neg is not None and y._neg is not None:
+            n = QFloat._xor_neg(x._neg, y._neg)
+            return 1 - 2 * n, n
+        return _mul(x._sign, y._sign), None
+
     # ---- statistics (reference qfloat.py:262-326) --------------------------------------------------
     @classmethod
     def reset_stats(cls):
@@ -254,7 +289,9 @@ class QFloat:
         return len(self._array)
 
     def copy(self):
-        return QFloat(list(self._array), self._ints, self._base, self._is_base_tidy, self._sign)
+        r = QFloat(list(self._array), self._ints, self._base, self._is_base_tidy, self._sign)
+        r._neg = self._neg
+        return r
 
     def to_array(self):
         return list(self._array)
@@ -320,7 +357,7 @@ class QFloat:
             return
         nmp = bpa.base_p_subtraction(c, [-x for x in d], zeros, p)
         self._array = [c.select(isneg, n, q) for n, q in zip(nmp, pmn)]
-        self._sign = 1 - 2 * isneg
+        self._set_neg(isneg)
 
     # ---- comparisons (reference qfloat.py:681-764) --------------------------------------------------------
     def __eq__(self, other):
@@ -367,20 +404,24 @@ class QFloat:
 
     def __abs__(self):
         r = self.copy()
-        r._sign = _mul(r._sign, r._sign)
-        return r
+        return r.abs()
 
     def abs(self):
-        self._sign = _mul(self._sign, self._sign)
+        if self._neg is not None:      # a non-zero sign squared
+            self._sign = 1
+        else:
+            self._sign = _mul(self._sign, self._sign)
         return self
 
     def __neg__(self):
         r = self.copy()
-        r._sign = -1 * r._sign
-        return r
+        return r.neg()
 
     def neg(self):
-        self._sign = -1 * self._sign
+        if self._neg is not None:
+            self._set_neg(1 - self._neg)
+        else:
+            self._sign = -1 * self._sign
         return self
 
     # ---- addition (reference qfloat.py:766-850) --------------------------------------------------------------
@@ -388,6 +429,8 @@ class QFloat:
         if isinstance(other, Zero):
             return None  # reference quirk (qfloat.py:803-804): `return` without a value
         QFloat.ADDITIONS += 1
+        if self._fused_add(other):
+            return self
         arr = [_mul(x, self._sign) for x in self._array]
         if isinstance(other, Lin) or isinstance(other, numbers.Integral):
             arr[self._ints - 1] = arr[self._ints - 1] + other
@@ -401,6 +444,57 @@ class QFloat:
         self._sign = None
         self.tidy()
         return self
+
+    def _fused_add(self, other):
+        """`+=` of base-2 operands by base_p_arrays.signed_add_binary (same integers as the reference's digit-times-sign
+        sum, carry chain and tidy; four look-up levels).  Returns False when the operands are not of that shape (other bases,
+        digits that are not tidy, a scalar beyond [-1, 1], plaintext): the caller then runs the reference's steps."""
+        units = self._ints - 1                         # the reference adds scalars at array[ints - 1] (the last digit when ints = 0)
+        if isinstance(other, QFloat):
+            b_digits, b_sign, b_neg = other._array, other._sign, other._neg
+            if not (other._is_base_tidy and other._base == 2 and len(other) == len(self) and other._ints == self._ints):
+                return False
+        else:
+            v = other.value if isinstance(other, SignedBinary) else other
+            if isinstance(v, numbers.Integral):
+                if abs(int(v)) > 1:
+                    return False
+                mag, b_neg = abs(int(v)), int(v < 0)
+            elif _is_enc(v) and v.lo >= -1 and v.hi <= 1:
+                mag, b_neg = v.c.lut(v, abs), v.c.lut(v, lambda x: int(x < 0))
+            else:
+                return False
+            b_digits = [0] * len(self)
+            b_digits[units] = mag
+            b_sign = None
+        c = _circ(self._array, self._sign, b_digits, b_sign, b_neg)
+        if c is None or self._base != 2 or not self._is_base_tidy or len(self) == 0:
+            return False
+
+        def shaped(digits):
+            return all(bpa.lo_of(x) >= 0 and bpa.hi_of(x) <= (3 if i == 0 else 1) for i, x in enumerate(digits))
+
+        def operand(digits, sign, neg):
+            """(digits, sign bit); a sign that may be zero is folded into the digits first (one look-up per digit)"""
+            if neg is not None:
+                return list(digits), neg
+            if not _is_enc(sign):
+                return ([0] * len(digits), 0) if int(sign) == 0 else (list(digits), int(sign < 0))
+            if sign.lo < -1 or sign.hi > 1:
+                return None
+            return [bpa.lut2(c, sign, x, lambda s_, d: d if s_ != 0 else 0) for x in digits], c.lut(sign, lambda s_: int(s_ < 0))
+
+        if not (shaped(self._array) and shaped(b_digits)):
+            return False
+        A = operand(self._array, self._sign, self._neg)
+        B = operand(b_digits, b_sign, b_neg)
+        if A is None or B is None:
+            return False
+        digits, neg = bpa.signed_add_binary(c, A[0], A[1], B[0], B[1])
+        self._array = digits
+        self._is_base_tidy = True
+        self._set_neg(neg)
+        return True
 
     def __add__(self, other):
         r = self.copy()
@@ -446,6 +540,7 @@ class QFloat:
             self.check_compatibility(other)
             prod = _product(self, other, len(self), self._ints)
             self._array, self._sign = prod._array, prod._sign
+            self._neg = prod._neg
             self._is_base_tidy = True
         return self
 
@@ -532,7 +627,9 @@ class QFloat:
         assert self._is_base_tidy
         fp = len(self) - self._ints
         quo = _divide(self._array + [0] * fp, other._array, self._base)
-        self._sign = _mul(self._sign, other._sign)
+        sign, neg = QFloat._sign_product(self, other)
+        self._sign = sign
+        self._neg = neg
         self._array = quo[fp:]
         return self
 
@@ -566,7 +663,10 @@ class QFloat:
         quo = _divide([1] + [0] * (fp_old + fp_new), self._array, self._base)
         extra = newlength - len(quo)
         quo = [0] * extra + quo if extra > 0 else quo[-extra:]
-        return QFloat(quo, newints, self._base, True, _mul(sign, self._sign))
+        r = QFloat(quo, newints, self._base, True, _mul(sign, self._sign))
+        if self._neg is not None and isinstance(sign, numbers.Integral):     # +-1 times a non-zero sign
+            r._set_neg(self._neg if sign > 0 else 1 - self._neg)
+        return r
 
     @classmethod
     def multi_invert(cls, list_qfloats, sign=1, newlength=None, newints=None):
@@ -639,7 +739,7 @@ def _product(a, b, newlength, newints):
                     cols[col].append(t)
     for col, (x, y) in waiting.items():
         cols[col].append(_mul(x, y))
-    sign = _mul(a._sign, b._sign)
+    sign, neg = QFloat._sign_product(a, b)
     if c is None:
         return QFloat(np.array([sum(col) for col in cols], dtype=np.int64), newints, p, False, sign)
     if all(bpa.lo_of(t) >= 0 for col in cols for t in col):
@@ -652,4 +752,6 @@ def _product(a, b, newlength, newints):
                 s = s + t
             sums.append(s)
         digits = bpa.carry_propagate_signed(c, sums, p)
-    return QFloat(digits, newints, p, True, sign)
+    r = QFloat(digits, newints, p, True, sign)
+    r._neg = neg
+    return r

@@ -255,24 +255,27 @@ class Engine:
         else:
             self._ck(self.lib.bmi_keygen_insecure_deterministic(self.h, C.c_uint64(seed)), "bmi_keygen_insecure_deterministic")
 
-    def keygen_shared(self, seed=None, group=None, src=0):
-        """One key set on every rank of a torch.distributed group WITHOUT the seeded (test-only) generator: rank `src`
-        generates it (CSPRNG when seed is None) and broadcasts secret and evaluation keys (about 100 MB at the north-star
-        set); the other ranks import them.  With a single process this is keygen(seed).  The sharded executor needs the
-        same evaluation keys on every GPU (executor.py); only the rank that encrypts / decrypts needs the secret ones."""
+    def keygen_shared(self, seed=None, group=None, src=0, share_secret=False):
+        """One set of EVALUATION keys on every rank of a torch.distributed group WITHOUT the seeded (test-only) generator: rank
+        `src` generates the key set (CSPRNG when seed is None) and broadcasts the bootstrap and keyswitch keys (about 100 MB at
+        the north-star set; the unrolled key too in unrolled mode); the other ranks import them as evaluation-only contexts -
+        the secret keys stay on `src`, the only rank that can encrypt / decrypt (share_secret=True replicates them as well, over
+        whatever transport the group uses: only for tests and trusted single-node groups).  With a single process this is
+        keygen(seed).  The sharded executor needs the same evaluation keys on every GPU and checks it (executor.py)."""
         import torch
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return self.keygen(seed)
         rank = dist.get_rank(group)
         unrolled = getattr(self, "unroll", 1) == 2     # the unrolled bootstrap key travels with the set
+        P, rows = self.P, (self.P.k + 1) * self.P.bs_levels
         if rank == src:
             self.keygen(seed)
-            parts = list(self.export_keys()) + ([self.export_bsk_unrolled()] if unrolled else [])
+            sk_small, sk_big, bsk, ksk = self.export_keys()
+            parts = ([sk_small, sk_big] if share_secret else []) + [bsk, ksk] + ([self.export_bsk_unrolled()] if unrolled else [])
         else:
-            P, rows = self.P, (self.P.k + 1) * self.P.bs_levels
-            parts = [np.zeros(P.n, np.uint64), np.zeros(P.k * P.N, np.uint64), np.zeros((P.n, rows, P.k + 1, P.N), np.uint64),
-                     np.zeros((P.k * P.N, P.ks_levels, P.n + 1), np.uint64)]
+            parts = ([np.zeros(P.n, np.uint64), np.zeros(P.k * P.N, np.uint64)] if share_secret else []) + \
+                    [np.zeros((P.n, rows, P.k + 1, P.N), np.uint64), np.zeros((P.k * P.N, P.ks_levels, P.n + 1), np.uint64)]
             if unrolled:
                 parts.append(np.zeros(self.unrolled_key_shape(), np.uint64))
         on_gpu = dist.get_backend(group) == "nccl"
@@ -284,9 +287,21 @@ class Engine:
             if on_gpu:
                 a.view(np.int64)[...] = t.cpu().numpy()
         if rank != src:
-            self.import_keys(*parts[:4])
+            sec = parts[:2] if share_secret else [None, None]
+            ev = parts[2:] if share_secret else parts
+            self.import_keys(sec[0], sec[1], ev[0], ev[1])
             if unrolled:
-                self.import_bsk_unrolled(parts[4])
+                self.import_bsk_unrolled(ev[2])
+
+    def eval_key_fingerprint(self):
+        """64-bit fingerprint of the evaluation keys this context holds (bootstrap, keyswitch and, in unrolled mode, the unrolled
+        key): equal on two contexts iff they bootstrap alike.  Used by the sharded executor to refuse ranks with different keys."""
+        import hashlib
+        _, _, bsk, ksk = self.export_keys(secret=False)
+        h = hashlib.blake2b(digest_size=8)
+        for a in (bsk, ksk) + ((self.export_bsk_unrolled(),) if getattr(self, "unroll", 1) == 2 else ()):
+            h.update(np.ascontiguousarray(a).view(np.uint8).data)
+        return int.from_bytes(h.digest(), "little") >> 1      # fits a signed 64-bit tensor element
 
     def export_keys(self, secret=True):
         """(sk_small, sk_big, bsk, ksk), standard domain; secret=False returns (None, None, bsk, ksk) and also works on

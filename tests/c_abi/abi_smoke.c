@@ -86,14 +86,29 @@ int main(void) {
     CHECK(bmi_preset_params("no such set", &S) < 0, "unknown preset rejected");
     CHECK(bmi_preset_params("north_star_torus64", &S) == 0 && S.q_bits == BMI_Q_TORUS64, "torus preset");
     CHECK(bmi_ctx_create(&S, 0, &ctx) == 0, "torus context");
-    CHECK(bmi_set_bsk_unroll(ctx, 2) < 0, "no unrolled kernel on the torus");
+    {
+        /* the torus set: Bg = 2^10, bootstrap key stored at 48 bits of precision (two limbs); 42 bits belongs to Bg = 2^15 */
+        uint32_t prec = 0;
+        CHECK(S.bs_base_log == 10 && bmi_get_bsk_precision(ctx, &prec) == 0 && prec == 48, "torus set: base 2^10, 48-bit key");
+        CHECK(bmi_set_bsk_precision(ctx, 42) < 0, "42-bit key refused at base 2^10");
+    }
     CHECK(bmi_keygen(ctx) == 0, "torus keygen");
     CHECK(bmi_lut_register(ctx, table, 4, 59, &lut) == 0, "torus lut");
     for (int i = 0; i < 5; i++) ids[i] = lut;
     CHECK(bmi_encrypt(ctx, msgs, 5, 59, ct) == 0 && bmi_pbs_batch_host(ctx, ct, ids, 5, out) == 0, "torus pbs");
     CHECK(bmi_decrypt(ctx, out, 5, 59, dec) == 0, "torus decrypt");
     for (int i = 0; i < 5; i++) CHECK(dec[i] == table[msgs[i] + 8], "torus LUT value");
+    /* the unrolled torus kernel: the unrolled key is derived from the secret keys held; other ciphertext bits, same messages */
+    CHECK(bmi_set_bsk_unroll(ctx, 2) == 0 && bmi_pbs_batch_host(ctx, ct, ids, 5, ct2) == 0, "unrolled torus pbs");
+    CHECK(bmi_decrypt(ctx, ct2, 5, 59, dec) == 0 && memcmp(out, ct2, 5 * big * 8) != 0, "unrolled torus decrypt");
+    for (int i = 0; i < 5; i++) CHECK(dec[i] == table[msgs[i] + 8], "torus LUT value (unrolled key)");
     bmi_ctx_destroy(ctx);
+    {
+        bmi_params T15 = S;     /* round 2's torus set (Bg = 2^15, exact key): no unrolled kernel (its limb sums would not fit) */
+        T15.bs_base_log = 15;
+        CHECK(bmi_ctx_create(&T15, 0, &ctx) == 0 && bmi_set_bsk_unroll(ctx, 2) < 0, "no unrolled torus kernel at base 2^15");
+        bmi_ctx_destroy(ctx);
+    }
     {
         /* x0, x1 inputs; node 0 reads x0; node 1 reads node 0 and x1; node 2 reads x1 and feeds nothing; output = node 1 */
         const int64_t ptr[4] = {0, 1, 3, 4};

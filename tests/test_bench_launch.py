@@ -30,6 +30,19 @@ def test_bench_gpus2_starts_two_ranks_plumbing_only():
     assert rec["n_gpus"] == 2 and rec["world_size_seen"] == 2 and rec["value"] is None and rec["max_over_ranks_check"] == 2.0
 
 
+def test_bench_gpus8_starts_eight_ranks_plumbing_only():
+    """the N = 8 launch the driver's scaling run uses (no GPU here: gloo, no PBS): eight ranks rendezvous, the line reports
+    eight, the MAX reduction sees the last rank, and the ranks' contiguous parts tile the whole-job batch exactly"""
+    p, lines = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "1000"], {"BMI_BENCH_REHEARSE": "plumbing"}, 600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["world_size_seen"] == 8 and rec["value"] is None and rec["max_over_ranks_check"] == 8.0
+    ranges = rec["shard_ranges"]
+    assert len(ranges) == 8 and ranges[0][0] == 0 and ranges[-1][1] == 8 * 1000
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])) and all(hi - lo == 1000 for lo, hi in ranges)
+
+
 def test_bench_refuses_more_gpus_than_visible():
     import torch
     if torch.cuda.device_count() >= 8:

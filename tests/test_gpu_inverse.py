@@ -347,16 +347,24 @@ def _two_rank_worker(rank, world, port, out_dir, tag, unroll=False):
     eng = tfhe.Engine(tfhe.default_params(q_bits=49, glwe_noise=2.0 ** -41) if unroll else None)
     if unroll:
         eng.set_bsk_unroll(2)                            # the unrolled bootstrap key travels with the broadcast key set
-    eng.keygen_shared()                                  # CSPRNG keys made on rank 0, broadcast to the other rank
     emi = EncryptedMatrixInversion(2, None, 2, c["len"], c["ints"], False, False, engine=eng, shard_threshold=48)
+    emi.keygen()                                         # under torch.distributed: CSPRNG keys made on rank 0, its EVALUATION keys
+                                                         # broadcast (Engine.keygen_shared); the secret keys stay on rank 0
     M = np.array(c["M"]).reshape(2, 2)
     q, s = emi.quantize(M)
-    enc = emi.encrypt(q, s) if rank == 0 else np.zeros((84, 1025), np.uint64)
+    if rank == 0:
+        enc = emi.encrypt(q, s)
+    else:
+        with pytest.raises(tfhe.BmiError):               # an evaluation-only context cannot encrypt
+            emi.encrypt(q, s)
+        enc = np.zeros((84, 1025), np.uint64)
     t = torch.from_numpy(enc.view(np.int64))             # the client's ciphertexts reach every rank
     dist.broadcast(t, src=0)
-    out = emi.decrypt(emi.evaluate(enc))
+    res = emi.evaluate(enc)
     ex = emi._executor()
-    np.save(os.path.join(out_dir, f"out{rank}.npy"), out)
+    np.save(os.path.join(out_dir, f"ct{rank}.npy"), res)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "out0.npy"), emi.decrypt(res))
     np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array([ex.sharded_levels, len(ex.levels), ex.world]))
     dist.barrier()
     dist.destroy_process_group()
@@ -366,7 +374,7 @@ def _two_rank_worker(rank, world, port, out_dir, tag, unroll=False):
 @pytest.mark.parametrize("unroll", [False, True], ids=["plain_key", "unrolled_key"])
 def test_two_rank_sharded_encrypted_inverse(tmp_path, unroll):
     """SURVEY 8e on the inverse itself: levels >= 48 wide are split over two ranks, narrower ones replicated;
-    both ranks must decrypt the reference's digits."""
+    both ranks end with the same ciphertexts, which decrypt (on rank 0, the only holder of the secret keys) to the reference's digits."""
     import socket
     import torch.multiprocessing as mp
     tag = "baseline_n2_len20_ints8"
@@ -376,8 +384,8 @@ def test_two_rank_sharded_encrypted_inverse(tmp_path, unroll):
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), tag, unroll), nprocs=2, join=True)
-    for r in range(2):
-        assert np.load(tmp_path / f"out{r}.npy").tolist() == c["out"], r
+    assert np.load(tmp_path / "out0.npy").tolist() == c["out"]                                  # rank 0 holds the secret keys
+    assert np.array_equal(np.load(tmp_path / "ct0.npy"), np.load(tmp_path / "ct1.npy"))       # both ranks hold the same result
     sharded, total, world = np.load(tmp_path / "meta0.npy")
     assert world == 2 and 0 < sharded < total
 
@@ -394,17 +402,19 @@ def _two_gpu_worker(rank, world, port, out_dir, tag):
     from bmi_amd.main import EncryptedMatrixInversion
     c = next(x for x in load("inverse.json") if x["tag"] == tag)
     eng = tfhe.Engine(device=rank)
-    eng.keygen_shared()
     emi = EncryptedMatrixInversion(c["n"], None, 2, c["len"], c["ints"], False, False, engine=eng, device=rank)
+    emi.keygen()                                         # rank 0's evaluation keys broadcast over RCCL
     M = np.array(c["M"]).reshape(c["n"], c["n"])
     q, s = emi.quantize(M)
     enc = emi.encrypt(q, s) if rank == 0 else np.zeros((c["n"] ** 2 * (c["len"] + 1), 1025), np.uint64)
     t = torch.from_numpy(enc.view(np.int64)).to(torch.device("cuda", rank))
     dist.broadcast(t, src=0)
     enc = t.cpu().numpy().view(np.uint64)
-    out = emi.decrypt(emi.evaluate(enc))
+    res = emi.evaluate(enc)
     ex = emi._executor()
-    np.save(os.path.join(out_dir, f"out{rank}.npy"), out)
+    np.save(os.path.join(out_dir, f"ct{rank}.npy"), res)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "out0.npy"), emi.decrypt(res))
     np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array([ex.sharded_levels, len(ex.levels), ex.world]))
     dist.barrier()
     dist.destroy_process_group()
@@ -426,8 +436,8 @@ def test_two_gpu_rccl_sharded_inverse(tmp_path):
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_two_gpu_worker, args=(2, port, str(tmp_path), tag), nprocs=2, join=True)
-    for r in range(2):
-        assert np.load(tmp_path / f"out{r}.npy").tolist() == c["out"], r
+    assert np.load(tmp_path / "out0.npy").tolist() == c["out"]
+    assert np.array_equal(np.load(tmp_path / "ct0.npy"), np.load(tmp_path / "ct1.npy"))
     sharded, total, world = np.load(tmp_path / "meta0.npy")
     assert world == 2 and 0 < sharded < total
 

@@ -340,6 +340,96 @@ def test_traced_tidy_on_mixed_sign_digits():
         assert out[:-1] == [int(x) for x in want.d] and out[-1] == int(want.sign)
 
 
+def _plain_add(d1, s1, d2, s2, ints):
+    """the reference's steps in plaintext mode (digits are ints: QFloat.__iadd__ runs digit-times-sign, the carry chain and
+    tidy - pinned to the reference's goldens above)"""
+    a = QFloat(np.array(d1), ints, 2, True, s1)
+    b = QFloat(np.array(d2), ints, 2, True, s2)
+    a += b
+    return [int(x) for x in a.array], int(a.sign)
+
+
+@pytest.mark.parametrize("size", [1, 2, 3, 4, 5, 9, 13, 30, 37])
+def test_fused_signed_addition_equals_the_reference_steps(size):
+    """QFloat += QFloat on encrypted base-2 digits takes base_p_arrays.signed_add_binary (three look-aheads in parallel and a
+    packed selection: four levels) instead of the reference's digit-times-sign sum, truncating carry chain and tidy.  Same
+    integers on random operands - leading digits up to 3 (from_float does not reduce them), signs -1 / 0 / +1 (a zero sign
+    makes the digits irrelevant), results that overflow the format, equal magnitudes, zeros - and every interval claim holds."""
+    rng = np.random.default_rng(100 + size)
+    ints = size // 2
+    circ = Circuit()
+    da = [circ.input(0, 3 if i == 0 else 1) for i in range(size)]
+    db = [circ.input(0, 3 if i == 0 else 1) for i in range(size)]
+    sa, sb = circ.input(-1, 1), circ.input(-1, 1)
+    q = QFloat(list(da), ints, 2, True, sa)
+    q += QFloat(list(db), ints, 2, True, sb)
+    assert q._neg is not None                         # went through the fused path
+    circ.set_outputs(list(q.array) + [q.sign])
+    depth = max(circ.leaf_level)
+    assert depth <= (9 if size > 36 else 8)           # operands with signs that may be zero and wide leading digits: 1 + 1 + 4 (+ sign 2)
+    cases = []
+    for t in range(300):
+        x = rng.integers(0, 2, size)
+        y = rng.integers(0, 2, size)
+        if t % 3 == 0:
+            x[0], y[0] = rng.integers(0, 4), rng.integers(0, 4)
+        if t % 7 == 0:
+            y = x.copy()                              # equal magnitudes: opposite signs cancel to +0
+        if t % 11 == 0:
+            x[:] = 0
+        if t % 13 == 0:
+            y[:] = 0
+        if t % 17 == 0:
+            x[:], y[:] = 1, 1                         # overflows when the signs agree
+        s1, s2 = (int(rng.choice([-1, 1])), int(rng.choice([-1, 1]))) if t % 5 else (int(rng.integers(-1, 2)), int(rng.integers(-1, 2)))
+        cases.append((x, s1, y, s2))
+    for x, s1, y, s2 in cases:
+        want_d, want_s = _plain_add(x, s1, y, s2, ints)
+        out = circ.simulate([int(v) for v in x] + [int(v) for v in y] + [s1, s2])
+        assert out[:-1] == want_d and out[-1] == want_s, (list(x), s1, list(y), s2, out, want_d, want_s)
+
+
+def test_fused_addition_chain_scalars_and_depth():
+    """A chain of additions costs four levels each once the operands carry their sign as a bit; scalars in {-1, 0, 1} (plain,
+    SignedBinary, encrypted) enter at digit ints - 1 like in the reference; operands the fused form does not cover (a scalar
+    beyond [-1, 1], another base) still take the reference's steps.  All against the plaintext mode."""
+    rng = np.random.default_rng(5)
+    size, ints = 12, 5
+    circ = Circuit()
+    ops = [([circ.input(0, 1) for _ in range(size)], circ.input(-1, 1)) for _ in range(4)]
+    v_enc = circ.input(-1, 1)
+    q = QFloat(list(ops[0][0]), ints, 2, True, ops[0][1])
+    levels = []
+    for d, sg in ops[1:]:
+        q += QFloat(list(d), ints, 2, True, sg)
+        levels.append(max(circ.leaf_level[t] for x in q.array if isinstance(x, Lin) for t in x.terms))
+    assert levels[1] - levels[0] <= 4 and levels[2] - levels[1] <= 4      # digits: at most four levels per chained addition (12 digits: 2 + 1, the sign path may add one)
+    q = q - SignedBinary(v_enc)          # r = -other; r += self with an encrypted ternary scalar
+    q = 1 - q
+    q += SignedBinary(-1)
+    q += 0
+    wide = q + 2                          # beyond [-1, 1]: the reference's steps
+    circ.set_outputs(list(q.array) + [q.sign] + list(wide.array) + [wide.sign])
+    for _ in range(200):
+        vals, plain = [], []
+        for _k in range(4):
+            d = rng.integers(0, 2, size)
+            sg = int(rng.choice([-1, 1]))
+            vals += [int(x) for x in d] + [sg]
+            plain.append(QFloat(np.array(d), ints, 2, True, sg))
+        v = int(rng.integers(-1, 2))
+        p = plain[0]
+        for o in plain[1:]:
+            p += o
+        p = p - SignedBinary(v)
+        p = 1 - p
+        p += SignedBinary(-1)
+        p += 0
+        pw = p + 2
+        out = circ.simulate(vals + [v])
+        assert out == [int(x) for x in p.array] + [int(p.sign)] + [int(x) for x in pw.array] + [int(pw.sign)]
+
+
 def test_circuit_guards():
     c = Circuit()
     x = c.input(0, 40)

@@ -54,7 +54,8 @@ def test_two_rank_gloo_sharding(tmp_path):
 
 # ----------------------------------------------------------------------------------------------------------------
 # The sharded level executor (bmi_amd/executor.py) under two gloo ranks.  The GPU engine is replaced by a plaintext
-# stand-in with the same call surface (a "ciphertext" is a row whose last word is the message at delta_log = 0), so
+# stand-in with the same call surface (a "ciphertext" is a row whose last word is the message at delta_log = 1: the executor
+# keeps constants in units of Delta / 2 for the half-scale tables of Circuit.lut_neg), so
 # what is tested here is the host logic: padded level regions, per-rank row ranges, the in-place all-gather and the
 # threshold below which levels are computed redundantly.  The same executor runs on GPUs in tests/test_gpu_inverse.py.
 class _PlainParams:
@@ -73,10 +74,10 @@ class _PlainEngine:
         return torch.device("cpu")
 
     def delta_log(self, msg_bits=4):
-        return 0
+        return 1
 
     def lut_register(self, table, msg_bits, out_delta_log):
-        self.tables.append((int(msg_bits), [int(v) for v in table]))
+        self.tables.append((int(msg_bits), [int(v) << int(out_delta_log) for v in table]))   # out_delta_log 0: a lut_neg table
         return len(self.tables) - 1
 
     def reserve(self, n):
@@ -98,6 +99,8 @@ class _PlainEngine:
         for r in range(count):
             p, table = self.tables[int(ids[r])]
             x = int(d_in[r, -1])
+            assert x % 2 == 0                     # whole multiples of Delta reach a look-up
+            x >>= 1
             m = x >> (4 - p)
             half = 1 << (p - 1)
             d_out[r] = 0
@@ -122,9 +125,10 @@ def _exec_worker(rank, world, port, out_dir, threshold):
     ex = Executor(circ, _PlainEngine(), shard_threshold=threshold)
     inputs = np.load(os.path.join(out_dir, "inputs.npy"))
     cts = np.zeros((circ.n_inputs, 3), np.uint64)
-    cts[:, -1] = inputs.astype(np.int64).view(np.uint64)
+    cts[:, -1] = (2 * inputs.astype(np.int64)).view(np.uint64)
     out = ex.run(cts)
-    np.save(os.path.join(out_dir, f"out{rank}.npy"), out[:, -1].view(np.int64))
+    assert not (out[:, -1].view(np.int64) % 2).any()
+    np.save(os.path.join(out_dir, f"out{rank}.npy"), out[:, -1].view(np.int64) // 2)
     np.save(os.path.join(out_dir, f"sharded{rank}.npy"), np.array([ex.sharded_levels, len(ex.levels)]))
     dist.barrier()
     dist.destroy_process_group()

@@ -14,7 +14,8 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     log_N = int(sys.argv[3]) if len(sys.argv) > 3 else 10   # 11: k_blind_rotate_wide49 (8 waves; pass variant 0)
     unroll = int(sys.argv[4]) if len(sys.argv) > 4 else 1   # 2: k_blind_rotate_lat2u_49 (pass variant 2 for the phase names); cycles are then per PAIR of coefficients / 2
-    eng = tfhe.Engine(tfhe.default_params(q_bits=49, log_N=log_N)); eng.set_bsk_unroll(unroll); eng.keygen(0x5EED)
+    q_bits = int(sys.argv[5]) if len(sys.argv) > 5 else 49  # 65 with unroll = 2: k_blind_rotate_lat2u_t64 (the unrolled torus kernel)
+    eng = tfhe.Engine(tfhe.default_params(q_bits=q_bits, log_N=log_N)); eng.set_bsk_unroll(unroll); eng.keygen(0x5EED)
     DL = eng.delta_log()
     lid = eng.lut_register(np.arange(-8, 8), 4, DL)
     ct = eng.encrypt(np.random.default_rng(1).integers(-8, 8, B), DL)
@@ -31,7 +32,8 @@ def main():
         eng.blind_rotate(d_small, d_ids, B, d_out, s)
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * 128)()
-    rc = (tfhe.load_library().bmi_debug_phase_prof_unrolled if unroll == 2 else tfhe.load_library().bmi_debug_phase_prof)(buf)
+    lib = tfhe.load_library()
+    rc = (lib.bmi_debug_phase_prof_unrolled_t64 if (unroll == 2 and q_bits == 65) else lib.bmi_debug_phase_prof_unrolled if unroll == 2 else lib.bmi_debug_phase_prof)(buf)
     assert rc == 0, rc
     a = np.array(buf[:], dtype=np.float64).reshape(16, 8)
     WIDE_NAMES = ["decompose + forward tasks (both rounds)", "barrier after tasks", "MAC (both rounds)", "barrier after MAC", "sums + barrier", "inverse + update (waves 0-3)", "barrier after inverse", "loop head"]

@@ -1,73 +1,136 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 output of tools/gpu_final.sh (gpurun_out/final/prof/{trace,fetch,write,sq}) into the tracked
-summaries under profiles/:  <tag>_kernel_stats_B<batch>.csv (the --stats table), <tag>_pmc_B<batch>.json (average
-counters per launch for the hot kernels) and hbm_traffic.json (what bench.py reports as roofline.traffic).
-usage: summarize_prof.py <tag> <batch> <hot kernel substring> [more kernel substrings...]"""
-import csv, glob, json, os, shutil, sys
+"""Turns the rocprofv3 output of tools/gpu_final.sh (<prof>/{trace,fetch,write,sq}) into the summaries that are committed
+under profiles/.  Every figure is kept PER KERNEL INSTANTIATION AND LAUNCH SHAPE: dispatches are grouped by the full kernel
+name (template arguments included), the grid size and the workgroup size, so the one-ciphertext and 256-ciphertext latency
+probes of bench.py never mix with the 8,192-ciphertext launches, and two instantiations of one template never share a row
+(VERDICT r2, weak 7).
+
+    <out>/<tag>_kernel_stats_B<batch>.csv     rocprofv3's own --stats table (copied)
+    <out>/<tag>_kernel_groups_B<batch>.json   per (kernel, grid, workgroup): calls, avg / min / max ms from the kernel trace,
+                                              average counters per dispatch from the three --pmc passes, HBM bytes per launch
+                                              ((2 * FETCH_SIZE + WRITE_SIZE) KiB, MI355X_MICROARCH.md), VALU busy fraction
+                                              (waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, waves per SIMD from the
+                                              workgroup size: these kernels hold one workgroup per compute unit)
+    <out>/hbm_traffic.json                    what bench.py reads for roofline.traffic: the blind-rotation groups
+
+usage: summarize_prof.py <tag> <batch> [<prof dir> [<out dir>]]      (defaults: gpurun_out/final/prof, profiles)"""
+import csv, glob, json, os, re, shutil, sys
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag, batch, hot = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-kernels = sys.argv[3:]
-base = os.path.join(REPO, "gpurun_out", "final", "prof")
+tag, batch = sys.argv[1], int(sys.argv[2])
+base = sys.argv[3] if len(sys.argv) > 3 else os.path.join(REPO, "gpurun_out", "final", "prof")
+out_dir = sys.argv[4] if len(sys.argv) > 4 else os.path.join(REPO, "profiles")
+os.makedirs(out_dir, exist_ok=True)
 
-def newest(pattern, needle):
-    for f in sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True):
-        if needle in open(f).read():
-            return f
-    raise SystemExit(f"no file matching {pattern} mentions {needle}")
 
-stats = newest(os.path.join(base, "trace", "*", "*_kernel_stats.csv"), hot)
-shutil.copy(stats, os.path.join(REPO, "profiles", f"{tag}_kernel_stats_B{batch}.csv"))
-avg_ns = {}
-for row in csv.DictReader(open(stats)):
-    for k in kernels:
-        if k in row["Name"]:
-            avg_ns[k] = float(row["AverageNs"])
-counters = {k: {} for k in kernels}
+def newest(pattern):
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)
+    return fs[0] if fs else None
+
+
+def col(row, *names):
+    for n in names:
+        if n in row and row[n] != "":
+            return row[n]
+    raise KeyError(f"none of {names} in {list(row)[:30]}")
+
+
+def short(name):
+    s = re.sub(r"^void\s+", "", name.strip().strip('"'))
+    s = re.sub(r"\(anonymous namespace\)::", "", s)
+    depth, cut = 0, len(s)
+    for i, ch in enumerate(s):          # cut the argument list: the first '(' outside template brackets
+        if ch == "<": depth += 1
+        elif ch == ">": depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    return s[:cut].strip().replace(" [clone .kd]", "").replace(".kd", "")
+
+
+def cts_per_workgroup(kernel, wg):
+    if "lat" in kernel or "wide" in kernel or "quad" in kernel: return 1        # one workgroup per ciphertext
+    if wg == 512: return 4                                                       # wave-pair kernels: four ciphertexts per workgroup
+    if wg == 256: return 2
+    return None
+
+
+groups = {}
+
+
+def grp(kernel, grid, wg):
+    return groups.setdefault((kernel, int(grid), int(wg)), {"kernel": kernel, "grid_size": int(grid), "workgroup_size": int(wg), "dur_ns": [], "counters": {}})
+
+
+trace = newest(os.path.join(base, "trace", "**", "*kernel_trace.csv")) or newest(os.path.join(base, "trace", "*", "*kernel_trace.csv"))
+if trace is None:
+    fs = glob.glob(os.path.join(base, "trace", "**", "*kernel_trace.csv"), recursive=True)
+    trace = max(fs, key=os.path.getmtime) if fs else None
+if trace is None:
+    raise SystemExit(f"no kernel trace under {base}/trace")
+for row in csv.DictReader(open(trace)):
+    k = short(col(row, "Kernel_Name", "Name"))
+    gx = int(col(row, "Grid_Size_X", "Grid_Size")) * int(row.get("Grid_Size_Y") or 1) * int(row.get("Grid_Size_Z") or 1)
+    wx = int(col(row, "Workgroup_Size_X", "Workgroup_Size")) * int(row.get("Workgroup_Size_Y") or 1) * int(row.get("Workgroup_Size_Z") or 1)
+    grp(k, gx, wx)["dur_ns"].append(int(col(row, "End_Timestamp")) - int(col(row, "Start_Timestamp")))
+
+stats = glob.glob(os.path.join(base, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(max(stats, key=os.path.getmtime), os.path.join(out_dir, f"{tag}_kernel_stats_B{batch}.csv"))
+
 for p in ("fetch", "write", "sq"):
-    try:
-        f = newest(os.path.join(base, p, "*", "*_counter_collection.csv"), hot)
-    except SystemExit:
+    fs = glob.glob(os.path.join(base, p, "**", "*counter_collection.csv"), recursive=True)
+    if not fs:
         continue
-    acc = {}
-    for row in csv.DictReader(open(f)):
-        for k in kernels:
-            if k in row["Kernel_Name"]:
-                acc.setdefault((k, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
-    # one row per (dispatch, counter[, dimension]): sum the rows of a dispatch, average over dispatches
     per = {}
-    for row in csv.DictReader(open(f)):
-        for k in kernels:
-            if k in row["Kernel_Name"]:
-                per.setdefault((k, row["Counter_Name"]), {}).setdefault(row["Dispatch_Id"], 0.0)
-                per[(k, row["Counter_Name"])][row["Dispatch_Id"]] += float(row["Counter_Value"])
-    for (k, c), d in per.items():
-        counters[k][c] = sum(d.values()) / len(d)
-traffic = {}
-tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-if os.path.exists(tpath):
-    try:
-        old = json.load(open(tpath))
-        traffic = old.get("kernels", {}) if "kernels" in old else {}
-    except Exception:
-        traffic = {}
-for hot in kernels:
-  h = counters[hot]
-  if "FETCH_SIZE" in h and "WRITE_SIZE" in h:
-    # MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64-byte units as 32 -> x2
-    h["hbm_bytes_per_launch_corrected"] = (2 * h["FETCH_SIZE"] + h["WRITE_SIZE"]) * 1024
-    extra = {}
-    if "SQ_ACTIVE_INST_VALU" in h and "SQ_WAVE_CYCLES" in h:
-        # share of the resident wavefronts' cycles in which a VALU instruction of theirs is executing, summed over the
-        # wavefronts of a SIMD (waves_per_simd of them resident): how busy the vector ALUs are - what bounds this kernel
-        wps = 2.0
-        extra = {"valu_busy_frac": wps * h["SQ_ACTIVE_INST_VALU"] / h["SQ_WAVE_CYCLES"], "waves_per_simd": wps,
-                 "valu_formula": "waves_per_simd * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES"}
-    traffic[hot] = {"batch": batch, "bytes_per_launch": h["hbm_bytes_per_launch_corrected"], "kernel": hot,
-                    "source": f"profiles/{tag}_pmc_B{batch}.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", **extra}
-json.dump({"kernels": traffic}, open(tpath, "w"), indent=1)
-h = counters[kernels[0]]
-json.dump({"tag": tag, "batch": batch, "kernel_trace_avg_ns": avg_ns, "counters_avg_per_launch": counters,
-           "note": "rocprofv3 --kernel-trace --stats pass and three separate --pmc passes of `python3 bench.py --batch "
-                   f"{batch} --no-cpu-baseline --no-inverse` (tools/gpu_final.sh); FETCH_SIZE/WRITE_SIZE in KiB; FETCH doubled per MI355X_MICROARCH.md"},
-          open(os.path.join(REPO, "profiles", f"{tag}_pmc_B{batch}.json"), "w"), indent=1)
-print(json.dumps({"avg_ns": avg_ns, "hot": {k: v for k, v in h.items()}}, indent=1))
+    for row in csv.DictReader(open(max(fs, key=os.path.getmtime))):
+        k = short(col(row, "Kernel_Name"))
+        key = (k, int(col(row, "Grid_Size", "Grid_Size_X")), int(col(row, "Workgroup_Size", "Workgroup_Size_X")))
+        d = per.setdefault((key, col(row, "Counter_Name")), {})
+        # one row per (dispatch, counter[, dimension]): sum the rows of a dispatch, average over dispatches
+        d[col(row, "Dispatch_Id")] = d.get(col(row, "Dispatch_Id"), 0.0) + float(col(row, "Counter_Value"))
+    for (key, cname), d in per.items():
+        g = grp(*key)
+        g["counters"][cname] = sum(d.values()) / len(d)
+        g.setdefault("counter_dispatches", {})[cname] = len(d)
+
+rows = []
+for g in groups.values():
+    if not g["dur_ns"] and not g["counters"]:
+        continue
+    r = {"kernel": g["kernel"], "grid_size": g["grid_size"], "workgroup_size": g["workgroup_size"],
+         "workgroups": g["grid_size"] // max(g["workgroup_size"], 1), "calls": len(g["dur_ns"])}
+    cpw = cts_per_workgroup(g["kernel"], g["workgroup_size"]) if "blind_rotate" in g["kernel"] else None
+    if cpw:
+        r["ciphertexts_per_launch"] = r["workgroups"] * cpw
+    if g["dur_ns"]:
+        r.update(avg_ms=sum(g["dur_ns"]) / len(g["dur_ns"]) / 1e6, min_ms=min(g["dur_ns"]) / 1e6, max_ms=max(g["dur_ns"]) / 1e6)
+    c = g["counters"]
+    if c:
+        r["counters_avg_per_dispatch"] = c
+        r["counter_dispatches"] = g.get("counter_dispatches", {})
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts a 128-byte request as 64 -> x 2
+        r["hbm_bytes_per_launch"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        r["hbm_formula"] = "(2 * FETCH_SIZE + WRITE_SIZE) * 1024"
+    if "SQ_ACTIVE_INST_VALU" in c and c.get("SQ_WAVE_CYCLES"):
+        wps = max(1.0, g["workgroup_size"] / 64 / 4)      # one workgroup per compute unit (LDS-limited kernels): its waves over 4 SIMDs
+        r.update(waves_per_simd=wps, valu_busy_frac=wps * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                 valu_formula="waves_per_simd * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (waves_per_simd = workgroup size / 256: one workgroup per CU)")
+    if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_ACTIVE_INST_LDS"):
+        r["lds_bank_conflict_frac"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_ACTIVE_INST_LDS"]
+    rows.append(r)
+rows.sort(key=lambda r: -(r.get("avg_ms", 0) * r["calls"]))
+note = ("rocprofv3 --kernel-trace --stats pass and three separate --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_*) of `python3 bench.py --batch "
+        f"{batch} --no-cpu-baseline --no-inverse` (tools/gpu_final.sh); one row per (kernel instantiation, grid size, workgroup size); "
+        "FETCH_SIZE / WRITE_SIZE in KiB, FETCH doubled per MI355X_MICROARCH.md")
+json.dump({"tag": tag, "batch": batch, "note": note, "groups": rows}, open(os.path.join(out_dir, f"{tag}_kernel_groups_B{batch}.json"), "w"), indent=1)
+entries = [{"kernel": r["kernel"], "grid_size": r["grid_size"], "workgroup_size": r["workgroup_size"], "batch": r.get("ciphertexts_per_launch"),
+            "avg_ms": r.get("avg_ms"), "calls": r["calls"], "bytes_per_launch": r.get("hbm_bytes_per_launch"),
+            "valu_busy_frac": r.get("valu_busy_frac"), "waves_per_simd": r.get("waves_per_simd"),
+            "source": f"profiles/{tag}_kernel_groups_B{batch}.json"}
+           for r in rows if "blind_rotate" in r["kernel"]]
+json.dump({"entries": entries, "note": "per (kernel instantiation, launch shape); bench.py matches kernel AND batch"},
+          open(os.path.join(out_dir, "hbm_traffic.json"), "w"), indent=1)
+for r in rows[:14]:
+    print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k not in ("counters_avg_per_dispatch", "counter_dispatches", "hbm_formula", "valu_formula")}))
