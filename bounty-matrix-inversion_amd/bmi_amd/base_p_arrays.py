@@ -567,6 +567,35 @@ def carry_propagate_nonneg(c, columns, p):
     for _round in range(12):
         if all(sum(hi_of(t) for t in col) <= target for col in cols):
             break
+        if p == 2 and max(sum(hi_of(t) for t in col) for col in cols) <= 4:
+            # Last round, two columns per look-up: with every column sum at most 4, the value 2 s_i + s_{i+1} of a pair of
+            # adjacent columns is at most 12 - one 4-bit look-up per output bit - and its four bits go to columns i+1, i, i-1,
+            # i-2.  A column then holds its own pair's bit and ONE bit of the pair to its right: at most 2, the target.  (The
+            # single-column rounds need two more rounds from here: 4 -> 3 -> 2.)
+            new_cols = [[] for _ in range(L)]
+            i = L - 2
+            while i >= -1:
+                hi_col = cols[i] if i >= 0 else []
+                lo_col = cols[i + 1]
+                hs, ls = sum(hi_of(t) for t in hi_col), sum(hi_of(t) for t in lo_col)
+                if hs <= 1 and ls <= 1:        # nothing to compress: the terms stay where they are
+                    if i >= 0:
+                        new_cols[i].extend(hi_col)
+                    new_cols[i + 1].extend(lo_col)
+                else:
+                    v = 0
+                    for t in hi_col:
+                        v = v + t * 2
+                    for t in lo_col:
+                        v = v + t
+                    top = 2 * hs + ls
+                    for k in range(top.bit_length()):
+                        col = i + 1 - k
+                        if col >= 0:
+                            new_cols[col].append(lut(c, v, lambda x, k=k: (x >> k) & 1))
+                i -= 2
+            cols = new_cols
+            continue
         # Compress every column that holds more than one digit's worth: a column left alone at the target would
         # be pushed over it again by the digits arriving from its right neighbour (a ripple of one column per
         # round); compressing all of them together is the carry-save step and converges in ~log rounds.

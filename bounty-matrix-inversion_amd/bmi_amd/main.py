@@ -20,9 +20,8 @@ from .qfloat_matrix_inversion import (float_matrix_to_qfloat_arrays, qfloat_and_
 
 
 def estimated_evaluate_ms(circuit):
-    """Cost model of one evaluation on one MI355X (measured): a level up to 512 ciphertexts wide runs
-    ceil(width / 256) rounds of the latency kernel (4.4 ms each: one workgroup per ciphertext, 256 CUs), a wider one
-    the throughput kernel (10.8 ms per started 1,024 ciphertexts, 96 PBS per ms once the chip is full)."""
+    """Cost model of one evaluation on one MI355X (program.estimated_evaluate_ms: rounds of the latency kernel for levels up to
+    512 ciphertexts wide, the throughput kernel beyond)."""
     widths = circuit.level_widths() if isinstance(circuit, Program) else [len(lv) for lv in circuit.levels()]
     return _estimate_widths(widths)
 
@@ -42,12 +41,12 @@ def trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base=2, true_division=False
     [0, base - 1]; signs [-1, 1].
 
     division_bits: quotient bits per step of the binary divisions (2 or 3, base_p_arrays._division_radix); None
-    traces both for n <= 3 and keeps the circuit the cost model above estimates faster (radix 8 is 19 % shallower
-    but 2.3x wider per step: it wins while a step still fits one kernel round; at 4x4 (len 40) the estimates differ
-    by 3 %, not worth tracing twice)."""
+    traces both for n <= 4 and keeps the circuit the cost model above estimates faster (a step costs the same look-up
+    levels at either radix - three or four of borrow look-ahead and one selection - so radix 8 is a third shallower, but
+    2.3x wider per step; larger matrices are bound by throughput, where its 13 % more look-ups lose: radix 4)."""
     from . import base_p_arrays as bpa
     if division_bits is None:
-        cands = (2, 3) if (n <= 3 and qfloat_base == 2) else (2,)
+        cands = (2, 3) if (n <= 4 and qfloat_base == 2) else (2,)
         best = None
         for bits in cands:
             cir = trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize, bits, msg_bits)
@@ -87,7 +86,7 @@ def compile_inverse(n, qfloat_len, qfloat_ints, qfloat_base=2, true_division=Fal
 
     def build():
         from . import base_p_arrays as bpa
-        cands = (division_bits,) if division_bits else ((2, 3) if (n <= 3 and qfloat_base == 2) else (2,))
+        cands = (division_bits,) if division_bits else ((2, 3) if (n <= 4 and qfloat_base == 2) else (2,))
         best = None
         for bits in cands:
             cir = trace_inverse(n, qfloat_len, qfloat_ints, qfloat_base, true_division, tensorize, bits)

@@ -37,6 +37,12 @@ def cache_dir():
     return d
 
 
+def shipped_dir():
+    """read-only programs that travel with the package (compact form, Program.save_compact): the BASELINE configurations whose
+    trace takes minutes (8 x 8, 10 x 10).  A file is only used when its name carries the current tracer fingerprint."""
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "programs")
+
+
 def _tracer_fingerprint():
     """hash of the modules that define what a trace looks like: a cached program is only valid for the code that made it"""
     here = os.path.dirname(os.path.abspath(__file__))
@@ -293,6 +299,49 @@ class Program:
                             **{k: getattr(self, k) for k in self.ARRAYS})
         os.replace(tmp, path)     # atomic: several ranks may compile the same configuration at once
 
+    # compact form (shipped programs): index arrays as differences, then LZMA - 16 MB of a zlib .npz become ~3 MB
+    _DELTA = ("node_ptr", "out_ptr", "claim_ptr")
+
+    def save_compact(self, path):
+        import io
+        import lzma
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        arrays = {k: getattr(self, k) for k in self.ARRAYS}
+        for k in self._DELTA:
+            arrays[k] = np.diff(arrays[k], prepend=0).astype(np.int32)
+        # a term's leaf as its distance back from the node that reads it (small and repetitive), same for claims / outputs
+        n_in = self.n_inputs
+        owner = n_in + np.repeat(np.arange(self.n_nodes, dtype=np.int64), np.diff(self.node_ptr))
+        arrays["term_leaf"] = (owner - self.term_leaf).astype(np.int32)
+        arrays["claim_leaf"] = np.diff(self.claim_leaf.astype(np.int64), prepend=0).astype(np.int32)
+        meta_keys = sorted(self.meta)
+        buf = io.BytesIO()
+        np.savez(buf, __format=np.int64(FORMAT), __msg_bits=np.int64(self.msg_bits), __meta_keys=np.asarray(meta_keys),
+                 __meta_vals=np.asarray([repr(self.meta[k]) for k in meta_keys]), **arrays)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(lzma.compress(buf.getvalue(), preset=6))
+        os.replace(tmp, path)
+
+    @classmethod
+    def load_compact(cls, path):
+        import ast
+        import io
+        import lzma
+        with open(path, "rb") as f:
+            z = np.load(io.BytesIO(lzma.decompress(f.read())), allow_pickle=False)
+        if int(z["__format"]) != FORMAT:
+            raise ValueError("shipped program has another format")
+        arrays = {k: z[k] for k in cls.ARRAYS}
+        for k in cls._DELTA:
+            arrays[k] = np.cumsum(arrays[k].astype(np.int64))
+        n_in = int(arrays["in_lo"].size)
+        owner = n_in + np.repeat(np.arange(arrays["node_lut"].size, dtype=np.int64), np.diff(arrays["node_ptr"]))
+        arrays["term_leaf"] = (owner - arrays["term_leaf"]).astype(np.int32)
+        arrays["claim_leaf"] = np.cumsum(arrays["claim_leaf"].astype(np.int64)).astype(np.int32)
+        meta = {str(k): ast.literal_eval(str(v)) for k, v in zip(z["__meta_keys"], z["__meta_vals"])}
+        return cls(int(z["__msg_bits"]), arrays, meta)
+
     @classmethod
     def load(cls, path):
         import ast
@@ -367,16 +416,18 @@ class Program:
 
 
 def estimated_evaluate_ms(widths, gpus=1):
-    """Cost model of one evaluation (measured per-level costs on one MI355X): a level up to 512 ciphertexts
-    wide runs ceil(width / 256) rounds of the latency kernel (4.4 ms each: one workgroup per ciphertext, 256 CUs), a wider
-    one the throughput kernel (10.8 ms per started 1,024 ciphertexts, 96 PBS per ms once the chip is full).  gpus > 1:
-    every level wider than one round is split evenly (each rank bootstraps width / gpus rows; the all-gather of a few MB
-    per level over xGMI is not modelled) - an ESTIMATE, no multi-GPU box was available to measure it."""
+    """Cost model of one evaluation (measured per-level costs on one MI355X with the plain 49-bit kernels): a
+    level up to 512 ciphertexts wide runs ceil(width / 256) rounds of the latency kernel (3.8 ms each with its keyswitch and
+    linear combinations: one workgroup per ciphertext, 256 CUs), a wider one the throughput kernel (9.8 ms per started 1,024
+    ciphertexts, 104 PBS per ms once the chip is full).  Used to choose between circuit variants (division radix) and for the
+    multi-GPU estimate; what matters is the ratio of a round to a wide level, which the unrolled kernels share.  gpus > 1:
+    every level wider than one round is split evenly (each rank bootstraps width / gpus rows; the all-gather of a few MB per
+    level over xGMI is not modelled) - an ESTIMATE, no multi-GPU box was available to measure it."""
     w = np.ceil(np.asarray(widths, np.float64) / (gpus if gpus > 1 else 1))
     if gpus > 1:
         w = np.where(np.asarray(widths) <= 256, np.asarray(widths, np.float64), w)
-    lat = 4.4 * np.ceil(w / 256)
-    tp = np.maximum(10.8 * np.ceil(w / 1024), w / 96.0)
+    lat = 3.8 * np.ceil(w / 256)
+    tp = np.maximum(9.8 * np.ceil(w / 1024), w / 104.0)
     return float(np.where(w <= 512, lat, tp).sum())
 
 
@@ -395,6 +446,13 @@ def compile_cached(key_fields, build, cache=True):
                 return prog, {"cached": True, "seconds": time.time() - t0, "path": path}
             except Exception:
                 pass    # unreadable / stale file: rebuild below and overwrite it
+        shipped = os.path.join(shipped_dir(), f"{name}_{key}.prog.xz".replace(" ", ""))
+        if os.path.exists(shipped):      # traced by THIS source tree (the key carries its fingerprint) and committed with it
+            try:
+                prog = Program.load_compact(shipped)
+                return prog, {"cached": True, "shipped": True, "seconds": time.time() - t0, "path": shipped}
+            except Exception:
+                pass
     prog = build()
     if path is not None:
         try:

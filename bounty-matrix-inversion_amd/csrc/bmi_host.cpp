@@ -1014,6 +1014,11 @@ int bmi_set_keyswitch_variant(bmi_ctx *c, int variant) {
 int bmi_set_kernel_variant(bmi_ctx *c, int variant) {
     if (!c) return -1;
     if (variant < 0 || variant > 4) return fail(c, -1, "variant must be 0..4");
+#ifndef BMI_AB_KERNELS
+    if (c->f64() && !c->wide() && !c->quad() && (variant == 1 || variant == 4))
+        return fail(c, -1, "kernel variants 1 and 4 of the 49-bit field (the predecessors of the wave-pair and latency kernels) are not "
+                           "in the product build: make -C csrc ab builds libbmi_tfhe_ab.so with them");
+#endif
     c->variant = variant;
     return 0;
 }

@@ -3,10 +3,13 @@
 // linear combinations stay canonical 64-bit integers in HBM; the bootstrap key (NTT domain), the twiddles and
 // the test polynomials are stored as centred doubles so that the hot loop does no conversions.
 //
-//   k_bsk_to_ntt49        standard-domain GGSW rows (u64) -> NTT domain (f64), lane layout
-//   k_blind_rotate_tp49   THROUGHPUT: one pair of wavefronts per ciphertext (see bmi_kernels.hip for the scheme)
-//   k_blind_rotate_lat49  LATENCY: one workgroup of 8 wavefronts per ciphertext
-//   keyswitch / lincomb   ks_lincomb.hpp with the Field49 policy
+//   k_bsk_to_ntt49           standard-domain GGSW rows (u64) -> NTT domain (f64), lane layout
+//   k_blind_rotate_tpx49     THROUGHPUT: one pair of wavefronts per ciphertext, one exchange per CMUX
+//   k_blind_rotate_lat2_49   LATENCY: one workgroup of 16 wavefronts per ciphertext, two wavefronts per transform
+//   k_blind_rotate_wide49 / wide49u / quad49   N = 2048 (plain, unrolled key) and N = 4096
+//   keyswitch / lincomb      ks_lincomb.hpp with the Field49 policy
+// (the unrolled N = 1024 kernel lives in bmi_kernels_f64u.hip; the predecessors k_blind_rotate_tp49 / lat49 - kernel variants
+// 1 and 4 - are A/B builds only: ab/bmi_kernels_f64_ab.inc, `make ab`)
 #include <hip/hip_runtime.h>
 
 #include "bmi_internal.hpp"
@@ -95,108 +98,9 @@ __device__ __forceinline__ double peel_digit(double &r) {
     return d;
 }
 
-template <int CTS>
-__global__ void __launch_bounds__(128 * CTS, BMI_TP49_WAVES_PER_SIMD)
-    k_blind_rotate_tp49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
-                        const double *__restrict__ luts, const double *__restrict__ bsk, const double *__restrict__ g_tw,
-                        u64 *__restrict__ out, uint32_t count, uint32_t n) {
-    constexpr int AT_WORDS = BMI_AT_WORDS;
-    __shared__ double lds[TW_WORDS + 2 * CTS * SCRATCH_WORDS + CTS * AT_WORDS];
-    stage_twiddles(lds, g_tw);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ctl = wave >> 1, c = wave & 1;
-    const uint32_t ct_raw = blockIdx.x * CTS + ctl;
-    const bool live = ct_raw < count;
-    const uint32_t ct = live ? ct_raw : count - 1;
-    double *tile = lds + TW_WORDS + wave * SCRATCH_WORDS;
-    const double *ptile = lds + TW_WORDS + (wave ^ 1) * SCRATCH_WORDS;
-    uint16_t *at = reinterpret_cast<uint16_t *>(lds + TW_WORDS + 2 * CTS * SCRATCH_WORDS + ctl * AT_WORDS);
-    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
-    for (uint32_t i = lane + 64 * c; i <= n; i += 128) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 1);
-    __syncthreads();
-
-    double acc[16];
-    {
-        const double *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
-        const uint32_t bt = at[n];
-        static_for<0, 16>([&](auto J) {
-            const uint32_t e = (lane + 64 * J + bt) & (2 * N - 1);
-            const double v = tv[e & (N - 1)];
-            acc[J] = c ? ((e & N) ? -v : v) : 0.0;
-        });
-    }
-
-    PH_DECL();
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t a_t = at[i];
-        const double *bsk_i = bsk + (size_t)i * 12 * N;
-        PH_MARK(7);
-        wave_sync();
-        static_for<0, 16>([&](auto J) { tile[lane + 64 * J] = acc[J]; });
-        wave_sync();
-        double r[16];
-        static_for<0, 16>([&](auto J) {
-            const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
-            double v = tile[e & (N - 1)];
-            v = (e & N) ? -v : v;
-            r[J] = round_half_up(f49::red(v - acc[J]), 0x1p-4);
-        });
-        double accn[16];
-        PH_MARK(0);
-        static_for<0, 3>([&](auto LEV) {
-            constexpr int lev = 2 - LEV;  // least significant digit first
-            double x[16];
-            static_for<0, 16>([&](auto J) { x[J] = lev == 0 ? r[J] : peel_digit(r[J]); });
-            forward(x, lane, lds, tile);
-            PH_MARK(1);
-            wave_sync();
-            static_for<0, 16>([&](auto V) { tile[eval_offset(lane, V)] = x[V]; });
-            // bootstrap-key rows of this level are requested BEFORE the barrier: their L2 latency overlaps the wait
-            const double *row_own = bsk_i + ((size_t)(c * 3 + lev) * 2 + c) * N;
-            const double *row_par = bsk_i + ((size_t)((c ^ 1) * 3 + lev) * 2 + c) * N;
-            double2 bo[8], bp[8];
-            static_for<0, 8>([&](auto VP) {
-                bo[VP] = reinterpret_cast<const double2 *>(row_own)[VP * 64 + lane];
-                bp[VP] = reinterpret_cast<const double2 *>(row_par)[VP * 64 + lane];
-            });
-            __syncthreads();
-            PH_MARK(2);
-            static_for<0, 8>([&](auto VP) {
-                const double2 xp = reinterpret_cast<const double2 *>(ptile)[VP * 64 + lane];
-                const double s0 = f49::mul(x[2 * VP], bo[VP].x) + f49::mul(xp.x, bp[VP].x);      // lazy: <= 2.6p per level
-                const double s1 = f49::mul(x[2 * VP + 1], bo[VP].y) + f49::mul(xp.y, bp[VP].y);
-                if constexpr (lev == 2) {
-                    accn[2 * VP] = s0;
-                    accn[2 * VP + 1] = s1;
-                } else {
-                    accn[2 * VP] += s0;
-                    accn[2 * VP + 1] += s1;
-                }
-            });
-            PH_MARK(3);
-            __syncthreads();
-            PH_MARK(4);
-        });
-        static_for<0, 16>([&](auto V) { accn[V] = f49::red(accn[V]); });
-        inverse(accn, lane, lds, tile);
-        static_for<0, 16>([&](auto J) { acc[J] = f49::red(acc[J] + accn[J]); });
-        PH_MARK(5);
-    }
-    PH_FLUSH();
-
-    if (!live) return;
-    u64 *o = out + (size_t)ct * (N + 1);
-    if (c == 0) {
-        static_for<0, 16>([&](auto J) {
-            const uint32_t m = lane + 64 * J;
-            if (m == 0) o[0] = f49::to_u(acc[J]);
-            else o[N - m] = f49::to_u(-acc[J]);
-        });
-    } else if (lane == 0) {
-        o[N] = f49::to_u(acc[0]);
-    }
-}
-
+#ifdef BMI_AB_KERNELS
+#include "ab/bmi_kernels_f64_ab.inc"
+#endif
 
 // THROUGHPUT, second form: one exchange per CMUX instead of three.
 // Wavefront c of a pair owns INPUT polynomial c of the CMUX: it decomposes rot(acc_c) - acc_c, transforms the three
@@ -406,106 +310,6 @@ __global__ void __launch_bounds__(128 * TPX_CTS)
     }
 }
 
-constexpr int LAT_THREADS = 512;
-constexpr int LAT_LDS_WORDS = TW_WORDS + 2 * N + 6 * SCRATCH_WORDS + 2 * N + BMI_AT_WORDS;
-static_assert(LAT_LDS_WORDS <= BMI_LDS_WORDS_MAX, "LAT_LDS_WORDS exceeds the 160 KB of LDS");
-
-__global__ void __launch_bounds__(LAT_THREADS)
-    k_blind_rotate_lat49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
-                         const double *__restrict__ luts, const double *__restrict__ bsk, const double *__restrict__ g_tw,
-                         u64 *__restrict__ out, uint32_t count, uint32_t n) {
-    extern __shared__ double lds[];
-    double *acc = lds + TW_WORDS;          // [2][N], natural coefficient order, centred (<= p/2)
-    double *tiles = acc + 2 * N;           // [6][SCRATCH_WORDS]
-    double *Y = tiles + 6 * SCRATCH_WORDS; // [2][N], evaluation layout
-    uint16_t *at = reinterpret_cast<uint16_t *>(Y + 2 * N);
-    stage_twiddles(lds, g_tw);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t ct = blockIdx.x;
-    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
-    for (uint32_t i = tid; i <= n; i += LAT_THREADS) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 1);
-    __syncthreads();
-    {
-        const double *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
-        const uint32_t bt = at[n];
-        for (int m = tid; m < N; m += LAT_THREADS) {
-            const uint32_t e = (m + bt) & (2 * N - 1);
-            const double v = tv[e & (N - 1)];
-            acc[m] = 0.0;
-            acc[N + m] = (e & N) ? -v : v;
-        }
-    }
-    __syncthreads();
-
-    PH_DECL();
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t a_t = at[i];
-        if (a_t == 0) continue;  // uniform over the workgroup
-        const double *bsk_i = bsk + (size_t)i * 12 * N;
-        PH_MARK(7);
-        double b[4][6];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int slot = tid + LAT_THREADS * m, oc = slot >> LOG_N, idx = slot & (N - 1);
-#pragma unroll
-            for (int r = 0; r < 6; r++) b[m][r] = bsk_i[(size_t)(r * 2 + oc) * N + idx];
-        }
-        if (wave < 6) {
-            const int c = wave / 3, lev = wave - 3 * c;
-            const double *a = acc + c * N;
-            double x[16];
-            static_for<0, 16>([&](auto J) {
-                const uint32_t mm = lane + 64 * J;
-                const uint32_t e = (mm + 2 * N - a_t) & (2 * N - 1);
-                double v = a[e & (N - 1)];
-                v = (e & N) ? -v : v;
-                x[J] = digit_of(round_half_up(f49::red(v - a[mm]), 0x1p-4), lev);
-            });
-            double *tile = tiles + wave * SCRATCH_WORDS;
-            forward(x, lane, lds, tile);
-            wave_sync();
-            static_for<0, 16>([&](auto V) { tile[eval_offset(lane, V)] = x[V]; });
-        }
-        PH_MARK(0);
-        __syncthreads();
-        PH_MARK(1);
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int slot = tid + LAT_THREADS * m, idx = slot & (N - 1);
-            double y = 0.0;  // lazy sum of six products (<= 7.8p), one reduction
-#pragma unroll
-            for (int r = 0; r < 6; r++) y += f49::mul(tiles[r * SCRATCH_WORDS + idx], b[m][r]);
-            Y[slot] = f49::red(y);
-        }
-        PH_MARK(2);
-        __syncthreads();
-        PH_MARK(3);
-        if (wave < 2) {
-            double x[16];
-            static_for<0, 16>([&](auto V) { x[V] = Y[wave * N + eval_offset(lane, V)]; });
-            double *tile = tiles + wave * SCRATCH_WORDS;
-            inverse(x, lane, lds, tile);
-            double *a = acc + wave * N;
-            static_for<0, 16>([&](auto J) { a[lane + 64 * J] = f49::red(a[lane + 64 * J] + x[J]); });
-        }
-        PH_MARK(4);
-        __syncthreads();
-        PH_MARK(5);
-    }
-#ifdef BMI_PHASE_PROF
-    if (blockIdx.x == 0 && lane == 0)
-        for (int k_ = 0; k_ < 8; k_++) g_phase[wave * 8 + k_] = ph_[k_];
-#endif
-    u64 *o = out + (size_t)ct * (N + 1);
-    for (int m = tid; m < N; m += LAT_THREADS) {
-        if (m == 0) {
-            o[0] = f49::to_u(acc[0]);
-            o[N] = f49::to_u(acc[N]);
-        } else {
-            o[N - m] = f49::to_u(-acc[m]);
-        }
-    }
-}
 
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1372,6 +1176,7 @@ int launch_negacyclic_mul(const u64 *a, const u64 *b, u64 *c, const double *g_tw
     return 0;
 }
 
+#ifdef BMI_AB_KERNELS
 int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
                            const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
     if (count == 0) return 0;
@@ -1381,6 +1186,12 @@ int launch_blind_rotate_tp(const u64 *small_cts, const uint32_t *lut_ids, const 
     BMI49_LAUNCH_CHECK();
     return 0;
 }
+#else
+// variants 1 and 4 are A/B kernels (make ab): not in the product build
+int launch_blind_rotate_tp(const u64 *, const uint32_t *, const double *, const double *, const double *, u64 *, uint32_t, uint32_t, hipStream_t) {
+    return (int)hipErrorNotSupported;
+}
+#endif
 
 
 // (levels, base log) pairs the templated kernels are instantiated for
@@ -1533,6 +1344,7 @@ int launch_blind_rotate_lat2(const u64 *small_cts, const uint32_t *lut_ids, cons
     return f ? f(small_cts, lut_ids, luts, bsk_lat, g_tw_h, out, count, n, s) : (int)hipErrorInvalidValue;
 }
 
+#ifdef BMI_AB_KERNELS
 int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const double *luts, const double *bsk,
                             const double *g_tw, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
     if (count == 0) return 0;
@@ -1544,6 +1356,11 @@ int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const
     BMI49_LAUNCH_CHECK();
     return 0;
 }
+#else
+int launch_blind_rotate_lat(const u64 *, const uint32_t *, const double *, const double *, const double *, u64 *, uint32_t, uint32_t, hipStream_t) {
+    return (int)hipErrorNotSupported;
+}
+#endif
 
 int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
                      uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,

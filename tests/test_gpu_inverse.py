@@ -96,8 +96,8 @@ def test_encrypted_inverse_modes_match_reference_golden(eng, tag):
     """The reference's other modes on ciphertexts: true_division=True (QFloat / QFloat through the long
     division instead of invert-and-multiply, qfloat.py:1183-1234) and tensorize=True (the multi_* twins)."""
     from bmi_amd.main import EncryptedMatrixInversion
-    if eng.q_bits != 49 and tag != "uniform_2x2_tensorize":
-        pytest.skip("the 3x3 mode cases run once, on the faster field")
+    if eng.q_bits == 64 and tag != "uniform_2x2_tensorize":
+        pytest.skip("the 3x3 mode cases run on the 49-bit field and on the 2^64 torus (the Goldilocks kernels are 4x slower)")
     c = next(x for x in load("inverse.json") if x["tag"] == tag)
     emi = EncryptedMatrixInversion(c["n"], None, 2, c["len"], c["ints"], c["true_division"], c["tensorize"], engine=eng)
     M = np.array(c["M"]).reshape(c["n"], c["n"])
@@ -127,8 +127,8 @@ def test_encrypted_3x3_inverse_matches_reference_golden(eng):
 
 
 def test_encrypted_4x4_inverse_matches_reference_golden(eng):
-    if eng.q_bits != 49:
-        pytest.skip("config 4 is run once, on the fastest field (the 64-bit moduli cover configs 2 and 3)")
+    if eng.q_bits == 64:
+        pytest.skip("config 4 runs on the 49-bit field and on the 2^64 torus (Goldilocks covers configs 2 and 3)")
     """BASELINE config 4 (4x4, len 40, ints 16) on ONE MI355X: 323 k PBS, depth 1,858.  (BASELINE shards this
     config's PBS over 8 GPUs; the inverse's levels are narrower than one GPU's latency-kernel capacity, so a
     single GPU is the faster placement - DESIGN.md §6.)"""
@@ -168,8 +168,9 @@ def test_encrypted_8x8_inverse_matches_reference_golden(eng):
     """BASELINE config 5 (8x8, len 48, ints 16) on ONE MI355X, every look-up on ciphertexts: 2.58 M PBS over 2,886
     levels; decrypted digits and signs == the reference's plaintext output (tests/golden/inverse.json,
     qfloat_matrix_inversion.py:672-720).  The ciphertext store holds the live set only (recycled rows)."""
-    if eng.q_bits != 49:
-        pytest.skip("config 5 is run once, on the fastest field")
+    if eng.q_bits == 64 or (eng.q_bits == 65 and os.environ.get("BMI_TEST_TORUS_8X8") != "1"):
+        pytest.skip("config 5 runs on the 49-bit field; on the 2^64 torus with BMI_TEST_TORUS_8X8=1 (tools/gpu_torus_8x8.sh, "
+                    "recorded in profiles/) - it is bound by throughput, 40 s there")
     import time
     from bmi_amd.main import EncryptedMatrixInversion
     c = next(x for x in load("inverse.json") if x["tag"] == "baseline_n8_len48_ints16")
@@ -185,9 +186,14 @@ def test_encrypted_8x8_inverse_matches_reference_golden(eng):
     res = emi.evaluate(enc)
     wall = time.time() - t0
     out = emi.decrypt(res)
+    # 2.1 M look-ups, most of them full 4-bit ones at the 6.2 sigma the north star's (n 630, N 1024) leave: a wrong digit is
+    # expected about once per ~1,000 runs of this test - rerun before suspecting the kernels
+    margin_note = ("8x8 digits differ: with 2.1 M look-ups at a 6.2 sigma decision margin (north-star parameters n 630, N 1024, 4-bit "
+                   "messages) about 1 run in 1,000 fails by noise alone; rerun once before suspecting the kernels")
     print(f"encrypted 8x8 (len 48, ints 16): {wall:.1f} s, store {ex.store_bytes() / 1e9:.2f} GB, "
           f"compile {emi.compile_info}, {emi.circuit.summary()}")
-    assert out.shape == (64, 49) and out.tolist() == c["out"]
+    assert out.shape == (64, 49)
+    assert out.tolist() == c["out"], margin_note
     assert emi.dequantize(out).flatten().tolist() == c["float"]
 
 
@@ -196,8 +202,8 @@ def test_encrypted_inverse_with_a_non_binary_leading_digit(eng, tag):
     """An entry beyond 2^ints keeps a leading digit of 2 or 3 (from_float does not reduce it, base_p_arrays.py:42-46;
     SURVEY section 8d asks for such a matrix on ciphertexts): digits and signs == the reference's."""
     from bmi_amd.main import EncryptedMatrixInversion
-    if eng.q_bits != 49 and "3x3" in tag:
-        pytest.skip("the 3x3 case runs once, on the faster field")
+    if eng.q_bits == 64 and "3x3" in tag:
+        pytest.skip("the 3x3 case runs on the 49-bit field and on the 2^64 torus")
     c = next(x for x in load("inverse.json") if x["tag"] == tag)
     assert max(row[0] for row in c["in_arrays"]) >= 2
     emi = EncryptedMatrixInversion(c["n"], None, 2, c["len"], c["ints"], False, False, engine=eng)

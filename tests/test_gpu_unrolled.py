@@ -252,7 +252,9 @@ def test_encrypted_inverse_with_the_unrolled_key_matches_reference_golden(tag, c
         res = emi.evaluate(enc)
         wall = time.time() - t0
         out = emi.decrypt(res)
-        assert out.tolist() == c["out"]
+        assert out.tolist() == c["out"], ("digits differ" + ("; the 8x8 runs 2.1 M look-ups at the 6.2 sigma decision margin the north star's (n 630, "
+                                          "N 1024, 4-bit messages) leave: about 1 run in 1,000 fails by noise alone - rerun once before "
+                                          "suspecting the kernels" if c["n"] == 8 else ""))
         with capsys.disabled():
             print(f"\nunrolled key, {tag}: evaluate {wall:.2f} s, {emi.circuit.summary()['depth']} levels, {wall / emi.circuit.summary()['depth'] * 1e3:.2f} ms per level")
     finally:

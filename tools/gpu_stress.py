@@ -23,7 +23,7 @@ def main():
     if unroll == 2:
         octx.set_bsk_unrolled(eng.export_bsk_unrolled())
     lb3 = (eng.P.bs_levels, eng.P.bs_base_log) == (3, 15)
-    all_variants = (0, 1, 2, 3, 4) if (lb3 or qb == 65) else (0, 2, 3)     # variants 1 / 4 of the 49-bit field exist for (3, 2^15) only
+    all_variants = (0, 1, 2, 3, 4) if qb != 49 else (0, 2, 3)     # variants 1 / 4 of the 49-bit field are A/B builds (make ab)
     rng = np.random.default_rng(2024)
     table = rng.integers(-8, 8, 16)
     lid = eng.lut_register(table, 4, dl)
