@@ -204,209 +204,12 @@ __global__ void __launch_bounds__(L2_THREADS)
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// The same kernel with its three workgroup barriers per step replaced by LDS counters, so that the phases of a step overlap
-// where the data allows it (round 3; the phase profile of the barrier form, profiles/r02_phase_profile_lat2u.txt, shows the
-// sixteen wavefronts of a SIMD finishing the multiply phase oldest first: wavefronts 0-7 - output polynomial 0 - are done
-// after 55 % of it and then wait 2.2 k cycles, twelve wavefronts idle through the single-wave inverse halves, four through
-// the forward phase):
-//   * the inverse halves of OUTPUT 0 (wavefronts 0, 1) start as soon as the eight wavefronts that multiply for output 0 have
-//     written their sums (counter M[0]), under the multiplications still running for output 1;
-//   * those of OUTPUT 1 run on wavefronts 14, 15 (no forward task, last to finish multiplying - exactly when M[1] completes);
-//   * the forward tasks of COMPONENT c of the NEXT step (wavefronts 6c .. 6c+5) start when the two inverse halves of output c
-//     have updated the accumulator (counter I[c]) and every wavefront has copied its digit transforms out of the tiles
-//     (counter R): component 0's six tasks run under the inverse halves of output 1;
-//   * the multiplications of a step start when all twelve forward tasks have stored their tiles (counter T).
-// Counters only grow (a step adds 12 / 16 / 8 / 2 to them), a waiting wavefront polls with s_sleep, every wavefront walks
-// the same step sequence (the skip of an all-zero pair is uniform), so every wait is eventually met.  The inverse halves have
-// tiles of their own (they run beside forward tasks now).
 #ifndef BMI_LAT2U_PIPE
-#define BMI_LAT2U_PIPE 1
+#define BMI_LAT2U_PIPE 0   // 1: the flag-synchronised form of the kernel above (an experiment that measured slower: ab/bmi_kernels_f64u_pipe.inc)
 #endif
-constexpr int L2UP_LDS_WORDS = L2U_LDS_WORDS + 4 * ntth::HSCRATCH + 8;
-static_assert(L2UP_LDS_WORDS <= BMI_LDS_WORDS_MAX, "L2UP_LDS_WORDS exceeds the 160 KB of LDS");
-
-// every lane calls it after the LDS writes the counter stands for; lane 0 adds
-__device__ __forceinline__ void flag_add(uint32_t *p, int lane) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");
-}
-// waits until *p >= v (one opaque asm block: as C++ control flow the poll loop makes the register allocator spill)
-__device__ __forceinline__ void flag_wait_ge(uint32_t *p, uint32_t v) {
-    const uint32_t addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)p;
-    uint32_t tmp;
-    asm volatile(
-        "1:\n\t"
-        "ds_read_b32 %0, %1\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_le_u32 vcc, %2, %0\n\t"
-        "s_cbranch_vccnz 2f\n\t"
-        "s_sleep 1\n\t"
-        "s_branch 1b\n"
-        "2:"
-        : "=&v"(tmp)
-        : "v"(addr), "s"(v)
-        : "vcc", "memory");
-}
-
-template <int L = 3, int BG = 15>
-__global__ void __launch_bounds__(L2_THREADS)
-    k_blind_rotate_lat2up_49(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids,
-                             const double *__restrict__ luts, const double *__restrict__ bsk3_lat,
-                             const double *__restrict__ g_tw_h, const double *__restrict__ g_root_pow,
-                             u64 *__restrict__ out, uint32_t count, uint32_t n) {
-    static_assert(4 * L <= 12, "forward tasks on wavefronts 0 .. 4L-1, inverse halves of output 1 on 14, 15");
-    extern __shared__ double lds[];
-    double *acc = lds + ntth::HT_WORDS;              // [2 components][2 parities][512], centred (<= q/2 + 2)
-    double *tiles = acc + 2 * N;                     // [12][HSCRATCH]
-    double *SD = tiles + 12 * ntth::HSCRATCH;        // [2 outputs][sum, difference][512]
-    uint16_t *at = reinterpret_cast<uint16_t *>(SD + 2 * N);
-    double *RP = SD + 2 * N + BMI_AT_WORDS;          // psi^x, x in [0, 2N)
-    double *itiles = RP + 2 * N;                     // [4][HSCRATCH]: scratch of the inverse halves
-    uint32_t *flags = reinterpret_cast<uint32_t *>(itiles + 4 * ntth::HSCRATCH);   // T, R, M[0], M[1], I[0], I[1]
-    uint32_t *fT = flags, *fR = flags + 1, *fM = flags + 2, *fI = flags + 4;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < 8) flags[tid] = 0;
-    for (int i = tid; i < ntth::HT_WORDS; i += L2_THREADS) lds[i] = g_tw_h[i];
-    for (int i = tid; i < 2 * N; i += L2_THREADS) RP[i ^ ((i >> 5) & 31)] = g_root_pow[i];
-    const uint32_t ct = blockIdx.x;
-    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
-    for (uint32_t i = tid; i <= n; i += L2_THREADS) at[i] = (uint16_t)f49::modswitch(lwe[i], LOG_N + 1);
-    __syncthreads();
-    {
-        const double *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
-        const uint32_t bt = at[n];
-        const uint32_t nn = tid;  // coefficient index
-        const uint32_t e = (nn + bt) & (2 * N - 1);
-        const double v = tv[e & (N - 1)];
-        acc[(nn & 1) * ntth::HALF + (nn >> 1)] = 0.0;
-        acc[N + (nn & 1) * ntth::HALF + (nn >> 1)] = (e & N) ? -v : v;
-    }
-    __syncthreads();
-    const int mo = tid >> 9, mp = tid & 511;  // multiplications: output polynomial, slot
-    const uint32_t root_e = 2 * ntth::kk_of(mp & 63, mp >> 6) + 1;
-    const uint32_t pairs = (n + 1) >> 1;
-    auto load_key = [&](double (&dst)[2 * L][2], uint32_t ip, int key) {
-        const double *bj = bsk3_lat + ((size_t)ip * 3 + key) * 4 * L * N;
-#pragma unroll
-        for (int r = 0; r < 2 * L; r++) {
-            const double2 w = reinterpret_cast<const double2 *>(bj + (size_t)(r * 2 + mo) * N)[mp];
-            dst[r][0] = w.x;
-            dst[r][1] = w.y;
-        }
-    };
-    double b[2 * L][2];
-    // inverse halves: output 0 on wavefronts 0, 1; output 1 on wavefronts 14, 15
-    const int inv_o = wave < 2 ? 0 : (wave >= 14 ? 1 : -1), inv_h = wave & 1;
-
-    uint32_t st = 0;   // executed steps so far (uniform over the workgroup)
-    for (uint32_t ip = 0; ip < pairs; ip++) {
-        const uint32_t a1 = at[2 * ip], a2 = (2 * ip + 1 < n) ? at[2 * ip + 1] : 0u;
-        if ((a1 | a2) == 0) continue;  // uniform over the workgroup: every factor X^0 - 1 vanishes
-        const uint32_t cj[3] = {(a1 + a2) & (2 * N - 1), a1, a2};
-        load_key(b, ip, 0);
-        if (wave < 4 * L) {
-            const int c = wave / (2 * L), lev = (wave % (2 * L)) >> 1, h = wave & 1;
-            const int pz = wave >> 1;
-            const double *ac = acc + c * N + h * ntth::HALF;
-            // the accumulator of this component is final (both inverse halves of the last step) and the tiles are free (every
-            // wavefront has copied its digit transforms of the last step out of them)
-            flag_wait_ge(fI + c, 2 * st);
-            flag_wait_ge(fR, 16 * st);
-            double x[8];
-#if BMI_LAT2_PRIO
-            if (c) __builtin_amdgcn_s_setprio(3);
-            else __builtin_amdgcn_s_setprio(1);
+#if BMI_LAT2U_PIPE
+#include "ab/bmi_kernels_f64u_pipe.inc"
 #endif
-            static_for<0, 8>([&](auto J) {
-                x[J] = Dec<L, BG>::digit(round_half_up(ac[lane + 64 * J], Dec<L, BG>::SC), lev);
-            });
-            double *tile = tiles + (2 * pz + h) * ntth::HSCRATCH;
-            if (h) ntth::forward_half<true>(x, lane, lds, tile);
-            else ntth::forward_half<false>(x, lane, lds, tile);
-            wave_sync();
-            static_for<0, 8>([&](auto R) { tile[R * 64 + lane] = x[R]; });
-#if BMI_LAT2_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            flag_add(fT, lane);
-        }
-        flag_wait_ge(fT, 12 * (st + 1));
-        {
-            double alo[2 * L], ahi[2 * L];
-#pragma unroll
-            for (int r = 0; r < 2 * L; r++) {
-                const double e = tiles[(2 * r) * ntth::HSCRATCH + mp], od = tiles[(2 * r + 1) * ntth::HSCRATCH + mp];
-                alo[r] = e + od;
-                ahi[r] = e - od;
-            }
-            flag_add(fR, lane);        // (the waitcnt inside also lands the tile reads above)
-#if BMI_LAT2_PRIO
-            if (mo) __builtin_amdgcn_s_setprio(2);
-            else __builtin_amdgcn_s_setprio(1);
-#endif
-            double slo = 0.0, shi = 0.0;   // sums of three reduced products (<= 1.6 q)
-            auto one_key = [&](const double (&kw)[2 * L][2], uint32_t c) {
-                double ylo = 0.0, yhi = 0.0;  // lazy sums of 2 L <= six reduced products (<= 3.1 q)
-#pragma unroll
-                for (int r = 0; r < 2 * L; r++) {
-                    ylo += f49::mul(alo[r], kw[r][0]);
-                    yhi += f49::mul(ahi[r], kw[r][1]);
-                }
-                const uint32_t xe = (root_e * c) & (2 * N - 1);
-                const double w = RP[xe ^ ((xe >> 5) & 31)];
-                const double wh = (c & 1) ? -w : w;
-                slo += f49::mul(ylo, w - 1.0);
-                shi += f49::mul(yhi, wh - 1.0);
-            };
-            double bn[2 * L][2];
-            load_key(bn, ip, 1);
-            one_key(b, cj[0]);
-            load_key(b, ip, 2);
-            one_key(bn, cj[1]);
-            one_key(b, cj[2]);
-            slo = f49::red(slo);
-            shi = f49::red(shi);
-            SD[(mo * 2 + 0) * ntth::HALF + mp] = slo + shi;
-            SD[(mo * 2 + 1) * ntth::HALF + mp] = slo - shi;
-#if BMI_LAT2_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            flag_add(fM + mo, lane);
-        }
-        if (inv_o >= 0) {
-            flag_wait_ge(fM + inv_o, 8 * (st + 1));
-#if BMI_LAT2_PRIO
-            if (inv_o) __builtin_amdgcn_s_setprio(3);
-#endif
-            double x[8];
-            static_for<0, 8>([&](auto R) { x[R] = SD[(inv_o * 2 + inv_h) * ntth::HALF + R * 64 + lane]; });
-            double *tile = itiles + (inv_o * 2 + inv_h) * ntth::HSCRATCH;
-            if (inv_h) ntth::inverse_half<true>(x, lane, lds, tile);
-            else ntth::inverse_half<false>(x, lane, lds, tile);
-            double *ao = acc + inv_o * N + inv_h * ntth::HALF;
-            static_for<0, 8>([&](auto J) { ao[lane + 64 * J] = f49::red(ao[lane + 64 * J] + x[J]); });
-#if BMI_LAT2_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            flag_add(fI + inv_o, lane);
-        }
-        st++;
-    }
-    __syncthreads();   // every inverse half of the last step has updated the accumulator
-    u64 *o = out + (size_t)ct * (N + 1);
-    {
-        const uint32_t nn = tid;
-        const double a0 = acc[(nn & 1) * ntth::HALF + (nn >> 1)];
-        if (nn == 0) {
-            o[0] = f49::to_u(a0);
-            o[N] = f49::to_u(acc[N]);
-        } else {
-            o[N - nn] = f49::to_u(-a0);
-        }
-    }
-}
 
 }  // namespace
 

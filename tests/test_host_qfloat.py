@@ -675,6 +675,35 @@ def test_program_cache_round_trip(tmp_path, monkeypatch):
     assert not i4["cached"] and np.array_equal(p4.term_leaf, p1.term_leaf)
 
 
+def test_shipped_programs_are_current_and_round_trip(tmp_path, monkeypatch):
+    """bmi_amd/programs/ carries the compiled programs of the configurations whose trace takes minutes (8 x 8, 10 x 10) in the
+    compact form (index arrays as differences + LZMA).  Their file names carry the tracer fingerprint: a change to the tracer's
+    sources makes them stale, and this test says so (regenerate with tools/ship_programs.py).  The compact form is lossless."""
+    import hashlib
+    from bmi_amd import program as pg
+    from bmi_amd.main import message_bits_for
+    for n, ln, ints in ((8, 48, 16), (10, 23, 9)):
+        key = dict(kind="inverse", n=n, len=ln, ints=ints, base=2, truediv=False, tensorize=False, divbits=0, msg=message_bits_for(2))
+        h = hashlib.sha256(repr((pg.FORMAT, pg._tracer_fingerprint(), sorted(key.items()))).encode()).hexdigest()[:24]
+        name = "_".join(f"{k}{v}" for k, v in sorted(key.items()) if not isinstance(v, bool) or v)
+        path = os.path.join(pg.shipped_dir(), f"{name}_{h}.prog.xz")
+        assert os.path.exists(path), f"shipped program for {n}x{n} is stale or missing: run tools/ship_programs.py ({os.path.basename(path)})"
+    # an empty cache directory: the configuration is served from the shipped file, not traced
+    monkeypatch.setenv("BMI_CACHE_DIR", str(tmp_path))
+    from bmi_amd.main import compile_inverse
+    prog, info = compile_inverse(10, 23, 9)
+    assert info["cached"] and info.get("shipped") and prog.n_nodes > 1_000_000
+    c = next(x for x in load("inverse.json") if x["tag"] == "main_n10_len23_ints9")
+    q, sg = qmi.float_matrix_to_qfloat_arrays(np.array(c["M"]).reshape(10, 10), 23, 9, 2)
+    out = np.array(prog.simulate(np.concatenate([np.asarray(q).reshape(-1), np.asarray(sg)]))).reshape(100, 24)
+    assert out.tolist() == c["out"]
+    # round trip of the compact form on a small program
+    small, _ = _small_program_and_circuit()
+    small.save_compact(str(tmp_path / "s.prog.xz"))
+    back = pg.Program.load_compact(str(tmp_path / "s.prog.xz"))
+    assert all(np.array_equal(getattr(back, k), getattr(small, k)) for k in pg.Program.ARRAYS) and back.meta == small.meta
+
+
 def test_store_rows_are_recycled_only_after_the_last_consumer():
     from bmi_amd.executor import assign_rows
     prog, _ = _small_program_and_circuit()

@@ -8,6 +8,7 @@ from bmi_amd import tfhe
 tfhe.LIB_PATH = tfhe.LIB_PATH.replace("libbmi_tfhe.so", "libbmi_tfhe_prof.so")
 
 NAMES = ["rotate+decompose", "forward NTT x3", "publish+key loads+barrier", "MAC x3", "barrier 2", "inverse+update", "-", "loop head"]
+PIPE_NAMES = ["wait accumulator + tiles free", "forward task", "wait all transforms", "multiply", "wait sums of my output", "inverse half", "-", "loop head + key request"]
 LAT_NAMES = ["key loads issue + decompose + forward (waves 0-5)", "barrier 1 wait", "MAC", "barrier 2 wait", "inverse + update (waves 0-1)", "barrier 3 wait", "-", "loop head"]
 
 def main():
@@ -40,6 +41,6 @@ def main():
     for w in range(8 if log_N > 10 else {1: 4, 2: 16, 3: 4, 4: 8}[variant]):
         tot = a[w].sum()
         print(json.dumps({"wave": w, "total_cycles": tot, "per_cmux": round(tot / eng.P.n, 1),
-                          "phases_cycles_per_cmux": {n: round(v / eng.P.n, 0) for n, v in zip(WIDE_NAMES if log_N > 10 else (LAT_NAMES if variant in (2, 4) else NAMES), a[w]) if n != "-"}}))
+                          "phases_cycles_per_cmux": {n: round(v / eng.P.n, 0) for n, v in zip(WIDE_NAMES if log_N > 10 else (PIPE_NAMES if (unroll == 2 and q_bits == 49 and os.environ.get('BMI_PIPE_NAMES', '1') == '1') else LAT_NAMES if variant in (2, 4) else NAMES), a[w]) if n != "-"}}))
 
 main()
