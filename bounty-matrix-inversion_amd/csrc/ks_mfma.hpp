@@ -9,7 +9,7 @@
 //     k_ks_digits      decomposes the big ciphertexts' mask coefficients into the int8 matrix D   (per call)
 //     k_ksk_to_limbs   lays the key out limb-wise in MFMA operand order                            (per keygen)
 //     k_ks_mfma        one wavefront = 32 ciphertexts x 32 output columns x all L limbs; operands straight from
-//                      global memory (coalesced 1 KiB fragments, register double buffer), optional split over K
+//                      global memory (coalesced 1 KiB fragments, a ring of KS_PF k-steps in flight), optional split over K
 //     k_ks_combine     sums the K-slices, recombines the limbs in 128-bit, reduces mod q, subtracts from (0, b)
 // Against the scalar kernel of ks_lincomb.hpp (8 ciphertexts x 631 columns per workgroup, 96-bit v_mad chains)
 // this moves the 5.2 M multiply-accumulates per ciphertext from half-rate 64-bit VALU work to the matrix cores.
@@ -32,6 +32,10 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int TILE = 32;     // ciphertexts per wavefront tile, and output columns per column block
 constexpr int KSTEP = 32;    // k consumed per MFMA
 constexpr int WAVES = 4;     // wavefronts (ciphertext tiles) per workgroup
+#ifndef BMI_KS_PF
+#define BMI_KS_PF_WIDE 3
+#define BMI_KS_PF 4   // measured at 8,192 ciphertexts, 7 limbs (keyswitch total, three kernels): 1.13 ms with the round-2 double buffer, 0.72 / 0.70 / 0.65 ms at depth 1 / 2 / 4 of this ring
+#endif
 
 // ---- digits: one thread per mask coefficient; requires levels <= 8 (one 8-byte store when levels == 8)
 template <class F>
@@ -79,6 +83,11 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---- the product.  grid = (ceil(tiles / WAVES), column blocks, slices); S[slice][ct][limb][cbs * 32] (int32)
+// k-steps of operands in flight per wavefront (7 limbs: the 49-bit field; 9 limbs: the 64-bit moduli, whose 144 accumulator
+// registers leave room for fewer stages at two wavefronts per SIMD)
+template <int L>
+constexpr int ks_pf() { return L <= 7 ? BMI_KS_PF : BMI_KS_PF_WIDE; }
+
 template <int L>
 __global__ void __launch_bounds__(64 * WAVES)
     k_ks_mfma(const signed char *__restrict__ D, const signed char *__restrict__ Bm, int *__restrict__ S, uint32_t count,
@@ -102,27 +111,37 @@ __global__ void __launch_bounds__(64 * WAVES)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[l][i] = 0;
 
-    v4i a_cur = {0, 0, 0, 0}, b_cur[L];
+    // Operands come straight from global memory (L2-resident key, streamed digits): a ring of KS_PF k-steps is kept in flight
+    // per wavefront.  With one step ahead (round 2) the kernel ran at the latency of an L2 access per k-step: 0.96 ms for 8,192
+    // ciphertexts against 0.12 ms of matrix-core time.
+    constexpr int KS_PF = ks_pf<L>();
+    v4i a_buf[KS_PF], b_buf[KS_PF][L];
 #pragma unroll
-    for (int l = 0; l < L; l++) b_cur[l] = v4i{0, 0, 0, 0};
-    if (ks0 < ks1) {  // an empty K-slice (slices not dividing the k-steps) touches no memory and writes zeros
-        a_cur = ap[0];
+    for (int s = 0; s < KS_PF; s++) {
+        a_buf[s] = v4i{0, 0, 0, 0};
 #pragma unroll
-        for (int l = 0; l < L; l++) b_cur[l] = bp[l * 64];
+        for (int l = 0; l < L; l++) b_buf[s][l] = v4i{0, 0, 0, 0};
+        if (ks0 + s < ks1) {  // an empty K-slice (slices not dividing the k-steps) touches no memory and writes zeros
+            a_buf[s] = ap[2 * s];
+#pragma unroll
+            for (int l = 0; l < L; l++) b_buf[s][l] = bp[s * BSTEP + l * 64];
+        }
     }
-    for (uint32_t ks = ks0; ks < ks1; ks++) {
-        v4i a_nxt = a_cur, b_nxt[L];
-        const bool more = ks + 1 < ks1;
-        ap += 2;
-        bp += BSTEP;
-        if (more) a_nxt = ap[0];
+    for (uint32_t ks = ks0; ks < ks1; ks += KS_PF) {
 #pragma unroll
-        for (int l = 0; l < L; l++) b_nxt[l] = more ? bp[l * 64] : b_cur[l];
+        for (int s = 0; s < KS_PF; s++) {
+            if (ks + s < ks1) {   // uniform over the wavefront
 #pragma unroll
-        for (int l = 0; l < L; l++) acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur, b_cur[l], acc[l], 0, 0, 0);
-        a_cur = a_nxt;
+                for (int l = 0; l < L; l++) acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_buf[s], b_buf[s][l], acc[l], 0, 0, 0);
+                if (ks + s + KS_PF < ks1) {   // refill this stage with the step KS_PF ahead
+                    a_buf[s] = ap[2 * (s + KS_PF)];
 #pragma unroll
-        for (int l = 0; l < L; l++) b_cur[l] = b_nxt[l];
+                    for (int l = 0; l < L; l++) b_buf[s][l] = bp[(s + KS_PF) * BSTEP + l * 64];
+                }
+            }
+        }
+        ap += 2 * KS_PF;
+        bp += (size_t)BSTEP * KS_PF;
     }
 
     const uint32_t cw = cbs * TILE;
