@@ -168,6 +168,12 @@ def test_blind_rotate_every_kernel_variant(eng, ora, variant):
     small = ctx.keyswitch(eng.encrypt(msgs, eng.delta_log()))
     small = np.concatenate([small, rand_q(rng, (1, 631), eng.modulus)])
     sel = np.array([0, 1, 0, 1, 0, 1, 1], np.uint32)
+    if eng.q_bits == 49 and variant in (1, 4):
+        # the predecessors of the 49-bit kernels are A/B builds (make -C csrc ab), not in the product library: refused, not run
+        from bmi_amd import tfhe
+        with pytest.raises(tfhe.BmiError):
+            eng.set_kernel_variant(variant)
+        return
     eng.set_kernel_variant(variant)
     try:
         got = eng.blind_rotate_host(small, np.array(ids, np.uint32)[sel])

@@ -2,7 +2,7 @@
 """Many random matrices through the encrypted inverse on the GPU, each compared with the plaintext evaluation of the same
 compiled program (identical integers expected) and with numpy's inverse: an empirical look at the look-up failure rate
 (every 4-bit look-up sits at >= 5.6 sigma).  usage: gpu_random_inverses.py [n] [count] [q_bits] [unroll]
-(unroll = 2: the unrolled bootstrap key at key noise 2^-41, what EncryptedMatrixInversion(unroll=True) runs)"""
+(unroll = 2: the unrolled bootstrap key - at key noise 2^-41 on the 49-bit field -, what EncryptedMatrixInversion(unroll=True) runs)"""
 import json, os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "bounty-matrix-inversion_amd"))
@@ -16,7 +16,7 @@ def main():
     qb = int(sys.argv[3]) if len(sys.argv) > 3 else 49
     ln, ints = {2: (20, 8), 3: (30, 12), 4: (40, 16)}[n]
     unroll = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-    eng = tfhe.Engine(tfhe.default_params(q_bits=qb, **({"glwe_noise": 2.0 ** -41} if unroll == 2 else {})))
+    eng = tfhe.Engine(tfhe.default_params(q_bits=qb, **({"glwe_noise": 2.0 ** -41} if (unroll == 2 and qb == 49) else {})))
     eng.set_bsk_unroll(unroll)
     eng.keygen()          # CSPRNG keys
     emi = EncryptedMatrixInversion(n, None, 2, ln, ints, False, False, engine=eng)
