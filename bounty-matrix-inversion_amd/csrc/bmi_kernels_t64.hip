@@ -39,6 +39,9 @@ namespace {
 #ifndef BMI_T64_RESYNC
 #define BMI_T64_RESYNC BMI_TPX49_RESYNC   // workgroup barrier every so many CMUXes (keeps the four pairs on the same key rows)
 #endif
+#ifndef BMI_T64_ACCF
+#define BMI_T64_ACCF 1    // wave-pair kernel, 48-bit key: accumulator as the exact integer word / 2^16 in a double (0: u64 words)
+#endif
 #ifndef BMI_T64_PRIO
 #define BMI_T64_PRIO 1    // 1 = issue priority steps down through the forward transforms (3, 2, 1), 0 in the limb loop; 0 = none
 #endif
@@ -108,6 +111,12 @@ __global__ void __launch_bounds__(128 * T64_CTS)
     static_assert(PRE + LIMBS * LB >= 64 && L * BG < 63, "limbs must cover the 64-bit word");
     extern __shared__ double lds[];
     double *tiles = lds + TW_WORDS;
+    // A key stored at fewer than 53 bits of precision (PRE >= 12) makes every accumulator word a multiple of 2^PRE: the
+    // accumulator is then kept as the exact integer word / 2^PRE, centred mod 2^AB (AB = 64 - PRE <= 52), in a DOUBLE - rotation,
+    // difference and limb accumulation are a handful of f64 instructions instead of half-rate 64-bit integer ones, and the result
+    // is the same word (the reduction mod 2^AB is the wrap of the u64 arithmetic).  The exact key (PRE = 0) keeps u64 words.
+    constexpr bool ACCF = BMI_T64_ACCF && PREC == 48;   // (the 42-bit option would spill registers in this form: it keeps u64 words)
+    constexpr int AB = ACCF ? 64 - PRE : 52;   // (unused without ACCF)
     u64 *accs = reinterpret_cast<u64 *>(tiles + 2 * CTS * SCRATCH_WORDS);
     double *at_base = reinterpret_cast<double *>(accs + 2 * CTS * N);
     uint32_t *flags = reinterpret_cast<uint32_t *>(at_base + CTS * T64_AT_WORDS);  // [2 CTS] published, [2 CTS] consumed
@@ -121,6 +130,11 @@ __global__ void __launch_bounds__(128 * T64_CTS)
     double *tile = tiles + wave * SCRATCH_WORDS;
     const double *ptile = tiles + (wave ^ 1) * SCRATCH_WORDS;
     u64 *accl = accs + wave * N;
+    double *accf = reinterpret_cast<double *>(accl);     // the same LDS words, read as doubles when ACCF
+    auto mod_ab = [](double t) {   // centred residue mod 2^AB of an exact integer |t| < 2^53
+        // (ties go to the negative end, like the two's complement reading of the u64 word: + 2^(AB-1) is - 2^(AB-1))
+        return __builtin_fma(-(double)(1ull << AB), __builtin_floor(__builtin_fma(t, 1.0 / (double)(1ull << AB), 0.5)), t);
+    };
     uint16_t *at = reinterpret_cast<uint16_t *>(at_base + ctl * T64_AT_WORDS);
     uint32_t *f_pub = flags + wave, *f_pub_partner = flags + (wave ^ 1);
     uint32_t *f_ack = flags + 2 * CTS + wave, *f_ack_partner = flags + 2 * CTS + (wave ^ 1);
@@ -133,7 +147,9 @@ __global__ void __launch_bounds__(128 * T64_CTS)
         static_for<0, 16>([&](auto J) {
             const uint32_t e = (lane + 64 * J + bt) & (2 * N - 1);
             const u64 v = tv[e & (N - 1)];
-            accl[lane + 64 * J] = c ? ((e & N) ? (u64)0 - v : v) : (u64)0;
+            const u64 w0 = c ? ((e & N) ? (u64)0 - v : v) : (u64)0;
+            if constexpr (ACCF) accf[lane + 64 * J] = (double)((i64)w0 >> PRE);     // test polynomials are multiples of 2^(59 or so)
+            else accl[lane + 64 * J] = w0;
         });
     }
 
@@ -150,7 +166,19 @@ __global__ void __launch_bounds__(128 * T64_CTS)
 #endif
         wave_sync();
         double r[16];
-        {
+        if constexpr (ACCF) {
+            double vr[16], vs[16];  // all 32 reads in flight before the first use
+            static_for<0, 16>([&](auto J) {
+                vr[J] = accf[(lane + 64 * J + 2 * N - a_t) & (N - 1)];
+                vs[J] = accf[lane + 64 * J];
+            });
+            sched_fence();
+            static_for<0, 16>([&](auto J) {
+                const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
+                const double d = mod_ab(((e & N) ? -vr[J] : vr[J]) - vs[J]);            // the centred lift of the u64 difference, / 2^PRE
+                r[J] = __builtin_floor(__builtin_fma(d, 1.0 / (double)(1ull << (AB - L * BG)), 0.5));   // round half up to L BG bits
+            });
+        } else {
             u64 vr[16], vs[16];  // all 32 reads in flight before the first use
             static_for<0, 16>([&](auto J) {
                 vr[J] = accl[(lane + 64 * J + 2 * N - a_t) & (N - 1)];
@@ -235,7 +263,19 @@ __global__ void __launch_bounds__(128 * T64_CTS)
             inverse(acc, lane, lds, tile);
             // the limb's exact integer result (|.| < 2^47.6 < p/2: the centred residue is the integer), shifted into place
             static_for<0, 16>([&](auto J) {
-                accl[lane + 64 * J] += f64_to_word(f49::red(acc[J])) << (PRE + LB * j);
+                if constexpr (ACCF) {
+                    // x 2^(LB j) mod 2^AB: only the low AB - LB j bits of the limb's integer survive the shift
+                    double x = f49::red(acc[J]);
+                    if constexpr (j > 0) {
+                        constexpr double W = (double)(1ull << (AB - LB * j));
+                        x = __builtin_fma(-W, __builtin_rint(x * (1.0 / W)), x);
+                        accf[lane + 64 * J] = mod_ab(__builtin_fma(x, (double)(1ull << (LB * j)), accf[lane + 64 * J]));
+                    } else {
+                        accf[lane + 64 * J] = mod_ab(accf[lane + 64 * J] + x);
+                    }
+                } else {
+                    accl[lane + 64 * J] += f64_to_word(f49::red(acc[J])) << (PRE + LB * j);
+                }
             });
             pin();
         });
@@ -247,12 +287,12 @@ __global__ void __launch_bounds__(128 * T64_CTS)
     if (c == 0) {
         static_for<0, 16>([&](auto J) {
             const uint32_t m = lane + 64 * J;
-            const u64 v = accl[m];
+            const u64 v = ACCF ? f64_to_word(accf[m]) << PRE : accl[m];
             if (m == 0) o[0] = v;
             else o[N - m] = (u64)0 - v;
         });
     } else if (lane == 0) {
-        o[N] = accl[0];
+        o[N] = ACCF ? f64_to_word(accf[0]) << PRE : accl[0];
     }
 }
 
