@@ -74,6 +74,27 @@ def test_wide_odd_lookups_on_gpu(eng):
         assert list(out) == circ.simulate([xv, yv]) == [sgn(xv), bpa._comb3(yv)], (xv, yv)
 
 
+def test_sign_to_bit_lookups_on_gpu(eng):
+    """Circuit.lut_neg on ciphertexts, all three moduli: [v < 0] for every v in [-15, 15] from the constant test polynomial at half
+    the output scale (the PBS returns (bit - 1/2) Delta; consumers' constants carry the other half), read directly, with a
+    coefficient, and as the input of a further look-up."""
+    from bmi_amd.circuit import Circuit
+    from bmi_amd.executor import Executor
+    circ = Circuit()
+    x = circ.input(-15, 15)
+    y = circ.input(0, 3)
+    bit = circ.lut_neg(x)
+    nxt = circ.lut2(bit, y, lambda b, v: v + 1 if b else 0)       # packed with another value: needs the bit at its exact scale
+    circ.set_outputs([bit, bit * 5 - 2 + y, nxt])
+    ex = Executor(circ, eng)
+    dl = eng.delta_log()
+    for xv in range(-15, 16):
+        yv = xv % 4
+        out = eng.decrypt(ex.run(eng.encrypt([xv, yv], dl)), dl)
+        b = int(xv < 0)
+        assert list(out) == circ.simulate([xv, yv]) == [b, 5 * b - 2 + yv, (yv + 1) if b else 0], xv
+
+
 @pytest.mark.parametrize("tag", ["survey_2x2", "baseline_n2_len20_ints8"])
 def test_encrypted_2x2_inverse_matches_reference_golden(eng, tag):
     from bmi_amd.main import EncryptedMatrixInversion

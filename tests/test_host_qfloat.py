@@ -430,6 +430,36 @@ def test_fused_addition_chain_scalars_and_depth():
         assert out == [int(x) for x in p.array] + [int(p.sign)] + [int(x) for x in pw.array] + [int(pw.sign)]
 
 
+def test_sign_to_bit_lookup_on_the_whole_torus():
+    """Circuit.lut_neg: [v < 0] for v in [-15, 15] as ONE look-up (the constant test polynomial at half the output scale; the
+    consumers' constants absorb Delta / 2 - program.half_unit_consts).  Every value, through Circuit.simulate, through the frozen
+    Program and through a serialisation round trip; narrow inputs fall back to ordinary look-ups; out-of-range inputs raise."""
+    from bmi_amd.program import Program
+    c = Circuit()
+    a = [c.input(0, 1) for _ in range(4)]
+    b = [c.input(0, 1) for _ in range(4)]
+    w = sum((a[i] - b[i]) * (1 << i) for i in range(4))          # a window of four digit differences: [-15, 15]
+    bit = c.lut_neg(w)
+    assert isinstance(bit, Lin) and (bit.lo, bit.hi) == (0, 1) and len(c.nodes) == 1
+    assert c.lut_neg(w) is not bit and len(c.nodes) == 1           # shared (CSE)
+    narrow = c.lut_neg(a[0] - b[0])                                # fits the ordinary message space: an ordinary look-up
+    total = bit * 3 + narrow - 1                                   # a consumer with a coefficient: owes 3 Delta / 2
+    c.set_outputs([bit, total])
+    assert c.lut_neg(5) .const == 0 and c.lut_neg(-5).const == 1
+    with pytest.raises(RangeError):
+        c.lut_neg(w * 2)
+    prog = Program.from_circuit(c)
+    assert prog.node_half.sum() == 1 and prog.lut_half.sum() == 1
+    consts = prog.half_unit_consts(prog.out_ptr, prog.out_leaf, prog.out_coef, prog.out_const)
+    assert consts.tolist() == [1, 2 * (-1) + 3]                    # units of Delta / 2
+    back = Circuit.from_dict(json.loads(json.dumps(c.to_dict())))
+    for x in range(16):
+        for y in range(16):
+            vals = [(x >> i) & 1 for i in range(4)] + [(y >> i) & 1 for i in range(4)]
+            want = [int(x < y), 3 * int(x < y) + int((x & 1) < (y & 1)) - 1]
+            assert c.simulate(vals) == want and prog.simulate(vals) == want and back.simulate(vals) == want
+
+
 def test_circuit_guards():
     c = Circuit()
     x = c.input(0, 40)
