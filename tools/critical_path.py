@@ -60,3 +60,7 @@ for k, v in cnt.most_common():
 print("by (function, enclosing operation):")
 for k, v in cnt2.most_common(16):
     print(f"  {v:4d}  {k}")
+allc = collections.Counter(tag_of.get(leaf, ("?", "")) for _, _, _, leaf in c.nodes)
+print("all look-ups by (function, enclosing operation):")
+for k, v in allc.most_common(14):
+    print(f"  {v:6d}  {k}")
