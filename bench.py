@@ -83,7 +83,9 @@ class SclkSampler:
 
     def result(self):
         if self.samples:
-            return float(np.median(self.samples)), f"sysfs pp_dpm_sclk, median of {len(self.samples)} samples during the timed steps"
+            return float(np.median(self.samples)), (f"sysfs pp_dpm_sclk (the selected DPM level), median of {len(self.samples)} samples during the timed "
+                                                    "steps; near the power limit the average clock is lower (rocm-smi: ~2.25 GHz under this "
+                                                    "kernel), so the fraction is a lower bound - the PMC view is valu_busy_frac_profiled")
         return 2400.0, "spec maximum (pp_dpm_sclk not readable here): the fraction is a lower bound"
 
 
