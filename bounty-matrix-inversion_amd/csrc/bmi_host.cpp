@@ -21,6 +21,7 @@
 #include "ntt_wave.hpp"
 #include "ntt_half_f64.hpp"
 #include "ntt_wave_f64.hpp"
+#include "fft_wave_f64.hpp"
 #include "t64_common.hpp"
 
 using gl::i64;
@@ -194,6 +195,7 @@ struct bmi_ctx {
     std::vector<u64> sk_small, sk_big, bsk_std, ksk;
     void *d_bsk = nullptr, *d_tw = nullptr, *d_luts = nullptr;  // u64 words (Goldilocks) or f64 words (49-bit field)
     double *d_tw_half = nullptr, *d_bsk_lat = nullptr;          // 49-bit field: tables and key copy of the split-transform latency kernel
+    double *d_tw_fft = nullptr, *d_bsk_fft = nullptr;           // 2^64 torus, key at 48 bits: tables and key copy of the floating-point-transform wave-pair kernel (bmi_kernels_t64f.hip)
     double *d_tw_wide = nullptr;                                // N = 2048: T / T^-1 of the even/odd combination (d_bsk_lat then holds the wide key copy)
     // bootstrap-key unrolling (49-bit field at N = 1024 / 2048, 2^64 torus; bmi_set_bsk_unroll): per pair of LWE coefficients the GGSW encryptions of
     // s s', s (1 - s'), (1 - s) s'; host copy in the standard domain, device copy in the slot order of the latency kernel
@@ -470,6 +472,21 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
         if (hipMemcpy(c->d_tw_half, th.data(), th.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(half-transform twiddles) failed");
     }
+    if (c->t64() && c->N == 1024) {   // tables of the folded 512-point complex transform (fft_wave_f64.hpp): powers of zeta = exp(i pi / 1024)
+        std::vector<double> tf(fftw::TW_WORDS);
+        auto zeta_pow = [](uint32_t e, double *dst) {
+            const long double ang = 3.14159265358979323846264338327950288L * (long double)(e % 2048) / 1024.0L;
+            dst[0] = (double)cosl(ang);
+            dst[1] = (double)sinl(ang);
+        };
+        for (uint32_t k2 = 0; k2 < 8; k2++)
+            for (uint32_t lane = 0; lane < 64; lane++) zeta_pow(lane * (4 * k2 + 1), &tf[fftw::TW_T1 + (k2 * 64 + lane) * 2]);
+        for (uint32_t d = 0; d < 8; d++)
+            for (uint32_t a = 0; a < 8; a++) zeta_pow(32 * a * d, &tf[fftw::TW_T2 + (d * 8 + a) * 2]);
+        if (hipMalloc(&c->d_tw_fft, tf.size() * 8) != hipSuccess) return bail("hipMalloc(fft twiddles) failed");
+        if (hipMemcpy(c->d_tw_fft, tf.data(), tf.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+            return bail("hipMemcpy(fft twiddles) failed");
+    }
     if ((c->f64() && !c->quad()) || c->t64()) {   // psi^x for the unrolled blind rotation (X^c at the root psi^e is psi^(e c))
         // N = 1024: psi = psi_2048, x in [0, 2048).  N = 2048: psi = psi_4096, x in [0, 2048) (the upper half is the negative)
         std::vector<u64> rp(2048);
@@ -500,7 +517,8 @@ void bmi_ctx_destroy(bmi_ctx *c) {
     for (void *p : {c->d_bsk, (void *)c->d_ksk, (void *)c->d_ks_bias, c->d_tw, c->d_luts, (void *)c->d_small,
                     (void *)c->d_io_a, (void *)c->d_io_b, (void *)c->d_io_ids, c->d_ks_partial,
                     (void *)c->d_ks_limbs, (void *)c->d_ks_digits, (void *)c->d_ks_sums, (void *)c->d_tw_half,
-                    (void *)c->d_bsk_lat, (void *)c->d_tw_wide, (void *)c->d_bsk3_lat, (void *)c->d_root_pow})
+                    (void *)c->d_bsk_lat, (void *)c->d_tw_wide, (void *)c->d_bsk3_lat, (void *)c->d_root_pow,
+                    (void *)c->d_tw_fft, (void *)c->d_bsk_fft})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -745,6 +763,17 @@ int upload_eval_keys(bmi_ctx *c) {
         }
         rc = bmit::launch_bsk_to_lat(d_tmp, c->d_bsk_lat, c->d_tw_half, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
         if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat (torus) launch failed"); }
+        // third copy where the floating-point transform carries the exact products (48-bit key, base 2^10): the wave-pair
+        // kernel of bmi_kernels_t64f.hip, same results at ~half the instructions
+        if (c->d_bsk_fft) { (void)hipFree(c->d_bsk_fft); c->d_bsk_fft = nullptr; }
+        if (c->d_tw_fft && bmit::shape_supported_fft(c->bsk_prec, P.bs_levels, P.bs_base_log)) {
+            if (hipMalloc(&c->d_bsk_fft, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) {
+                (void)hipFree(d_tmp);
+                return fail(c, -2, "hipMalloc(torus fft key) failed");
+            }
+            rc = bmit::launch_bsk_to_fft(d_tmp, c->d_bsk_fft, c->d_tw_fft, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
+            if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_fft (torus) launch failed"); }
+        }
     } else if (c->wide() || c->quad()) {  // N = 2048 / 4096: one key copy, in the slot order of k_blind_rotate_wide49 / quad49
         if (!c->d_bsk_lat && hipMalloc(&c->d_bsk_lat, bsk_words * 8) != hipSuccess) {
             (void)hipFree(d_tmp);
@@ -1013,7 +1042,8 @@ int bmi_set_keyswitch_variant(bmi_ctx *c, int variant) {
 
 int bmi_set_kernel_variant(bmi_ctx *c, int variant) {
     if (!c) return -1;
-    if (variant < 0 || variant > 4) return fail(c, -1, "variant must be 0..4");
+    if (variant < 0 || variant > 5) return fail(c, -1, "variant must be 0..5");
+    if (variant == 5 && !c->t64()) return fail(c, -1, "kernel variant 5 (wave pairs, floating-point transform) exists on the 2^64 torus only");
 #ifndef BMI_AB_KERNELS
     if (c->f64() && !c->wide() && !c->quad() && (variant == 1 || variant == 4))
         return fail(c, -1, "kernel variants 1 and 4 of the 49-bit field (the predecessors of the wave-pair and latency kernels) are not "
@@ -1121,6 +1151,15 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
         if (lat_t) {
             rc = bmit::launch_blind_rotate_lat(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_lat, c->d_tw_half, d_out,
                                                count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
+            return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+        }
+        // wave pairs: through the floating-point transform where its key copy exists (48-bit key, base 2^10; variant 5 pins it,
+        // variants 1 / 3 pin the exact transform mod 2^49 - 720895)
+        if (c->variant == 5 && !c->d_bsk_fft)
+            return fail(c, -1, "kernel variant 5 needs the bootstrap key at 48 bits of precision in base 2^10 (the torus default)");
+        if (c->d_bsk_fft && (c->variant == 0 || c->variant == 5)) {
+            rc = bmit::launch_blind_rotate_fft(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_fft, c->d_tw_fft, d_out, count, c->P.n,
+                                               c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }
         rc = bmit::launch_blind_rotate(d_small, d_lut_ids, (const u64 *)c->d_luts, (const double *)c->d_bsk,

@@ -175,6 +175,13 @@ int launch_blind_rotate_lat(const u64 *small_cts, const uint32_t *lut_ids, const
 int launch_blind_rotate_lat2u(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk3_lat,
                               const double *g_tw_h, const double *g_root_pow, u64 *out, uint32_t count, uint32_t n, int prec,
                               uint32_t levels, uint32_t base_log, hipStream_t s);
+// wave pairs with the exact limb products carried by the folded complex FFT (bmi_kernels_t64f.hip, fft_wave_f64.hpp): key copy
+// [poly][limb][8 registers][64 lanes] complex words; tables fftw::TW_WORDS doubles; same results as launch_blind_rotate
+bool shape_supported_fft(int prec, uint32_t levels, uint32_t base_log);
+int launch_bsk_to_fft(const u64 *std_polys, double *limb_polys, const double *g_tw_fft, uint32_t n_polys, int prec, hipStream_t s);
+int launch_blind_rotate_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
+                            const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
+                            uint32_t base_log, hipStream_t s);
 int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
                      uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,
                      hipStream_t s);

@@ -25,6 +25,7 @@
 #include "ks_mfma.hpp"
 #include "ntt_half_f64.hpp"
 #include "ntt_wave_f64.hpp"
+#include "pair_sync.hpp"
 #include "t64_common.hpp"
 
 using f49::i64;
@@ -72,31 +73,6 @@ __global__ void __launch_bounds__(256) k_bsk_to_limbs_t64(const u64 *__restrict_
     static_for<0, 16>([&](auto J) { x[J] = (double)t64::limb_of((i64)std_polys[(size_t)poly * N + lane + 64 * J], j, prec); });
     forward(x, lane, lds, scratch);
     static_for<0, 16>([&](auto V) { limb_polys[(size_t)item * N + eval_offset(lane, V)] = f49::red(x[V]); });
-}
-
-__device__ __forceinline__ void pair_post(uint32_t *flag, uint32_t v) {
-    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// one opaque asm block (as C++ control flow the poll loop makes the register allocator spill, see bmi_kernels_f64.hip)
-__device__ __forceinline__ void pair_wait(uint32_t *flag, uint32_t v) {
-    const uint32_t addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)flag;
-    uint32_t tmp;
-    asm volatile(
-        "1:\n\t"
-        "ds_read_b32 %0, %1\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_eq_u32 vcc, %2, %0\n\t"
-        "s_cbranch_vccnz 2f\n\t"
-        "s_sleep 1\n\t"
-        "s_branch 1b\n"
-        "2:"
-        : "=&v"(tmp)
-        : "v"(addr), "s"(v)
-        : "vcc", "memory");
-}
-__device__ __forceinline__ void pin() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int PREC, int L = 3, int BG = 15>

@@ -1,0 +1,276 @@
+// 2^64 TORUS, throughput blind rotation with the exact products carried by a floating-point transform (gfx950).
+//
+// Same function as k_blind_rotate_t64<48, L, 10> (bmi_kernels_t64.hip) - bootstrap key stored at 48 bits of precision as two
+// balanced 24-bit limbs, digits in base 2^10, accumulator as the exact integer word / 2^16 in a double - and the same results
+// bit for bit: per limb the sum over the 2 L digit x limb polynomial products is an integer below 2^45, and it is computed here
+// through the folded 512-point complex FFT of fft_wave_f64.hpp and ROUNDED TO THE NEAREST INTEGER, which returns that
+// integer exactly (the transform's error on these operands stays below 2^-11, see the header; tests/test_gpu_parity.py and
+// tests/test_gpu_torus_fft.py hold the kernel to the oracle's integer arithmetic).  What changes is the cost: a transform of
+// 1,024 real coefficients is ~300 f64 instructions per lane instead of ~700 for the exact one mod 2^49 - 720895, and a
+// multiply-accumulate is 4 fused multiply-adds per complex point (2 coefficients) instead of 6 instructions per coefficient.
+//
+// Structure = k_blind_rotate_t64: a pair of wavefronts per ciphertext, four ciphertexts per workgroup; wavefront c owns input
+// polynomial c (decomposes it, transforms its L digit polynomials once, multiplies them with both key columns per limb),
+// publishes the partner's partial sum through its LDS tile, adds the partner's, and runs the inverse transform of output c.
+#include <hip/hip_runtime.h>
+
+#include "bmi_internal.hpp"
+#include "fft_wave_f64.hpp"
+#include "pair_sync.hpp"
+#include "t64_common.hpp"
+
+using t64::i64;
+using t64::u64;
+using namespace fftw;
+
+namespace {
+
+#ifndef BMI_T64F_RESYNC
+#define BMI_T64F_RESYNC 4   // workgroup barrier every so many CMUXes (keeps the four pairs on the same key rows, shared through L1)
+#endif
+#ifndef BMI_T64F_PRIO
+#define BMI_T64F_PRIO 1     // issue priority steps down through the forward transforms (3, 2, 1), 0 in the limb loop
+#endif
+
+using t64::f64_to_word;
+using t64::Scheme;
+constexpr int TF_CTS = 4;
+constexpr int TF_LDS_WORDS = TW_WORDS + 2 * TF_CTS * (SCRATCH_WORDS + N) + TF_CTS * BMI_AT_WORDS + 4 * TF_CTS;
+static_assert(TF_LDS_WORDS <= BMI_LDS_WORDS_MAX, "TF_LDS_WORDS exceeds the 160 KB of LDS");
+static_assert(SCRATCH_WORDS >= N, "a tile carries 512 complex partial sums to the partner");
+
+// standard-domain GGSW polynomials (u64 torus words, already rounded to the key precision) -> per polynomial the two limb
+// polynomials in the evaluation layout of fft_wave_f64.hpp ([poly][limb][register c][lane] complex words)
+__global__ void __launch_bounds__(256) k_bsk_to_fft_t64(const u64 *__restrict__ std_polys, double *__restrict__ limb_polys,
+                                                        const double *__restrict__ g_tw, uint32_t n_polys, int prec) {
+    const int limbs = t64::limbs_of(prec);
+    __shared__ double lds[TW_WORDS + 4 * SCRATCH_WORDS];
+    for (int i = threadIdx.x; i < TW_WORDS; i += blockDim.x) lds[i] = g_tw[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t item = blockIdx.x * 4 + wave;            // (polynomial, limb)
+    if (item >= n_polys * (uint32_t)limbs) return;
+    const uint32_t poly = item / limbs;
+    const int j = (int)(item % limbs);
+    double *scratch = lds + TW_WORDS + wave * SCRATCH_WORDS;
+    double x[16];
+    static_for<0, 16>([&](auto J) { x[J] = (double)t64::limb_of((i64)std_polys[(size_t)poly * N + lane + 64 * J], j, prec); });
+    forward(x, lane, lds, scratch);
+    double2 *dst = reinterpret_cast<double2 *>(limb_polys + (size_t)item * N);
+    static_for<0, 8>([&](auto Cc) { dst[Cc * 64 + lane] = double2{x[Cc], x[Cc + 8]}; });
+}
+
+template <int L, int BG>
+__global__ void __launch_bounds__(128 * TF_CTS)
+    k_blind_rotate_t64f(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids, const u64 *__restrict__ luts,
+                        const double *__restrict__ bsk, const double *__restrict__ g_tw, u64 *__restrict__ out,
+                        uint32_t count, uint32_t n) {
+    constexpr int CTS = TF_CTS;
+    constexpr int LIMBS = Scheme<48>::LIMBS, LB = Scheme<48>::BITS, PRE = Scheme<48>::PRE, AB = 64 - PRE;
+    // a limb's sum: 2 L N terms of |digit| <= 2^(BG-1) times |limb| <= 2^(LB-1) - the transform's error bound is stated for this size
+    static_assert(2.0 * L * N * (double)(1ull << (BG - 1)) * (double)(1ull << (LB - 1)) <= 0x1p45, "limb sums must stay below 2^45");
+    static_assert(LIMBS == 2 && L * BG < AB, "two limbs; the decomposed bits lie inside the key precision");
+    extern __shared__ double lds[];
+    double *tiles = lds + TW_WORDS;
+    double *accs = tiles + 2 * CTS * SCRATCH_WORDS;          // accumulators: exact integers word / 2^PRE, centred mod 2^AB
+    double *at_base = accs + 2 * CTS * N;
+    uint32_t *flags = reinterpret_cast<uint32_t *>(at_base + CTS * BMI_AT_WORDS);  // [2 CTS] published, [2 CTS] consumed
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ctl = wave >> 1, c = wave & 1;
+    if (threadIdx.x < 4 * CTS) flags[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < TW_WORDS; i += blockDim.x) lds[i] = g_tw[i];
+    const uint32_t ct_raw = blockIdx.x * CTS + ctl;
+    const bool live = ct_raw < count;
+    const uint32_t ct = live ? ct_raw : count - 1;
+    double *tile = tiles + wave * SCRATCH_WORDS;
+    const double *ptile = tiles + (wave ^ 1) * SCRATCH_WORDS;
+    double *accf = accs + wave * N;
+    auto mod_ab = [](double t) {   // centred residue mod 2^AB of an exact integer |t| < 2^53
+        // (ties go to the negative end, like the two's complement reading of the u64 word: + 2^(AB-1) is - 2^(AB-1))
+        return __builtin_fma(-(double)(1ull << AB), __builtin_floor(__builtin_fma(t, 1.0 / (double)(1ull << AB), 0.5)), t);
+    };
+    uint16_t *at = reinterpret_cast<uint16_t *>(at_base + ctl * BMI_AT_WORDS);
+    uint32_t *f_pub = flags + wave, *f_pub_partner = flags + (wave ^ 1);
+    uint32_t *f_ack = flags + 2 * CTS + wave, *f_ack_partner = flags + 2 * CTS + (wave ^ 1);
+    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
+    for (uint32_t i = lane + 64 * c; i <= n; i += 128) at[i] = (uint16_t)t64::modswitch<LOG_N + 1>(lwe[i]);
+    __syncthreads();
+    {
+        const u64 *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
+        const uint32_t bt = at[n];
+        static_for<0, 16>([&](auto J) {
+            const uint32_t e = (lane + 64 * J + bt) & (2 * N - 1);
+            const u64 v = tv[e & (N - 1)];
+            const u64 w0 = c ? ((e & N) ? (u64)0 - v : v) : (u64)0;
+            accf[lane + 64 * J] = (double)((i64)w0 >> PRE);     // test polynomials are multiples of 2^(59 or so)
+        });
+    }
+
+    uint32_t hand = 0;   // handshake counter of the pair (one per inverse transform)
+    for (uint32_t i = 0; i < n; i++) {
+#if BMI_T64F_RESYNC
+        if (i % BMI_T64F_RESYNC == 0) __syncthreads();
+#endif
+        const uint32_t a_t = at[i];
+        // this wavefront's L GGSW rows: [row = L c + lev][column][limb][N]
+        const double *bsk_c = bsk + ((size_t)i * 4 * L + c * 2 * L) * LIMBS * N;
+#if BMI_T64F_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        wave_sync();
+        double r[16];
+        {
+            double vr[16], vs[16];  // all 32 reads in flight before the first use
+            static_for<0, 16>([&](auto J) {
+                vr[J] = accf[(lane + 64 * J + 2 * N - a_t) & (N - 1)];
+                vs[J] = accf[lane + 64 * J];
+            });
+            sched_fence();
+            static_for<0, 16>([&](auto J) {
+                const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
+                const double d = mod_ab(((e & N) ? -vr[J] : vr[J]) - vs[J]);            // the centred lift of the u64 difference, / 2^PRE
+                r[J] = __builtin_floor(__builtin_fma(d, 1.0 / (double)(1ull << (AB - L * BG)), 0.5));   // round half up to L BG bits
+            });
+        }
+        double X[L][16];   // the L digit polynomials, evaluation layout, live across the limb loop
+        static_for<0, L>([&](auto LEV) {
+            constexpr int lev = L - 1 - LEV;  // least significant digit first
+            pin();
+#if BMI_T64F_PRIO
+            __builtin_amdgcn_s_setprio(lev + 1);
+#endif
+            static_for<0, 16>([&](auto J) {
+                if constexpr (lev == 0) {
+                    X[0][J] = r[J];
+                } else {
+                    const double rn = __builtin_floor(__builtin_fma(r[J], 1.0 / (double)(1ull << BG), 0.5));
+                    X[lev][J] = __builtin_fma(-(double)(1ull << BG), rn, r[J]);          // digit in [-2^(BG-1), 2^(BG-1))
+                    r[J] = rn;
+                }
+            });
+            forward(X[lev], lane, lds, tile);
+        });
+#if BMI_T64F_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        static_for<0, LIMBS>([&](auto JL) {
+            constexpr int j = JL;
+            // 2 L key rows of this limb, partner's column first (its partial sum is published while the own column is
+            // still being multiplied): rows 0..L-1 = (lev, column c^1), rows L..2L-1 = (lev, column c)
+            auto row_ptr = [&](int q) {
+                const int lev = q % L, col = q < L ? (c ^ 1) : c;
+                return reinterpret_cast<const double2 *>(bsk_c + ((size_t)(lev * 2 + col) * LIMBS + j) * N);
+            };
+            double2 kb[8];
+            double acc[16];
+            hand++;
+            static_for<0, 2 * L>([&](auto Q) {
+                constexpr int q = Q, lev = q % L;
+                static_for<0, 8>([&](auto P) { kb[P] = row_ptr(q)[P * 64 + lane]; });
+                sched_fence();
+                static_for<0, 8>([&](auto P) {
+                    const double xr = X[lev][P], xi = X[lev][P + 8];
+                    if constexpr (lev == 0) {
+                        acc[P] = __builtin_fma(xr, kb[P].x, -(xi * kb[P].y));
+                        acc[P + 8] = __builtin_fma(xr, kb[P].y, xi * kb[P].x);
+                    } else {
+                        acc[P] = __builtin_fma(xr, kb[P].x, __builtin_fma(-xi, kb[P].y, acc[P]));
+                        acc[P + 8] = __builtin_fma(xr, kb[P].y, __builtin_fma(xi, kb[P].x, acc[P + 8]));
+                    }
+                });
+                if constexpr (q == L - 1) {
+                    // the partner's partial goes through this wavefront's tile (free since the last transform)
+                    wave_sync();
+                    static_for<0, 8>([&](auto P) {
+                        reinterpret_cast<double2 *>(tile)[P * 64 + lane] = double2{acc[P], acc[P + 8]};
+                    });
+                    pair_post(f_pub, hand);
+                }
+                pin();
+            });
+            pair_wait(f_pub_partner, hand);
+            static_for<0, 8>([&](auto P) {
+                const double2 p = reinterpret_cast<const double2 *>(ptile)[P * 64 + lane];
+                acc[P] += p.x;
+                acc[P + 8] += p.y;
+            });
+            pair_post(f_ack, hand);          // release: the reads above have landed
+            pair_wait(f_ack_partner, hand);  // the partner has read this tile: the inverse transform may overwrite it
+            inverse(acc, lane, lds, tile);
+            // the limb's exact integer result (|.| < 2^45: nearest integer of the transform's output), shifted into place
+            static_for<0, 16>([&](auto J) {
+                double x = __builtin_rint(acc[J]);
+                if constexpr (j > 0) {
+                    // x 2^(LB j) mod 2^AB: only the low AB - LB j bits of the limb's integer survive the shift
+                    constexpr double W = (double)(1ull << (AB - LB * j));
+                    x = __builtin_fma(-W, __builtin_rint(x * (1.0 / W)), x);
+                    accf[lane + 64 * J] = mod_ab(__builtin_fma(x, (double)(1ull << (LB * j)), accf[lane + 64 * J]));
+                } else {
+                    accf[lane + 64 * J] = mod_ab(accf[lane + 64 * J] + x);
+                }
+            });
+            pin();
+        });
+    }
+
+    if (!live) return;
+    wave_sync();
+    u64 *o = out + (size_t)ct * (N + 1);
+    if (c == 0) {
+        static_for<0, 16>([&](auto J) {
+            const uint32_t m = lane + 64 * J;
+            const u64 v = f64_to_word(accf[m]) << PRE;
+            if (m == 0) o[0] = v;
+            else o[N - m] = (u64)0 - v;
+        });
+    } else if (lane == 0) {
+        o[N] = f64_to_word(accf[0]) << PRE;
+    }
+}
+
+}  // namespace
+
+namespace bmit {
+
+#define BMITF_LAUNCH_CHECK()                    \
+    do {                                        \
+        hipError_t e__ = hipGetLastError();     \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+// (precision, levels, base log) combinations the transform's error bound was established for
+bool shape_supported_fft(int prec, uint32_t levels, uint32_t base_log) {
+    return prec == 48 && base_log == 10 && (levels == 3 || levels == 2);
+}
+
+int launch_bsk_to_fft(const u64 *std_polys, double *limb_polys, const double *g_tw_fft, uint32_t n_polys, int prec, hipStream_t s) {
+    if (prec != 48) return (int)hipErrorInvalidValue;
+    const uint32_t items = n_polys * (uint32_t)t64::limbs_of(prec);
+    hipLaunchKernelGGL(k_bsk_to_fft_t64, dim3((items + 3) / 4), dim3(256), 0, s, std_polys, limb_polys, g_tw_fft, n_polys, prec);
+    BMITF_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int L, int BG>
+static int launch_t64f(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
+                       const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+    static std::atomic<uint64_t> configured{0};
+    const size_t lds = (size_t)TF_LDS_WORDS * sizeof(double);
+    auto kern = k_blind_rotate_t64f<L, BG>;
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
+    hipLaunchKernelGGL(kern, dim3((count + TF_CTS - 1) / TF_CTS), dim3(128 * TF_CTS), lds, s, small_cts, lut_ids, luts, bsk_fft,
+                       g_tw_fft, out, count, n);
+    BMITF_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_blind_rotate_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
+                            const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
+                            uint32_t base_log, hipStream_t s) {
+    if (count == 0) return 0;
+    if (!shape_supported_fft(prec, levels, base_log)) return (int)hipErrorInvalidValue;
+    if (levels == 3) return launch_t64f<3, 10>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, s);
+    return launch_t64f<2, 10>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, s);
+}
+
+}  // namespace bmit

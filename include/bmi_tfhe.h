@@ -179,7 +179,10 @@ int bmi_sync(bmi_ctx *ctx, void *stream);
 /* Selects the blind-rotation kernel: 0 = auto (by batch size), 1 = throughput, a pair of wavefronts per
  * ciphertext exchanging every level, 2 = latency (one workgroup of 8 wavefronts per ciphertext), 3 = throughput,
  * a pair of wavefronts per ciphertext exchanging once per CMUX (49-bit field; what auto picks for large batches),
- * 4 = the one-wavefront-per-transform latency kernel (2 is the two-wavefronts-per-transform one on the 49-bit field). */
+ * 4 = the one-wavefront-per-transform latency kernel (2 is the two-wavefronts-per-transform one on the 49-bit field),
+ * 5 = 2^64 torus only, bootstrap key at 48 bits in base 2^10 (the torus default): the wave-pair kernel whose exact limb
+ *     products are carried by a folded 512-point complex FFT in f64 and rounded to the nearest integer (same words as 1 / 3,
+ *     which pin the exact transform mod 2^49 - 720895; what auto picks for large batches on that key). */
 int bmi_set_kernel_variant(bmi_ctx *ctx, int variant);
 
 /* 2^64 torus only, before keygen / import: precision the bootstrap key is stored at.  No transform exists mod 2^64, so the
