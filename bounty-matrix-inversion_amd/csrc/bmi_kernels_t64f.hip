@@ -26,7 +26,7 @@ using namespace fftw;
 namespace {
 
 #ifndef BMI_T64F_RESYNC
-#define BMI_T64F_RESYNC 4   // workgroup barrier every so many CMUXes (keeps the four pairs on the same key rows, shared through L1)
+#define BMI_T64F_RESYNC 1   // workgroup barrier every so many CMUXes: keeps the four pairs on the same key rows, which they share through L1 (0: 83.2 ms, 4: 70.1, 1: 68.9 per 8,192)
 #endif
 #ifndef BMI_T64F_PRIO
 #define BMI_T64F_PRIO 1     // issue priority steps down through the forward transforms (3, 2, 1), 0 in the limb loop
@@ -133,6 +133,15 @@ __global__ void __launch_bounds__(128 * TF_CTS)
             });
         }
         double X[L][16];   // the L digit polynomials, evaluation layout, live across the limb loop
+        // key rows in the order they are multiplied: t = limb * 2 L + q; q < L: (level q, partner's column c^1) - its partial sum is
+        // published while the own column (q >= L: level q - L, column c) is still being multiplied.  A row is 8 complex words per
+        // lane; the NEXT row is requested before the current one is multiplied (two register sets), the first one before the last
+        // forward transform: a row's 32 multiply-adds are far shorter than the latency of its loads.
+        auto row_ptr = [&](int t) {
+            const int j = t / (2 * L), q = t % (2 * L), lev = q % L, col = q < L ? (c ^ 1) : c;
+            return reinterpret_cast<const double2 *>(bsk_c + ((size_t)(lev * 2 + col) * LIMBS + j) * N);
+        };
+        double2 kb[2][8];
         static_for<0, L>([&](auto LEV) {
             constexpr int lev = L - 1 - LEV;  // least significant digit first
             pin();
@@ -148,68 +157,70 @@ __global__ void __launch_bounds__(128 * TF_CTS)
                     r[J] = rn;
                 }
             });
+            if constexpr (lev == 0) {
+                static_for<0, 8>([&](auto P) { kb[0][P] = row_ptr(0)[P * 64 + lane]; });
+                pin();
+            }
             forward(X[lev], lane, lds, tile);
         });
 #if BMI_T64F_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
-        static_for<0, LIMBS>([&](auto JL) {
-            constexpr int j = JL;
-            // 2 L key rows of this limb, partner's column first (its partial sum is published while the own column is
-            // still being multiplied): rows 0..L-1 = (lev, column c^1), rows L..2L-1 = (lev, column c)
-            auto row_ptr = [&](int q) {
-                const int lev = q % L, col = q < L ? (c ^ 1) : c;
-                return reinterpret_cast<const double2 *>(bsk_c + ((size_t)(lev * 2 + col) * LIMBS + j) * N);
-            };
-            double2 kb[8];
-            double acc[16];
-            hand++;
-            static_for<0, 2 * L>([&](auto Q) {
-                constexpr int q = Q, lev = q % L;
-                static_for<0, 8>([&](auto P) { kb[P] = row_ptr(q)[P * 64 + lane]; });
-                sched_fence();
+        double acc[16];
+        static_for<0, LIMBS * 2 * L>([&](auto T) {
+            constexpr int t = T, j = t / (2 * L), q = t % (2 * L), lev = q % L, cur = t & 1;
+            if constexpr (q == 0) hand++;
+            // (the first row of the next limb is requested after the inverse transform, which needs the registers)
+            if constexpr (t + 1 < LIMBS * 2 * L && q != 2 * L - 1)
+                static_for<0, 8>([&](auto P) { kb[cur ^ 1][P] = row_ptr(t + 1)[P * 64 + lane]; });
+            sched_fence();
+            static_for<0, 8>([&](auto P) {
+                const double xr = X[lev][P], xi = X[lev][P + 8];
+                if constexpr (lev == 0) {
+                    acc[P] = __builtin_fma(xr, kb[cur][P].x, -(xi * kb[cur][P].y));
+                    acc[P + 8] = __builtin_fma(xr, kb[cur][P].y, xi * kb[cur][P].x);
+                } else {
+                    acc[P] = __builtin_fma(xr, kb[cur][P].x, __builtin_fma(-xi, kb[cur][P].y, acc[P]));
+                    acc[P + 8] = __builtin_fma(xr, kb[cur][P].y, __builtin_fma(xi, kb[cur][P].x, acc[P + 8]));
+                }
+            });
+            if constexpr (q == L - 1) {
+                // the partner's partial goes through this wavefront's tile (free since the last transform)
+                wave_sync();
                 static_for<0, 8>([&](auto P) {
-                    const double xr = X[lev][P], xi = X[lev][P + 8];
-                    if constexpr (lev == 0) {
-                        acc[P] = __builtin_fma(xr, kb[P].x, -(xi * kb[P].y));
-                        acc[P + 8] = __builtin_fma(xr, kb[P].y, xi * kb[P].x);
+                    reinterpret_cast<double2 *>(tile)[P * 64 + lane] = double2{acc[P], acc[P + 8]};
+                });
+                pair_post(f_pub, hand);
+            }
+            pin();
+            if constexpr (q == 2 * L - 1) {
+                pair_wait(f_pub_partner, hand);
+                static_for<0, 8>([&](auto P) {
+                    const double2 p = reinterpret_cast<const double2 *>(ptile)[P * 64 + lane];
+                    acc[P] += p.x;
+                    acc[P + 8] += p.y;
+                });
+                pair_post(f_ack, hand);          // release: the reads above have landed
+                pair_wait(f_ack_partner, hand);  // the partner has read this tile: the inverse transform may overwrite it
+                inverse(acc, lane, lds, tile);
+                if constexpr (t + 1 < LIMBS * 2 * L) {
+                    static_for<0, 8>([&](auto P) { kb[cur ^ 1][P] = row_ptr(t + 1)[P * 64 + lane]; });
+                    pin();
+                }
+                // the limb's exact integer result (|.| < 2^45: nearest integer of the transform's output), shifted into place
+                static_for<0, 16>([&](auto J) {
+                    double x = __builtin_rint(acc[J]);
+                    if constexpr (j > 0) {
+                        // x 2^(LB j) mod 2^AB: only the low AB - LB j bits of the limb's integer survive the shift
+                        constexpr double W = (double)(1ull << (AB - LB * j));
+                        x = __builtin_fma(-W, __builtin_rint(x * (1.0 / W)), x);
+                        accf[lane + 64 * J] = mod_ab(__builtin_fma(x, (double)(1ull << (LB * j)), accf[lane + 64 * J]));
                     } else {
-                        acc[P] = __builtin_fma(xr, kb[P].x, __builtin_fma(-xi, kb[P].y, acc[P]));
-                        acc[P + 8] = __builtin_fma(xr, kb[P].y, __builtin_fma(xi, kb[P].x, acc[P + 8]));
+                        accf[lane + 64 * J] = mod_ab(accf[lane + 64 * J] + x);
                     }
                 });
-                if constexpr (q == L - 1) {
-                    // the partner's partial goes through this wavefront's tile (free since the last transform)
-                    wave_sync();
-                    static_for<0, 8>([&](auto P) {
-                        reinterpret_cast<double2 *>(tile)[P * 64 + lane] = double2{acc[P], acc[P + 8]};
-                    });
-                    pair_post(f_pub, hand);
-                }
                 pin();
-            });
-            pair_wait(f_pub_partner, hand);
-            static_for<0, 8>([&](auto P) {
-                const double2 p = reinterpret_cast<const double2 *>(ptile)[P * 64 + lane];
-                acc[P] += p.x;
-                acc[P + 8] += p.y;
-            });
-            pair_post(f_ack, hand);          // release: the reads above have landed
-            pair_wait(f_ack_partner, hand);  // the partner has read this tile: the inverse transform may overwrite it
-            inverse(acc, lane, lds, tile);
-            // the limb's exact integer result (|.| < 2^45: nearest integer of the transform's output), shifted into place
-            static_for<0, 16>([&](auto J) {
-                double x = __builtin_rint(acc[J]);
-                if constexpr (j > 0) {
-                    // x 2^(LB j) mod 2^AB: only the low AB - LB j bits of the limb's integer survive the shift
-                    constexpr double W = (double)(1ull << (AB - LB * j));
-                    x = __builtin_fma(-W, __builtin_rint(x * (1.0 / W)), x);
-                    accf[lane + 64 * J] = mod_ab(__builtin_fma(x, (double)(1ull << (LB * j)), accf[lane + 64 * J]));
-                } else {
-                    accf[lane + 64 * J] = mod_ab(accf[lane + 64 * J] + x);
-                }
-            });
-            pin();
+            }
         });
     }
 

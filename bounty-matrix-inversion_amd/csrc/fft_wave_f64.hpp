@@ -125,10 +125,10 @@ __device__ __forceinline__ void forward(double (&x)[16], int lane, const double 
     static_for<1, 8>([&](auto R) { v[R] = cmul<false>(C{x[R], x[R + 8]}, TWIST_C[R], TWIST_S[R]); });
     dft8<false>(v);
     static_for<0, 8>([&](auto K) { v[K] = cmul<false>(v[K], w[K].x, w[K].y); });
+    const int r1 = ex1_row(lane), a = lane & 7, base = ex2_base(lane);
     wave_sync();
     static_for<0, 8>([&](auto K) { sc[K * ROWC + lane] = double2{v[K].r, v[K].i}; });
     wave_sync();
-    const int r1 = ex1_row(lane), a = lane & 7, base = ex2_base(lane);
     static_for<0, 8>([&](auto B) {
         const double2 t = sc[r1 + 8 * B];
         v[B] = C{t.x, t.y};
@@ -179,8 +179,9 @@ __device__ __forceinline__ void inverse(double (&x)[16], int lane, const double 
     wave_sync();
     static_for<0, 8>([&](auto K) {
         const double2 t = sc[K * ROWC + lane];
-        v[K] = cmul<true>(C{t.x, t.y}, w[K].x, w[K].y);
+        v[K] = C{t.x, t.y};
     });
+    static_for<0, 8>([&](auto K) { v[K] = cmul<true>(v[K], w[K].x, w[K].y); });
     dft8<true>(v);   // over k2 -> r
     x[0] = v[0].r * (1.0 / 512);
     x[8] = v[0].i * (1.0 / 512);
