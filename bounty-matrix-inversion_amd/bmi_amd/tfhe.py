@@ -427,7 +427,7 @@ class Engine:
     def set_kernel_variant(self, v):
         """blind rotation: 0 auto, 1 pair kernel exchanging per level, 2 latency kernel (two wavefronts per transform on
         the 49-bit field), 3 pair kernel exchanging per CMUX, 4 latency kernel with one wavefront per transform, 5 (2^64 torus,
-        48-bit key in base 2^10) pair kernel with the exact limb products carried by the f64 complex FFT"""
+        48-bit key in base 2^10) pair kernel with the exact limb products carried by the f64 complex FFT, 6 its latency form"""
         self._ck(self.lib.bmi_set_kernel_variant(self.h, int(v)), "bmi_set_kernel_variant")
 
     def set_bsk_precision(self, bits):

@@ -1042,8 +1042,8 @@ int bmi_set_keyswitch_variant(bmi_ctx *c, int variant) {
 
 int bmi_set_kernel_variant(bmi_ctx *c, int variant) {
     if (!c) return -1;
-    if (variant < 0 || variant > 5) return fail(c, -1, "variant must be 0..5");
-    if (variant == 5 && !c->t64()) return fail(c, -1, "kernel variant 5 (wave pairs, floating-point transform) exists on the 2^64 torus only");
+    if (variant < 0 || variant > 6) return fail(c, -1, "variant must be 0..6");
+    if (variant >= 5 && !c->t64()) return fail(c, -1, "kernel variants 5 and 6 (floating-point transform) exist on the 2^64 torus only");
 #ifndef BMI_AB_KERNELS
     if (c->f64() && !c->wide() && !c->quad() && (variant == 1 || variant == 4))
         return fail(c, -1, "kernel variants 1 and 4 of the 49-bit field (the predecessors of the wave-pair and latency kernels) are not "
@@ -1147,7 +1147,17 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
                                                  count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }
-        const bool lat_t = c->variant == 2 || c->variant == 4 || (c->variant == 0 && count <= c->lat_threshold);
+        // with the floating-point-transform kernels one round of 256 one-workgroup bootstraps (4.5 ms) beats the wave-pair kernel
+        // (8.4 ms up to 1,024 ciphertexts), two rounds (9.0 ms) do not
+        const uint32_t thr = c->d_bsk_fft ? 256 : c->lat_threshold;
+        const bool lat_t = c->variant == 2 || c->variant == 4 || c->variant == 6 || (c->variant == 0 && count <= thr);
+        if (c->variant == 6 && !c->d_bsk_fft)
+            return fail(c, -1, "kernel variant 6 needs the bootstrap key at 48 bits of precision in base 2^10 (the torus default)");
+        if (lat_t && c->d_bsk_fft && c->variant != 4) {   // latency form through the floating-point transform (variant 4 pins the exact one)
+            rc = bmit::launch_blind_rotate_lat_fft(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_fft, c->d_tw_fft, d_out, count,
+                                                   c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
+            return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+        }
         if (lat_t) {
             rc = bmit::launch_blind_rotate_lat(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_lat, c->d_tw_half, d_out,
                                                count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);

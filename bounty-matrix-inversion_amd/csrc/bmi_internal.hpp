@@ -182,6 +182,10 @@ int launch_bsk_to_fft(const u64 *std_polys, double *limb_polys, const double *g_
 int launch_blind_rotate_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
                             const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
                             uint32_t base_log, hipStream_t s);
+// latency form (one workgroup of 8 wavefronts per ciphertext) on the same key copy
+int launch_blind_rotate_lat_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
+                                const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
+                                uint32_t base_log, hipStream_t s);
 int launch_keyswitch(const u64 *in, const u64 *ksk, const u64 *ks_bias, u64 *out, void *partial, uint32_t slices,
                      uint32_t count, uint32_t n, uint32_t big_n, uint32_t levels, uint32_t base_log, uint32_t ks_stride,
                      hipStream_t s);

@@ -239,6 +239,149 @@ __global__ void __launch_bounds__(128 * TF_CTS)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// LATENCY form: one workgroup of 8 wavefronts per ciphertext, three phases per CMUX separated by workgroup barriers
+//   A  wavefronts 0 .. 2L-1 = (input polynomial c, level): rotate / decompose the u64 accumulator (integer rule of the oracle),
+//      whole forward transform -> tile, evaluation layout
+//   B  all 512 threads = (output polynomial o, two complex slots): per limb the sum over the 2L rows of digit x key; the key
+//      words of the whole step (2L rows x 2 limbs x 2 slots, one 16-byte word each, the SAME key copy as the wave-pair kernel)
+//      are requested before phase A and land under it
+//   C  wavefronts 0 .. 3 = (limb, o): inverse transform, nearest integer, shift into place and ONE LDS atomic add per coefficient
+//      into the accumulator (the two limbs of a coefficient meet there)
+constexpr int LF_THREADS = 512;
+constexpr int LF_MAX_L = 3;
+constexpr int LF_LDS_WORDS = TW_WORDS + 2 * N + 2 * LF_MAX_L * SCRATCH_WORDS + 2 * 2 * N + BMI_AT_WORDS;
+static_assert(LF_LDS_WORDS <= BMI_LDS_WORDS_MAX, "LF_LDS_WORDS exceeds the 160 KB of LDS");
+
+template <int L, int BG>
+__global__ void __launch_bounds__(LF_THREADS)
+    k_blind_rotate_lat_t64f(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids, const u64 *__restrict__ luts,
+                            const double *__restrict__ bsk, const double *__restrict__ g_tw, u64 *__restrict__ out,
+                            uint32_t count, uint32_t n) {
+    constexpr int LIMBS = Scheme<48>::LIMBS, LB = Scheme<48>::BITS, PRE = Scheme<48>::PRE;
+    static_assert(2.0 * L * N * (double)(1ull << (BG - 1)) * (double)(1ull << (LB - 1)) <= 0x1p45, "limb sums must stay below 2^45");
+    static_assert(LIMBS == 2 && L <= LF_MAX_L, "two limbs, at most three levels");
+    extern __shared__ double lds[];
+    u64 *acc = reinterpret_cast<u64 *>(lds + TW_WORDS);          // [2 components][N] words mod 2^64
+    double *tiles = lds + TW_WORDS + 2 * N;                      // [2L][SCRATCH_WORDS]
+    double *SD = tiles + 2 * LF_MAX_L * SCRATCH_WORDS;           // [limb][output][512 complex]
+    uint16_t *at = reinterpret_cast<uint16_t *>(SD + LIMBS * 2 * N);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < TW_WORDS; i += LF_THREADS) lds[i] = g_tw[i];
+    const uint32_t ct = blockIdx.x;
+    const u64 *lwe = small_cts + (size_t)ct * (n + 1);
+    for (uint32_t i = tid; i <= n; i += LF_THREADS) at[i] = (uint16_t)t64::modswitch<LOG_N + 1>(lwe[i]);
+    __syncthreads();
+    {
+        const u64 *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
+        const uint32_t bt = at[n];
+        for (uint32_t nn = tid; nn < (uint32_t)N; nn += LF_THREADS) {
+            const uint32_t e = (nn + bt) & (2 * N - 1);
+            const u64 v = tv[e & (N - 1)];
+            acc[nn] = 0;
+            acc[N + nn] = (e & N) ? (u64)0 - v : v;
+        }
+    }
+    __syncthreads();
+    const int mo = tid >> 8, mq = tid & 255;   // phase B: output polynomial, first complex slot (the second is mq + 256)
+
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t a_t = at[i];
+        if (a_t == 0) continue;  // uniform over the workgroup
+        // key words of this thread: [row 2L][output 2][limb][512 complex slots], the layout of k_bsk_to_fft_t64
+        const double *bi = bsk + (size_t)i * 4 * L * LIMBS * N;
+        double2 kw[2 * L][LIMBS][2];
+        static_for<0, 2 * L>([&](auto R) {
+            static_for<0, LIMBS>([&](auto J) {
+                const double2 *row = reinterpret_cast<const double2 *>(bi + ((size_t)(R * 2 + mo) * LIMBS + J) * N);
+                kw[R][J][0] = row[mq];
+                kw[R][J][1] = row[mq + 256];
+            });
+        });
+        if (wave < 2 * L) {
+            const int c = wave / L, lev = wave % L;
+            const u64 *ac = acc + c * N;
+            double x[16];
+            u64 vr[16], vs[16];
+            static_for<0, 16>([&](auto J) {
+                vr[J] = ac[(lane + 64 * J + 2 * N - a_t) & (N - 1)];
+                vs[J] = ac[lane + 64 * J];
+            });
+            static_for<0, 16>([&](auto J) {
+                const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
+                const u64 v = (e & N) ? (u64)0 - vr[J] : vr[J];
+                double r = t64::rounded_top<L, BG>(v - vs[J]);                          // round half up to L BG bits
+                double d = r;                                                          // digit `lev`, balanced [-2^(BG-1), 2^(BG-1))
+#pragma unroll
+                for (int s = L - 1; s > 0; s--) {
+                    const double rn = __builtin_floor(__builtin_fma(r, 1.0 / (double)(1ull << BG), 0.5));
+                    if (s == lev) d = __builtin_fma(-(double)(1ull << BG), rn, r);
+                    r = rn;
+                }
+                x[J] = lev == 0 ? r : d;
+            });
+            double *tile = tiles + wave * SCRATCH_WORDS;
+            forward(x, lane, lds, tile);
+            wave_sync();
+            static_for<0, 8>([&](auto Cc) { reinterpret_cast<double2 *>(tile)[Cc * 64 + lane] = double2{x[Cc], x[Cc + 8]}; });
+        }
+        __syncthreads();
+        {
+            double2 sum[LIMBS][2];
+            static_for<0, 2 * L>([&](auto R) {
+                const double2 *xt = reinterpret_cast<const double2 *>(tiles + R * SCRATCH_WORDS);
+                static_for<0, 2>([&](auto S) {
+                    const double2 xv = xt[mq + 256 * S];
+                    static_for<0, LIMBS>([&](auto J) {
+                        const double2 k = kw[R][J][S];
+                        if constexpr (R == 0) {
+                            sum[J][S].x = __builtin_fma(xv.x, k.x, -(xv.y * k.y));
+                            sum[J][S].y = __builtin_fma(xv.x, k.y, xv.y * k.x);
+                        } else {
+                            sum[J][S].x = __builtin_fma(xv.x, k.x, __builtin_fma(-xv.y, k.y, sum[J][S].x));
+                            sum[J][S].y = __builtin_fma(xv.x, k.y, __builtin_fma(xv.y, k.x, sum[J][S].y));
+                        }
+                    });
+                });
+            });
+            static_for<0, LIMBS>([&](auto J) {
+                double2 *sd = reinterpret_cast<double2 *>(SD + (size_t)(J * 2 + mo) * N);
+                sd[mq] = sum[J][0];
+                sd[mq + 256] = sum[J][1];
+            });
+        }
+        __syncthreads();
+        if (wave < 2 * LIMBS) {
+            const int j = wave >> 1, o = wave & 1;
+            const double2 *sd = reinterpret_cast<const double2 *>(SD + (size_t)(j * 2 + o) * N);
+            double x[16];
+            static_for<0, 8>([&](auto Cc) {
+                const double2 t = sd[Cc * 64 + lane];
+                x[Cc] = t.x;
+                x[Cc + 8] = t.y;
+            });
+            inverse(x, lane, lds, tiles + wave * SCRATCH_WORDS);
+            unsigned long long *ao = reinterpret_cast<unsigned long long *>(acc + o * N);
+            const int sh = PRE + LB * j;
+            static_for<0, 16>([&](auto J) {
+                // the limb's exact integer (|.| < 2^45: nearest integer of the transform's output), shifted into place
+                atomicAdd(ao + lane + 64 * J, (unsigned long long)(f64_to_word(__builtin_rint(x[J])) << sh));
+            });
+        }
+        __syncthreads();
+    }
+    u64 *o = out + (size_t)ct * (N + 1);
+    for (uint32_t nn = tid; nn < (uint32_t)N; nn += LF_THREADS) {
+        const u64 a0 = acc[nn];
+        if (nn == 0) {
+            o[0] = a0;
+            o[N] = acc[N];
+        } else {
+            o[N - nn] = (u64)0 - a0;
+        }
+    }
+}
+
 }  // namespace
 
 namespace bmit {
@@ -273,6 +416,27 @@ static int launch_t64f(const u64 *small_cts, const uint32_t *lut_ids, const u64 
                        g_tw_fft, out, count, n);
     BMITF_LAUNCH_CHECK();
     return 0;
+}
+
+template <int L, int BG>
+static int launch_lat_t64f(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
+                           const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+    static std::atomic<uint64_t> configured{0};
+    const size_t lds = (size_t)LF_LDS_WORDS * sizeof(double);
+    auto kern = k_blind_rotate_lat_t64f<L, BG>;
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
+    hipLaunchKernelGGL(kern, dim3(count), dim3(LF_THREADS), lds, s, small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n);
+    BMITF_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_blind_rotate_lat_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
+                                const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
+                                uint32_t base_log, hipStream_t s) {
+    if (count == 0) return 0;
+    if (!shape_supported_fft(prec, levels, base_log)) return (int)hipErrorInvalidValue;
+    if (levels == 3) return launch_lat_t64f<3, 10>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, s);
+    return launch_lat_t64f<2, 10>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, s);
 }
 
 int launch_blind_rotate_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,

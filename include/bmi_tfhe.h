@@ -182,7 +182,8 @@ int bmi_sync(bmi_ctx *ctx, void *stream);
  * 4 = the one-wavefront-per-transform latency kernel (2 is the two-wavefronts-per-transform one on the 49-bit field),
  * 5 = 2^64 torus only, bootstrap key at 48 bits in base 2^10 (the torus default): the wave-pair kernel whose exact limb
  *     products are carried by a folded 512-point complex FFT in f64 and rounded to the nearest integer (same words as 1 / 3,
- *     which pin the exact transform mod 2^49 - 720895; what auto picks for large batches on that key). */
+ *     which pin the exact transform mod 2^49 - 720895; what auto picks for large batches on that key),
+ * 6 = the same for the latency form (one workgroup per ciphertext; what auto and 2 pick on that key; 4 pins the exact transform). */
 int bmi_set_kernel_variant(bmi_ctx *ctx, int variant);
 
 /* 2^64 torus only, before keygen / import: precision the bootstrap key is stored at.  No transform exists mod 2^64, so the

@@ -156,8 +156,9 @@ def test_keyswitch_matrix_core_path_bit_exact(eng, ora):
         assert list(to.decode(to.lwe_phase(sk_small, got[ok]), eng.delta_log())) == list(msgs[ok])
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5],
-                         ids=["pair_per_level", "latency", "pair_per_cmux", "latency_one_wave_transform", "pair_float_transform"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6],
+                         ids=["pair_per_level", "latency", "pair_per_cmux", "latency_one_wave_transform", "pair_float_transform",
+                              "latency_float_transform"])
 def test_blind_rotate_every_kernel_variant(eng, ora, variant):
     """7 ciphertexts: ragged against the 2 (variant 1) and 4 (variant 3) ciphertexts per workgroup.  Variant 5 (2^64 torus: the
     wave-pair kernel whose exact limb products go through the folded complex FFT, bmi_kernels_t64f.hip) must return the same
@@ -171,7 +172,7 @@ def test_blind_rotate_every_kernel_variant(eng, ora, variant):
     small = ctx.keyswitch(eng.encrypt(msgs, eng.delta_log()))
     small = np.concatenate([small, rand_q(rng, (1, 631), eng.modulus)])
     sel = np.array([0, 1, 0, 1, 0, 1, 1], np.uint32)
-    if variant == 5 and eng.q_bits != 65:
+    if variant in (5, 6) and eng.q_bits != 65:
         from bmi_amd import tfhe
         with pytest.raises(tfhe.BmiError):
             eng.set_kernel_variant(variant)
