@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — PBS throughput of the MI355X-native TFHE engine (BASELINE.json metric "PBS/sec per GPU").
 
-`value` = whole-job PBS/s (the first half of BASELINE.json's metric); the encrypted-inverse wall-clocks (the second
-half) are reported under config.encrypted_inverse_wall_clock at N = 1.
+`value` = whole-job PBS/s (the first half of BASELINE.json's metric) on the 2^64 TORUS, the ciphertext modulus Concrete - the
+reference's back end - computes on (since round 3 the fastest modulus here as well: exact limb products through an f64 FFT);
+the encrypted-inverse wall-clocks (the second half) are reported under config.encrypted_inverse_wall_clock* at N = 1.
 
 One "step" = one pass of the hot path (keyswitch -> mod-switch -> blind rotation -> sample extraction)
 over one batch of B synthetic ciphertexts per GPU, inputs already resident in HBM, at the north-star
@@ -21,9 +22,9 @@ no-reuse convention, against peak HBM bandwidth) for the dominant kernel (blind 
 duration is measured live with events on the launch stream; `alu` adds the vector-ALU view the path is
 really bound by.  `cpu_baseline` times the oracle's fast path (exact f64 arithmetic, vectorised 32 x 32
 transforms, OpenMP over the batch; bit-identical to the generic oracle, re-checked on a sample inside the run) on this
-box's host cores, on a bounded sample of the same ciphertexts (N=1, rank 0 only).  `torus64` / `torus64_unrolled_key` repeat the
-batch on the 2^64 torus, Concrete's own ciphertext modulus (top-level value_torus64 / frac_torus64 / value_torus64_unrolled ...);
-`unrolled_key_49` and `roofline_q64_goldilocks` on the unrolled 49-bit key and on the Goldilocks field;
+box's host cores, on a bounded sample of the same ciphertexts (N=1, rank 0 only).  `p49_field` / `torus64_unrolled_key` /
+`unrolled_key_49` / `roofline_q64_goldilocks` repeat the batch on the 49-bit prime field (rounds 1-2's headline: top-level
+value_p49 / frac_p49 ...), with the unrolled keys, and on the Goldilocks field; value_torus64 / frac_torus64 repeat the headline;
 `config.output_noise` compares the timed outputs' noise with the analytic CGGI variance; `roofline.alu` states the fraction of
 the vector-ALU issue roof (static instruction counts x live rate / 1,024 SIMDs x sampled shader clock).
 """
@@ -147,8 +148,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--q-bits", type=int, default=None, choices=[64, 49, 65],
-                    help="ciphertext modulus: 49 = 2^49-720895 (f64 kernels, the default), 65 = 2^64 exactly (Concrete's "
-                         "torus; exact products through limb-split f64 transforms), 64 = 2^64-2^32+1 (integer kernels)")
+                    help="ciphertext modulus of the headline: 65 = 2^64 exactly (Concrete's torus; exact limb products through an f64 "
+                         "FFT; the default), 49 = 2^49-720895 (exact f64 transform mod p), 64 = 2^64-2^32+1 (integer kernels); "
+                         "given explicitly, the extra legs on the other moduli are skipped")
     ap.add_argument("--no-inverse", action="store_true", help="skip the encrypted-inverse wall-clock leg")
     ap.add_argument("--no-readme-benchmark", action="store_true",
                     help="skip the reference's README benchmark configurations (2x2 / 3x3 low precision, ~20 s with cold compiles)")
@@ -192,7 +194,8 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    eng = tfhe.Engine(tfhe.default_params(q_bits=args.q_bits), device=dev_index)
+    headline_q = tfhe.TORUS64 if args.q_bits is None else args.q_bits
+    eng = tfhe.Engine(tfhe.default_params(q_bits=headline_q), device=dev_index)
     eng.keygen(0x5EED)  # keys replicated on every GPU (same seed)
     P = eng.P
     DL = eng.delta_log()
@@ -252,12 +255,13 @@ def main():
     want = np.where(lut_sel == 0, msgs, rnd_table[msgs + 8])
     verified = bool(np.array_equal(dec, want))
 
-    KERNEL = {64: "k_blind_rotate_tp<2>", 49: "k_blind_rotate_tpx49<13, 3, 15>", 65: "k_blind_rotate_t64<48, 3, 10>"}
+    KERNEL = {64: "k_blind_rotate_tp<2>", 49: "k_blind_rotate_tpx49<13, 3, 15>", 65: "k_blind_rotate_t64f<3, 10, false>"}
     ARITH = {64: "integers mod 2^64-2^32+1 in u64 (64-bit integer VALU)",
              49: "exact integers mod 2^49-720895 carried in f64 (FMA pairs); keyswitch: int8 matrix cores, int32 sums",
-             65: "ciphertexts mod 2^64 (Concrete's torus), Bg 2^10; exact external products: digit transforms mod 2^49-720895 in f64 "
-                 "against two 24-bit limbs of every key word (key stored at 48 bits of precision), recombined mod 2^64; keyswitch: "
-                 "int8 matrix cores"}
+             65: "ciphertexts mod 2^64 (Concrete's torus), Bg 2^10; exact external products: digit polynomials against two 24-bit limbs "
+                 "of every key word (key stored at 48 bits of precision) through a folded 512-point complex FFT in f64, every limb sum "
+                 "(an integer below 2^45, transform error below 2^-11) rounded to the nearest integer and recombined mod 2^64 - the same "
+                 "words as the oracle's integer arithmetic; keyswitch: int8 matrix cores"}
     DTYPE = {64: "u64", 49: "f64", 65: "u64/f64"}
 
     def key_weights(e):
@@ -343,7 +347,9 @@ def main():
                    "batch_per_gpu": B, "pbs_per_gpu_per_s": value / world, "verified_decrypt": verified,
                    "output_noise": output_noise(eng, out, want) if rank == 0 else None,
                    "derived_reference_pbs_per_s_64core_cpu": "35-69 (derived, BASELINE.md §1)"},
-        "roofline": {"bound": "hbm", "physical_bound": "valu issue (f64): see `alu`", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "physical_bound": ("f64 vector issue, LDS stores and L1 key intake together (each about half busy; DESIGN.md section 4): see `alu`"
+                                                       if eng.q_bits == 65 else "valu issue (f64): see `alu`"),
+                     "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "measured_hbm_frac": (None if traffic is None else traffic / (br_ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
                      "traffic_source": "profiled-static: rocprofv3 --pmc pass of this command, profiles/hbm_traffic.json "
@@ -356,6 +362,24 @@ def main():
                      "algorithmic_bytes_per_pbs": BSK_BYTES_PER_PBS,
                      "alu": alu},
     }
+
+    def latency_ms(e, d_small_x, d_ids_x, d_out_x, cnt):
+        e.blind_rotate(d_small_x, d_ids_x, cnt, d_out_x, stream)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            e.blind_rotate(d_small_x, d_ids_x, cnt, d_out_x, stream)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / 5
+
+    if rank == 0 and world == 1:
+        d_lat = torch.empty_like(d_out)   # (the timed outputs stay untouched: they are checked against the oracle below)
+        res["latency_ms_1"], res["latency_ms_256"] = (latency_ms(eng, d_small, d_ids, d_lat, c) for c in (1, 256))
+        del d_lat
+        if eng.q_bits == 65:   # the reference's own modulus is the headline: the fields rounds 2-3 asked for repeat it
+            res.update(value_torus64=value, frac_torus64=achieved_gbs / HBM_PEAK_GBS, alu_frac_torus64=alu.get("frac"),
+                       latency_ms_torus64=res["latency_ms_1"])
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # threads of the CPU baseline = the host cores this process may actually use (affinity mask, cgroup CPU quota),
@@ -473,15 +497,10 @@ def main():
                                       "unit": "SIMD issue cycles/s", "sclk_mhz": sm, "sclk_source": ss,
                                       "valu_instructions_per_step_per_wavefront": c["valu"]}
                 # latency of one bootstrap and of one full round of 256 (events around the kernel)
+                d_lat2 = torch.empty_like(d_out2)
                 for cnt in (1, 256):
-                    e2.blind_rotate(d_small2, d_ids2, cnt, d_out2, stream)
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    for _ in range(5):
-                        e2.blind_rotate(d_small2, d_ids2, cnt, d_out2, stream)
-                    b.record()
-                    torch.cuda.synchronize()
-                    rep[f"latency_ms_{cnt}"] = a.elapsed_time(b) / 5
+                    rep[f"latency_ms_{cnt}"] = latency_ms(e2, d_small2, d_ids2, d_lat2, cnt)
+                del d_lat2
                 if not args.no_cpu_baseline and (unroll or qb == 65):
                     # the oracle's blind rotation (plain or unrolled mode) on a few ciphertexts of the batch: bit for bit
                     from oracle import tfhe_oracle as to
@@ -504,8 +523,8 @@ def main():
                 e2.close()
 
         INV_FIELDS = ("len", "ints", "evaluate_s", "end_to_end_s", "ms_per_level", "pbs", "depth", "matches_plaintext_circuit")
-        legs = (("torus64", 65, False, False), ("torus64_unrolled_key", 65, True, True), ("unrolled_key_49", 49, True, True),
-                ("roofline_q64_goldilocks", 64, False, False))
+        legs = (("torus64", 65, False, False), ("p49_field", 49, False, True), ("torus64_unrolled_key", 65, True, True),
+                ("unrolled_key_49", 49, True, True), ("roofline_q64_goldilocks", 64, False, False))
         for name, qb, un, inv in legs:
             if qb == eng.q_bits and not un:
                 continue
@@ -521,6 +540,16 @@ def main():
             res["frac_torus64"] = res["torus64"]["frac"]
             res["alu_frac_torus64"] = res["torus64"].get("alu", {}).get("frac")
             res["latency_ms_torus64"] = res["torus64"]["latency_ms_1"]
+        if "kernel_ms" in res.get("p49_field", {}):
+            res["p49_field"]["key"] = ("the 49-bit prime field q = 2^49 - 720895 (rounds 1-2's headline): (l, Bg) = (3, 2^15), exact transform mod q "
+                                       "in f64; CGGI's plain blind rotation")
+            res["value_p49"] = res["p49_field"]["pbs_per_s"]
+            res["frac_p49"] = res["p49_field"]["frac"]
+            res["alu_frac_p49"] = res["p49_field"].get("alu", {}).get("frac")
+            res["latency_ms_p49"] = res["p49_field"]["latency_ms_1"]
+            inv = res["p49_field"].get("encrypted_inverse_wall_clock")
+            if isinstance(inv, dict):
+                res["config"]["encrypted_inverse_wall_clock_p49"] = {k: {f: v.get(f) for f in INV_FIELDS} for k, v in inv.items()}
         if "kernel_ms" in res.get("torus64_unrolled_key", {}):
             res["torus64_unrolled_key"]["key"] = ("the same set with the unrolled bootstrap key (1.5 x the plain key), two LWE coefficients per "
                                                   "step; key noise unchanged (2^-44): output noise 2^-22.7")

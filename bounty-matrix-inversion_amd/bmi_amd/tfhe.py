@@ -66,6 +66,7 @@ _SIGS = {
     "bmi_keyswitch_batch_host": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
     "bmi_blind_rotate_batch_host": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
     "bmi_negacyclic_mul_host": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
+    "bmi_fft_margin_host": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_double)],
     "bmi_sync": [C.c_void_p, C.c_void_p],
     "bmi_reserve": [C.c_void_p, C.c_uint32],
     "bmi_import_keys": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -490,6 +491,17 @@ class Engine:
         self._ck(self.lib.bmi_blind_rotate_batch_host(self.h, _ptr(small), _ptr(ids), small.shape[0], _ptr(out)),
                  "bmi_blind_rotate_batch_host")
         return out
+
+    def fft_margin_host(self, small, lut_ids):
+        """test hook (2^64 torus, 48-bit key in base 2^10): blind rotation by the floating-point-transform wave-pair kernel ->
+        (outputs, largest distance of a limb sum from the integer it was rounded to)"""
+        small = np.ascontiguousarray(small, dtype=np.uint64).reshape(-1, self.P.small)
+        ids = np.ascontiguousarray(lut_ids, dtype=np.uint32).reshape(-1)
+        out = np.zeros((small.shape[0], self.P.big), np.uint64)
+        dist = C.c_double(0.0)
+        self._ck(self.lib.bmi_fft_margin_host(self.h, _ptr(small), _ptr(ids), small.shape[0], _ptr(out), C.byref(dist)),
+                 "bmi_fft_margin_host")
+        return out, float(dist.value)
 
     def negacyclic_mul_host(self, a, b):
         a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, self.P.N)

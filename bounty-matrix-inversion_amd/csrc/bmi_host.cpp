@@ -1169,7 +1169,7 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
             return fail(c, -1, "kernel variant 5 needs the bootstrap key at 48 bits of precision in base 2^10 (the torus default)");
         if (c->d_bsk_fft && (c->variant == 0 || c->variant == 5)) {
             rc = bmit::launch_blind_rotate_fft(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_fft, c->d_tw_fft, d_out, count, c->P.n,
-                                               c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
+                                               c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, nullptr, (hipStream_t)stream);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }
         rc = bmit::launch_blind_rotate(d_small, d_lut_ids, (const u64 *)c->d_luts, (const double *)c->d_bsk,
@@ -1351,6 +1351,36 @@ int bmi_blind_rotate_batch_host(bmi_ctx *c, const uint64_t *small_in, const uint
     if (rc) return rc;
     HIP_OK(c, hipMemcpyAsync(out, c->d_io_b, (size_t)count * (c->big_n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bmi_fft_margin_host(bmi_ctx *c, const uint64_t *small_in, const uint32_t *lut_ids, uint32_t count, uint64_t *out,
+                        double *max_distance) {
+    if (!c || !small_in || !lut_ids || !out || !max_distance) return -1;
+    if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
+    if (!c->d_bsk_fft)
+        return fail(c, -1, "the floating-point-transform kernels exist on the 2^64 torus with the bootstrap key at 48 bits in base 2^10");
+    if (int bad = check_lut_ids(c, lut_ids, count)) return bad;
+    HIP_OK(c, hipSetDevice(c->device));
+    int rc = ensure_io(c, count);
+    if (rc) return rc;
+    rc = ensure_small(c, count);
+    if (rc) return rc;
+    unsigned long long *d_stat = nullptr;
+    HIP_OK(c, hipMalloc(&d_stat, 8));
+    hipError_t e = hipMemsetAsync(d_stat, 0, 8, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_small, small_in, (size_t)count * (c->P.n + 1) * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_io_ids, lut_ids, count * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = (hipError_t)bmit::launch_blind_rotate_fft(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_fft, c->d_tw_fft, c->d_io_b,
+                                                      count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, d_stat, c->stream);
+    unsigned long long bits = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(out, c->d_io_b, (size_t)count * (c->big_n + 1) * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&bits, d_stat, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_stat);
+    if (e != hipSuccess) return fail(c, -2, std::string("bmi_fft_margin_host: ") + hipGetErrorString(e));
+    std::memcpy(max_distance, &bits, 8);
     return 0;
 }
 

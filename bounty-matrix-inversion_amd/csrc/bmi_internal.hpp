@@ -179,9 +179,10 @@ int launch_blind_rotate_lat2u(const u64 *small_cts, const uint32_t *lut_ids, con
 // [poly][limb][8 registers][64 lanes] complex words; tables fftw::TW_WORDS doubles; same results as launch_blind_rotate
 bool shape_supported_fft(int prec, uint32_t levels, uint32_t base_log);
 int launch_bsk_to_fft(const u64 *std_polys, double *limb_polys, const double *g_tw_fft, uint32_t n_polys, int prec, hipStream_t s);
+// stat (may be null): receives, as the bit pattern of a double, the largest distance of a limb sum from the integer it was rounded to
 int launch_blind_rotate_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
                             const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
-                            uint32_t base_log, hipStream_t s);
+                            uint32_t base_log, unsigned long long *stat, hipStream_t s);
 // latency form (one workgroup of 8 wavefronts per ciphertext) on the same key copy
 int launch_blind_rotate_lat_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
                                 const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,

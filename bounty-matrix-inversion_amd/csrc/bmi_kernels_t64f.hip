@@ -60,11 +60,12 @@ __global__ void __launch_bounds__(256) k_bsk_to_fft_t64(const u64 *__restrict__ 
     static_for<0, 8>([&](auto Cc) { dst[Cc * 64 + lane] = double2{x[Cc], x[Cc + 8]}; });
 }
 
-template <int L, int BG>
+// STATS (the test hook bmi_fft_margin_host): also records the largest distance of a limb sum from the integer it is rounded to
+template <int L, int BG, bool STATS = false>
 __global__ void __launch_bounds__(128 * TF_CTS)
     k_blind_rotate_t64f(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids, const u64 *__restrict__ luts,
                         const double *__restrict__ bsk, const double *__restrict__ g_tw, u64 *__restrict__ out,
-                        uint32_t count, uint32_t n) {
+                        uint32_t count, uint32_t n, unsigned long long *__restrict__ stat) {
     constexpr int CTS = TF_CTS;
     constexpr int LIMBS = Scheme<48>::LIMBS, LB = Scheme<48>::BITS, PRE = Scheme<48>::PRE, AB = 64 - PRE;
     // a limb's sum: 2 L N terms of |digit| <= 2^(BG-1) times |limb| <= 2^(LB-1) - the transform's error bound is stated for this size
@@ -107,6 +108,7 @@ __global__ void __launch_bounds__(128 * TF_CTS)
     }
 
     uint32_t hand = 0;   // handshake counter of the pair (one per inverse transform)
+    double dev = 0.0;    // STATS: largest |value - nearest integer| this lane has rounded away
     for (uint32_t i = 0; i < n; i++) {
 #if BMI_T64F_RESYNC
         if (i % BMI_T64F_RESYNC == 0) __syncthreads();
@@ -210,6 +212,7 @@ __global__ void __launch_bounds__(128 * TF_CTS)
                 // the limb's exact integer result (|.| < 2^45: nearest integer of the transform's output), shifted into place
                 static_for<0, 16>([&](auto J) {
                     double x = __builtin_rint(acc[J]);
+                    if constexpr (STATS) dev = __builtin_fmax(dev, __builtin_fabs(acc[J] - x));
                     if constexpr (j > 0) {
                         // x 2^(LB j) mod 2^AB: only the low AB - LB j bits of the limb's integer survive the shift
                         constexpr double W = (double)(1ull << (AB - LB * j));
@@ -224,6 +227,7 @@ __global__ void __launch_bounds__(128 * TF_CTS)
         });
     }
 
+    if constexpr (STATS) atomicMax(stat, (unsigned long long)__double_as_longlong(dev));   // non-negative doubles order like their bit patterns
     if (!live) return;
     wave_sync();
     u64 *o = out + (size_t)ct * (N + 1);
@@ -405,15 +409,15 @@ int launch_bsk_to_fft(const u64 *std_polys, double *limb_polys, const double *g_
     return 0;
 }
 
-template <int L, int BG>
+template <int L, int BG, bool STATS>
 static int launch_t64f(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
-                       const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+                       const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, unsigned long long *stat, hipStream_t s) {
     static std::atomic<uint64_t> configured{0};
     const size_t lds = (size_t)TF_LDS_WORDS * sizeof(double);
-    auto kern = k_blind_rotate_t64f<L, BG>;
+    auto kern = k_blind_rotate_t64f<L, BG, STATS>;
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
     hipLaunchKernelGGL(kern, dim3((count + TF_CTS - 1) / TF_CTS), dim3(128 * TF_CTS), lds, s, small_cts, lut_ids, luts, bsk_fft,
-                       g_tw_fft, out, count, n);
+                       g_tw_fft, out, count, n, stat);
     BMITF_LAUNCH_CHECK();
     return 0;
 }
@@ -441,11 +445,15 @@ int launch_blind_rotate_lat_fft(const u64 *small_cts, const uint32_t *lut_ids, c
 
 int launch_blind_rotate_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
                             const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
-                            uint32_t base_log, hipStream_t s) {
+                            uint32_t base_log, unsigned long long *stat, hipStream_t s) {
     if (count == 0) return 0;
     if (!shape_supported_fft(prec, levels, base_log)) return (int)hipErrorInvalidValue;
-    if (levels == 3) return launch_t64f<3, 10>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, s);
-    return launch_t64f<2, 10>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, s);
+    if (stat) {
+        if (levels == 3) return launch_t64f<3, 10, true>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, stat, s);
+        return launch_t64f<2, 10, true>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, stat, s);
+    }
+    if (levels == 3) return launch_t64f<3, 10, false>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, nullptr, s);
+    return launch_t64f<2, 10, false>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, nullptr, s);
 }
 
 }  // namespace bmit
