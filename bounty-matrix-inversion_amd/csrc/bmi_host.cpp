@@ -21,6 +21,7 @@
 #include "ntt_wave.hpp"
 #include "ntt_half_f64.hpp"
 #include "ntt_wave_f64.hpp"
+#include "fft_half_f64.hpp"
 #include "fft_wave_f64.hpp"
 #include "t64_common.hpp"
 
@@ -196,6 +197,7 @@ struct bmi_ctx {
     void *d_bsk = nullptr, *d_tw = nullptr, *d_luts = nullptr;  // u64 words (Goldilocks) or f64 words (49-bit field)
     double *d_tw_half = nullptr, *d_bsk_lat = nullptr;          // 49-bit field: tables and key copy of the split-transform latency kernel
     double *d_tw_fft = nullptr, *d_bsk_fft = nullptr;           // 2^64 torus, key at 48 bits: tables and key copy of the floating-point-transform wave-pair kernel (bmi_kernels_t64f.hip)
+    double *d_tw_fh = nullptr, *d_bsk_latf = nullptr;           // ... and of its latency form (half transforms, fft_half_f64.hpp; key in slot-pair order)
     double *d_tw_wide = nullptr;                                // N = 2048: T / T^-1 of the even/odd combination (d_bsk_lat then holds the wide key copy)
     // bootstrap-key unrolling (49-bit field at N = 1024 / 2048, 2^64 torus; bmi_set_bsk_unroll): per pair of LWE coefficients the GGSW encryptions of
     // s s', s (1 - s'), (1 - s) s'; host copy in the standard domain, device copy in the slot order of the latency kernel
@@ -486,6 +488,11 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
         if (hipMalloc(&c->d_tw_fft, tf.size() * 8) != hipSuccess) return bail("hipMalloc(fft twiddles) failed");
         if (hipMemcpy(c->d_tw_fft, tf.data(), tf.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(fft twiddles) failed");
+        std::vector<double> th(ffth::HT_WORDS);
+        ffth::build_tables(th.data());
+        if (hipMalloc(&c->d_tw_fh, th.size() * 8) != hipSuccess) return bail("hipMalloc(half-fft twiddles) failed");
+        if (hipMemcpy(c->d_tw_fh, th.data(), th.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+            return bail("hipMemcpy(half-fft twiddles) failed");
     }
     if ((c->f64() && !c->quad()) || c->t64()) {   // psi^x for the unrolled blind rotation (X^c at the root psi^e is psi^(e c))
         // N = 1024: psi = psi_2048, x in [0, 2048).  N = 2048: psi = psi_4096, x in [0, 2048) (the upper half is the negative)
@@ -518,7 +525,7 @@ void bmi_ctx_destroy(bmi_ctx *c) {
                     (void *)c->d_io_a, (void *)c->d_io_b, (void *)c->d_io_ids, c->d_ks_partial,
                     (void *)c->d_ks_limbs, (void *)c->d_ks_digits, (void *)c->d_ks_sums, (void *)c->d_tw_half,
                     (void *)c->d_bsk_lat, (void *)c->d_tw_wide, (void *)c->d_bsk3_lat, (void *)c->d_root_pow,
-                    (void *)c->d_tw_fft, (void *)c->d_bsk_fft})
+                    (void *)c->d_tw_fft, (void *)c->d_bsk_fft, (void *)c->d_tw_fh, (void *)c->d_bsk_latf})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -766,6 +773,7 @@ int upload_eval_keys(bmi_ctx *c) {
         // third copy where the floating-point transform carries the exact products (48-bit key, base 2^10): the wave-pair
         // kernel of bmi_kernels_t64f.hip, same results at ~half the instructions
         if (c->d_bsk_fft) { (void)hipFree(c->d_bsk_fft); c->d_bsk_fft = nullptr; }
+        if (c->d_bsk_latf) { (void)hipFree(c->d_bsk_latf); c->d_bsk_latf = nullptr; }
         if (c->d_tw_fft && bmit::shape_supported_fft(c->bsk_prec, P.bs_levels, P.bs_base_log)) {
             if (hipMalloc(&c->d_bsk_fft, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) {
                 (void)hipFree(d_tmp);
@@ -773,6 +781,12 @@ int upload_eval_keys(bmi_ctx *c) {
             }
             rc = bmit::launch_bsk_to_fft(d_tmp, c->d_bsk_fft, c->d_tw_fft, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
             if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_fft (torus) launch failed"); }
+            if (hipMalloc(&c->d_bsk_latf, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) {
+                (void)hipFree(d_tmp);
+                return fail(c, -2, "hipMalloc(torus fft latency-kernel key) failed");
+            }
+            rc = bmit::launch_bsk_to_latf(d_tmp, c->d_bsk_latf, c->d_tw_fh, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
+            if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_latf (torus) launch failed"); }
         }
     } else if (c->wide() || c->quad()) {  // N = 2048 / 4096: one key copy, in the slot order of k_blind_rotate_wide49 / quad49
         if (!c->d_bsk_lat && hipMalloc(&c->d_bsk_lat, bsk_words * 8) != hipSuccess) {
@@ -1154,7 +1168,7 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
         if (c->variant == 6 && !c->d_bsk_fft)
             return fail(c, -1, "kernel variant 6 needs the bootstrap key at 48 bits of precision in base 2^10 (the torus default)");
         if (lat_t && c->d_bsk_fft && c->variant != 4) {   // latency form through the floating-point transform (variant 4 pins the exact one)
-            rc = bmit::launch_blind_rotate_lat_fft(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_fft, c->d_tw_fft, d_out, count,
+            rc = bmit::launch_blind_rotate_lat_fft(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_latf, c->d_tw_fh, d_out, count,
                                                    c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }

@@ -183,7 +183,9 @@ int launch_bsk_to_fft(const u64 *std_polys, double *limb_polys, const double *g_
 int launch_blind_rotate_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
                             const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
                             uint32_t base_log, unsigned long long *stat, hipStream_t s);
-// latency form (one workgroup of 8 wavefronts per ciphertext) on the same key copy
+// latency form (one workgroup of 16 wavefronts per ciphertext, half transforms: fft_half_f64.hpp): own key copy, per (polynomial,
+// limb) 256 slots of [F_k, F_{k+256}]; tables ffth::HT_WORDS doubles
+int launch_bsk_to_latf(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, int prec, hipStream_t s);
 int launch_blind_rotate_lat_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
                                 const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
                                 uint32_t base_log, hipStream_t s);

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bmi_internal.hpp"
+#include "fft_half_f64.hpp"
 #include "fft_wave_f64.hpp"
 #include "pair_sync.hpp"
 #include "t64_common.hpp"
@@ -244,34 +245,79 @@ __global__ void __launch_bounds__(128 * TF_CTS)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// LATENCY form: one workgroup of 8 wavefronts per ciphertext, three phases per CMUX separated by workgroup barriers
-//   A  wavefronts 0 .. 2L-1 = (input polynomial c, level): rotate / decompose the u64 accumulator (integer rule of the oracle),
-//      whole forward transform -> tile, evaluation layout
-//   B  all 512 threads = (output polynomial o, two complex slots): per limb the sum over the 2L rows of digit x key; the key
-//      words of the whole step (2L rows x 2 limbs x 2 slots, one 16-byte word each, the SAME key copy as the wave-pair kernel)
-//      are requested before phase A and land under it
-//   C  wavefronts 0 .. 3 = (limb, o): inverse transform, nearest integer, shift into place and ONE LDS atomic add per coefficient
-//      into the accumulator (the two limbs of a coefficient meet there)
-constexpr int LF_THREADS = 512;
+// LATENCY form: one workgroup of 16 wavefronts per ciphertext, every transform split over TWO wavefronts by parity
+// (fft_half_f64.hpp: 256-point halves whose lane exchanges are register swaps and DPP moves - no LDS round trip inside a
+// transform); three phases per CMUX separated by workgroup barriers
+//   A  wavefronts 0 .. 4L-1 = (input polynomial c, level, parity h): rotate / decompose 512 coefficients of the u64 accumulator
+//      (integer rule of the oracle), forward half -> tile (slot order)
+//   B  all 1,024 threads = (limb j, output polynomial o, slot q): E + O' and E - O' of the 2L digit transforms, the two complex
+//      multiply-accumulates per row against this thread's key words (own key copy: per slot the pair F_k, F_{k+256} side by
+//      side; requested before phase A, landing under it), then the sum and the twisted difference for the inverse halves
+//   C  wavefronts 0 .. 7 = (limb, o, parity): inverse half, nearest integer, shift into place and ONE LDS atomic add per
+//      coefficient into the accumulator (the two limbs of a coefficient meet there)
+constexpr int LF_THREADS = 1024;
 constexpr int LF_MAX_L = 3;
-constexpr int LF_LDS_WORDS = TW_WORDS + 2 * N + 2 * LF_MAX_L * SCRATCH_WORDS + 2 * 2 * N + BMI_AT_WORDS;
+constexpr int LF_HALF = N / 2;
+constexpr int LF_LDS_WORDS = ffth::HT_WORDS + 2 * N + 2 * LF_MAX_L * N + 2 * 2 * N + BMI_AT_WORDS;
 static_assert(LF_LDS_WORDS <= BMI_LDS_WORDS_MAX, "LF_LDS_WORDS exceeds the 160 KB of LDS");
+
+// accumulator words are kept split by parity (a lane's four points are 128 coefficients apart and of one parity)
+__device__ __forceinline__ uint32_t acc_slot(uint32_t n) { return (n & 1) * LF_HALF + (n >> 1); }
+
+// standard-domain GGSW polynomials -> per (polynomial, limb) 256 slots of [F_k, F_{k+256}] (k = ffth::slot_freq of the slot)
+__global__ void __launch_bounds__(256) k_bsk_to_latf_t64(const u64 *__restrict__ std_polys, double *__restrict__ lat_polys,
+                                                         const double *__restrict__ g_tw_h, uint32_t n_polys, int prec) {
+    const int limbs = t64::limbs_of(prec);
+    __shared__ double lds[ffth::HT_WORDS + 4 * LF_HALF];
+    for (int i = threadIdx.x; i < ffth::HT_WORDS; i += blockDim.x) lds[i] = g_tw_h[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = wave & 1;
+    const uint32_t item = blockIdx.x * 2 + (wave >> 1);   // (polynomial, limb): two per workgroup, two wavefronts each
+    const bool ok = item < n_polys * (uint32_t)limbs;
+    const uint32_t poly = ok ? item / limbs : 0;
+    const int j = ok ? (int)(item % limbs) : 0;
+    double2 *tile = reinterpret_cast<double2 *>(lds + ffth::HT_WORDS + wave * LF_HALF);   // 256 complex per wavefront
+    if (ok) {
+        double re[4], im[4];
+        static_for<0, 4>([&](auto R) {
+            const uint32_t m = 2 * (lane + 64 * R) + h;
+            re[R] = (double)t64::limb_of((i64)std_polys[(size_t)poly * N + m], j, prec);
+            im[R] = (double)t64::limb_of((i64)std_polys[(size_t)poly * N + m + 512], j, prec);
+        });
+        ffth::C v[4];
+        if (h) ffth::forward_half<1>(re, im, v, lane, lds);
+        else ffth::forward_half<0>(re, im, v, lane, lds);
+        static_for<0, 4>([&](auto R) { tile[R * 64 + lane] = double2{v[R].r, v[R].i}; });
+    }
+    __syncthreads();
+    if (ok) {
+        const double2 *te = reinterpret_cast<const double2 *>(lds + ffth::HT_WORDS + (wave & ~1) * LF_HALF), *to = te + LF_HALF / 2;
+        double2 *o = reinterpret_cast<double2 *>(lat_polys + (size_t)item * N);
+        static_for<0, 2>([&](auto Q2) {
+            const int q = (h * 2 + Q2) * 64 + lane;
+            const double2 e = te[q], od = to[q];
+            o[2 * q] = double2{e.x + od.x, e.y + od.y};
+            o[2 * q + 1] = double2{e.x - od.x, e.y - od.y};
+        });
+    }
+}
 
 template <int L, int BG>
 __global__ void __launch_bounds__(LF_THREADS)
     k_blind_rotate_lat_t64f(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids, const u64 *__restrict__ luts,
-                            const double *__restrict__ bsk, const double *__restrict__ g_tw, u64 *__restrict__ out,
+                            const double *__restrict__ bsk_latf, const double *__restrict__ g_tw_h, u64 *__restrict__ out,
                             uint32_t count, uint32_t n) {
     constexpr int LIMBS = Scheme<48>::LIMBS, LB = Scheme<48>::BITS, PRE = Scheme<48>::PRE;
     static_assert(2.0 * L * N * (double)(1ull << (BG - 1)) * (double)(1ull << (LB - 1)) <= 0x1p45, "limb sums must stay below 2^45");
     static_assert(LIMBS == 2 && L <= LF_MAX_L, "two limbs, at most three levels");
     extern __shared__ double lds[];
-    u64 *acc = reinterpret_cast<u64 *>(lds + TW_WORDS);          // [2 components][N] words mod 2^64
-    double *tiles = lds + TW_WORDS + 2 * N;                      // [2L][SCRATCH_WORDS]
-    double *SD = tiles + 2 * LF_MAX_L * SCRATCH_WORDS;           // [limb][output][512 complex]
-    uint16_t *at = reinterpret_cast<uint16_t *>(SD + LIMBS * 2 * N);
+    u64 *acc = reinterpret_cast<u64 *>(lds + ffth::HT_WORDS);               // [2 components][2 parities][512] words mod 2^64
+    double2 *tiles = reinterpret_cast<double2 *>(lds + ffth::HT_WORDS + 2 * N);   // [2L rows][2 halves][256 slots] complex
+    double2 *SD = tiles + LF_MAX_L * N;                                     // [limb][output][S, D][256 slots] complex
+    uint16_t *at = reinterpret_cast<uint16_t *>(SD + 2 * N);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < TW_WORDS; i += LF_THREADS) lds[i] = g_tw[i];
+    for (int i = tid; i < ffth::HT_WORDS; i += LF_THREADS) lds[i] = g_tw_h[i];
     const uint32_t ct = blockIdx.x;
     const u64 *lwe = small_cts + (size_t)ct * (n + 1);
     for (uint32_t i = tid; i <= n; i += LF_THREADS) at[i] = (uint16_t)t64::modswitch<LOG_N + 1>(lwe[i]);
@@ -279,40 +325,39 @@ __global__ void __launch_bounds__(LF_THREADS)
     {
         const u64 *tv = luts + (size_t)(lut_ids[ct] & (BMI_LUT_CAP - 1)) * N;
         const uint32_t bt = at[n];
-        for (uint32_t nn = tid; nn < (uint32_t)N; nn += LF_THREADS) {
-            const uint32_t e = (nn + bt) & (2 * N - 1);
-            const u64 v = tv[e & (N - 1)];
-            acc[nn] = 0;
-            acc[N + nn] = (e & N) ? (u64)0 - v : v;
-        }
+        const uint32_t nn = tid;  // coefficient index
+        const uint32_t e = (nn + bt) & (2 * N - 1);
+        const u64 v = tv[e & (N - 1)];
+        acc[acc_slot(nn)] = 0;
+        acc[N + acc_slot(nn)] = (e & N) ? (u64)0 - v : v;
     }
     __syncthreads();
-    const int mo = tid >> 8, mq = tid & 255;   // phase B: output polynomial, first complex slot (the second is mq + 256)
+    const int mj = tid >> 9, mo = (tid >> 8) & 1, mq = tid & 255;   // phase B: limb, output polynomial, slot
 
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t a_t = at[i];
         if (a_t == 0) continue;  // uniform over the workgroup
-        // key words of this thread: [row 2L][output 2][limb][512 complex slots], the layout of k_bsk_to_fft_t64
-        const double *bi = bsk + (size_t)i * 4 * L * LIMBS * N;
-        double2 kw[2 * L][LIMBS][2];
+        // key words of this thread: [row 2L][output 2][limb][256 slots][F_k, F_{k+256}]
+        const double *bi = bsk_latf + (size_t)i * 4 * L * LIMBS * N;
+        double2 klo[2 * L], khi[2 * L];
         static_for<0, 2 * L>([&](auto R) {
-            static_for<0, LIMBS>([&](auto J) {
-                const double2 *row = reinterpret_cast<const double2 *>(bi + ((size_t)(R * 2 + mo) * LIMBS + J) * N);
-                kw[R][J][0] = row[mq];
-                kw[R][J][1] = row[mq + 256];
-            });
+            const double2 *row = reinterpret_cast<const double2 *>(bi + ((size_t)(R * 2 + mo) * LIMBS + mj) * N);
+            klo[R] = row[2 * mq];
+            khi[R] = row[2 * mq + 1];
         });
-        if (wave < 2 * L) {
-            const int c = wave / L, lev = wave % L;
+        if (wave < 4 * L) {
+            const int c = wave / (2 * L), lev = (wave % (2 * L)) >> 1, h = wave & 1;
             const u64 *ac = acc + c * N;
-            double x[16];
-            u64 vr[16], vs[16];
-            static_for<0, 16>([&](auto J) {
-                vr[J] = ac[(lane + 64 * J + 2 * N - a_t) & (N - 1)];
-                vs[J] = ac[lane + 64 * J];
+            double x[8];   // re[r] = x[r], im[r] = x[r + 4]
+            u64 vr[8], vs[8];
+            static_for<0, 8>([&](auto J) {
+                const uint32_t m = 2 * (lane + 64 * (J & 3)) + h + 512 * (J >> 2);
+                vr[J] = ac[acc_slot((m + 2 * N - a_t) & (N - 1))];
+                vs[J] = ac[acc_slot(m)];
             });
-            static_for<0, 16>([&](auto J) {
-                const uint32_t e = (lane + 64 * J + 2 * N - a_t) & (2 * N - 1);
+            static_for<0, 8>([&](auto J) {
+                const uint32_t m = 2 * (lane + 64 * (J & 3)) + h + 512 * (J >> 2);
+                const uint32_t e = (m + 2 * N - a_t) & (2 * N - 1);
                 const u64 v = (e & N) ? (u64)0 - vr[J] : vr[J];
                 double r = t64::rounded_top<L, BG>(v - vs[J]);                          // round half up to L BG bits
                 double d = r;                                                          // digit `lev`, balanced [-2^(BG-1), 2^(BG-1))
@@ -324,62 +369,60 @@ __global__ void __launch_bounds__(LF_THREADS)
                 }
                 x[J] = lev == 0 ? r : d;
             });
-            double *tile = tiles + wave * SCRATCH_WORDS;
-            forward(x, lane, lds, tile);
-            wave_sync();
-            static_for<0, 8>([&](auto Cc) { reinterpret_cast<double2 *>(tile)[Cc * 64 + lane] = double2{x[Cc], x[Cc + 8]}; });
+            const double re[4] = {x[0], x[1], x[2], x[3]}, im[4] = {x[4], x[5], x[6], x[7]};
+            ffth::C v[4];
+            if (h) ffth::forward_half<1>(re, im, v, lane, lds);
+            else ffth::forward_half<0>(re, im, v, lane, lds);
+            double2 *tile = tiles + (size_t)(wave >> 1) * LF_HALF + h * (LF_HALF / 2);
+            static_for<0, 4>([&](auto R) { tile[R * 64 + lane] = double2{v[R].r, v[R].i}; });
         }
         __syncthreads();
         {
-            double2 sum[LIMBS][2];
+            ffth::C ylo{0.0, 0.0}, yhi{0.0, 0.0};
             static_for<0, 2 * L>([&](auto R) {
-                const double2 *xt = reinterpret_cast<const double2 *>(tiles + R * SCRATCH_WORDS);
-                static_for<0, 2>([&](auto S) {
-                    const double2 xv = xt[mq + 256 * S];
-                    static_for<0, LIMBS>([&](auto J) {
-                        const double2 k = kw[R][J][S];
-                        if constexpr (R == 0) {
-                            sum[J][S].x = __builtin_fma(xv.x, k.x, -(xv.y * k.y));
-                            sum[J][S].y = __builtin_fma(xv.x, k.y, xv.y * k.x);
-                        } else {
-                            sum[J][S].x = __builtin_fma(xv.x, k.x, __builtin_fma(-xv.y, k.y, sum[J][S].x));
-                            sum[J][S].y = __builtin_fma(xv.x, k.y, __builtin_fma(xv.y, k.x, sum[J][S].y));
-                        }
-                    });
-                });
+                const double2 e = tiles[(size_t)R * LF_HALF + mq], od = tiles[(size_t)R * LF_HALF + LF_HALF / 2 + mq];
+                const double lr = e.x + od.x, li = e.y + od.y, hr = e.x - od.x, hi = e.y - od.y;
+                ylo.r = __builtin_fma(lr, klo[R].x, __builtin_fma(-li, klo[R].y, ylo.r));
+                ylo.i = __builtin_fma(lr, klo[R].y, __builtin_fma(li, klo[R].x, ylo.i));
+                yhi.r = __builtin_fma(hr, khi[R].x, __builtin_fma(-hi, khi[R].y, yhi.r));
+                yhi.i = __builtin_fma(hr, khi[R].y, __builtin_fma(hi, khi[R].x, yhi.i));
             });
-            static_for<0, LIMBS>([&](auto J) {
-                double2 *sd = reinterpret_cast<double2 *>(SD + (size_t)(J * 2 + mo) * N);
-                sd[mq] = sum[J][0];
-                sd[mq + 256] = sum[J][1];
-            });
+            const double2 w = reinterpret_cast<const double2 *>(lds + ffth::HT_W)[mq];
+            const ffth::C d = ffth::cmul<true>(ffth::C{ylo.r - yhi.r, ylo.i - yhi.i}, w.x, w.y);
+            double2 *sd = SD + (size_t)(mj * 2 + mo) * LF_HALF;
+            sd[mq] = double2{ylo.r + yhi.r, ylo.i + yhi.i};
+            sd[LF_HALF / 2 + mq] = double2{d.r, d.i};
         }
         __syncthreads();
-        if (wave < 2 * LIMBS) {
-            const int j = wave >> 1, o = wave & 1;
-            const double2 *sd = reinterpret_cast<const double2 *>(SD + (size_t)(j * 2 + o) * N);
-            double x[16];
-            static_for<0, 8>([&](auto Cc) {
-                const double2 t = sd[Cc * 64 + lane];
-                x[Cc] = t.x;
-                x[Cc + 8] = t.y;
+        if (wave < 4 * LIMBS) {
+            const int j = wave >> 2, o = (wave >> 1) & 1, h = wave & 1;
+            const double2 *sd = SD + (size_t)(j * 2 + o) * LF_HALF + h * (LF_HALF / 2);
+            ffth::C v[4];
+            static_for<0, 4>([&](auto R) {
+                const double2 t = sd[R * 64 + lane];
+                v[R] = ffth::C{t.x, t.y};
             });
-            inverse(x, lane, lds, tiles + wave * SCRATCH_WORDS);
+            double re[4], im[4];
+            if (h) ffth::inverse_half<1>(v, re, im, lane, lds);
+            else ffth::inverse_half<0>(v, re, im, lane, lds);
             unsigned long long *ao = reinterpret_cast<unsigned long long *>(acc + o * N);
             const int sh = PRE + LB * j;
-            static_for<0, 16>([&](auto J) {
-                // the limb's exact integer (|.| < 2^45: nearest integer of the transform's output), shifted into place
-                atomicAdd(ao + lane + 64 * J, (unsigned long long)(f64_to_word(__builtin_rint(x[J])) << sh));
+            static_for<0, 4>([&](auto R) {
+                // the limb's exact integers (|.| < 2^45: nearest integers of the transform's outputs), shifted into place
+                const uint32_t m = 2 * (lane + 64 * R) + h;
+                atomicAdd(ao + acc_slot(m), (unsigned long long)(f64_to_word(__builtin_rint(re[R])) << sh));
+                atomicAdd(ao + acc_slot(m + 512), (unsigned long long)(f64_to_word(__builtin_rint(im[R])) << sh));
             });
         }
         __syncthreads();
     }
     u64 *o = out + (size_t)ct * (N + 1);
-    for (uint32_t nn = tid; nn < (uint32_t)N; nn += LF_THREADS) {
-        const u64 a0 = acc[nn];
+    {
+        const uint32_t nn = tid;
+        const u64 a0 = acc[acc_slot(nn)];
         if (nn == 0) {
             o[0] = a0;
-            o[N] = acc[N];
+            o[N] = acc[N + acc_slot(0)];
         } else {
             o[N - nn] = (u64)0 - a0;
         }
@@ -418,6 +461,14 @@ static int launch_t64f(const u64 *small_cts, const uint32_t *lut_ids, const u64 
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
     hipLaunchKernelGGL(kern, dim3((count + TF_CTS - 1) / TF_CTS), dim3(128 * TF_CTS), lds, s, small_cts, lut_ids, luts, bsk_fft,
                        g_tw_fft, out, count, n, stat);
+    BMITF_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_bsk_to_latf(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, int prec, hipStream_t s) {
+    if (prec != 48) return (int)hipErrorInvalidValue;
+    const uint32_t items = n_polys * (uint32_t)t64::limbs_of(prec);
+    hipLaunchKernelGGL(k_bsk_to_latf_t64, dim3((items + 1) / 2), dim3(256), 0, s, std_polys, lat_polys, g_tw_h, n_polys, prec);
     BMITF_LAUNCH_CHECK();
     return 0;
 }
