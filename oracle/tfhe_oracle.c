@@ -832,12 +832,11 @@ F_CLONES static void f_ntt_inv(const ora_fctx *c, double *a) { /* input |.| <= 0
     for (uint32_t i = 0; i < N; i++) a[i] = f_mul(a[i], c->inv_N);
 }
 
-ora_fctx *ora_fctx_create(const ora_params *P, const u64 *bsk, const u64 *ksk) {
-    if (P->q_bits != 49) return NULL;
-    ora_set_field(49);
+/* transform tables of the 49-bit field (no keys); the caller has selected that field */
+static ora_fctx *f_tables_create(const ora_params *P) {
     ora_fctx *c = (ora_fctx *)calloc(1, sizeof *c);
     c->P = *P; c->N = 1u << P->log_N;
-    uint32_t N = c->N, n = P->n, k = P->k, lk = P->ks_levels;
+    uint32_t N = c->N;
     ntt_tab *t = ntt_make(P->log_N);
     c->psi_br = (double *)malloc(N * 8); c->ipsi_br = (double *)malloc(N * 8);
     for (uint32_t i = 0; i < N; i++) { c->psi_br[i] = f_center(t->psi_br[i]); c->ipsi_br[i] = f_center(t->ipsi_br[i]); }
@@ -869,6 +868,15 @@ ora_fctx *ora_fctx_create(const ora_params *P, const u64 *bsk, const u64 *ksk) {
                 c->twi[r * 32 + cc] = f_center(mulq(powq(ipsi, (u64)cc * leaf_e[r] % 2048), t->inv_N));
             }
     }
+    ntt_free(t);
+    return c;
+}
+
+ora_fctx *ora_fctx_create(const ora_params *P, const u64 *bsk, const u64 *ksk) {
+    if (P->q_bits != 49) return NULL;
+    ora_set_field(49);
+    ora_fctx *c = f_tables_create(P);
+    uint32_t N = c->N, n = P->n, k = P->k, lk = P->ks_levels;
     size_t polys = (size_t)n * (k + 1) * P->bs_levels * (k + 1);
     c->bsk = (double *)malloc(polys * N * 8);
 #pragma omp parallel for schedule(static)
@@ -881,7 +889,6 @@ ora_fctx *ora_fctx_create(const ora_params *P, const u64 *bsk, const u64 *ksk) {
     size_t kw = (size_t)k * N * lk * (n + 1);
     c->ksk_lo = (double *)malloc(kw * 8); c->ksk_hi = (double *)malloc(kw * 8);
     for (size_t i = 0; i < kw; i++) { c->ksk_lo[i] = (double)(ksk[i] & 0x1FFFFFFull); c->ksk_hi[i] = (double)(ksk[i] >> 25); }
-    ntt_free(t);
     return c;
 }
 void ora_fctx_destroy(ora_fctx *c) { if (!c) return; free(c->t1); free(c->t1i); free(c->t2); free(c->t2i); free(c->tw); free(c->twi); free(c->psi_br); free(c->ipsi_br); free(c->bsk); free(c->ksk_lo); free(c->ksk_hi); free(c); }
@@ -1021,6 +1028,168 @@ void ora_fast_pbs_batch(const ora_fctx *c, const u64 *in, const u64 *tvs, const 
             for (uint32_t i = 0; i < n; i++)
                 for (uint32_t g = 0; g < m; g++) f_br_step(c, s[g].small, i, &s[g]);
             for (uint32_t g = 0; g < m; g++) f_br_extract(c, &s[g], out + (size_t)(first + g) * big);
+        }
+        for (int g = 0; g < F_GROUP; g++) f_scratch_free(&s[g]);
+    }
+}
+
+/* ====================================================================== fast path (2^64 torus, 48-bit key) ====
+ * The CPU baseline of bench.py on the torus: the same PBS, same words as ora_pbs_batch on the same (rounded) key - held by
+ * tests/test_oracle_tfhe.py - with the arithmetic of the fast path above: bootstrap key stored at 48 bits of precision as two
+ * balanced 24-bit limbs, digits in base 2^10 (|d| <= 2^9), every limb sum an integer below p / 2 = 2^48 computed EXACTLY mod
+ * p = 2^49 - 720895 in doubles (the route the GPU's exact-transform kernel k_blind_rotate_t64 takes; the generic path above
+ * goes through Goldilocks transforms of the key's 32-bit halves), accumulator = word / 2^16 as an exact double centred mod
+ * 2^48.  Keyswitch: wrap-around u64 arithmetic. */
+typedef struct {
+    ora_fctx *f;     /* transform tables of the 49-bit field */
+    ora_params P;
+    double *bsk;     /* [n][rows][k+1][2 limbs][N] transform domain, centred */
+    u64 *ksk;        /* [kN*lk][n+1] words */
+} ora_tctx;
+
+static inline i64 t_limb(i64 kword, int j) { /* balanced 24-bit limbs of the 48-bit key word k / 2^16; the second takes the rest */
+    kword >>= 16;
+    const i64 d = ((kword + (1 << 23)) & ((1 << 24) - 1)) - (1 << 23);
+    return j == 0 ? d : (kword - d) >> 24;
+}
+static inline double t_mod48(double t) { /* centred residue mod 2^48 of an exact integer |t| < 2^53, ties to the negative end */
+    return __builtin_fma(-0x1p48, __builtin_floor(__builtin_fma(t, 0x1p-48, 0.5)), t);
+}
+static inline u64 t_word(double v) { return (u64)(i64)v << 16; } /* |v| < 2^48 exact integer -> torus word */
+
+ora_tctx *ora_tctx_create(const ora_params *P, const u64 *bsk, const u64 *ksk) {
+    if (P->q_bits != Q_TORUS64 || P->log_N != 10 || P->bs_base_log > 10 || P->bs_levels * P->bs_base_log >= 48) return NULL;
+    size_t polys = (size_t)P->n * (P->k + 1) * P->bs_levels * (P->k + 1), N = (size_t)1 << P->log_N;
+    for (size_t i = 0; i < polys * N; i++) if (bsk[i] & 0xFFFF) return NULL;   /* the key must be the 48-bit (rounded) one */
+    ora_tctx *c = (ora_tctx *)calloc(1, sizeof *c);
+    c->P = *P;
+    ora_set_field(49);
+    c->f = f_tables_create(P);
+    c->bsk = (double *)malloc(polys * 2 * N * 8);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < polys * 2; i++) {
+        double *d = c->bsk + i * N;
+        const u64 *src = bsk + (i >> 1) * N;
+        for (size_t x = 0; x < N; x++) d[x] = (double)t_limb((i64)src[x], (int)(i & 1));
+        f_ntt_fwd(c->f, d);
+        for (size_t x = 0; x < N; x++) d[x] = f_red(d[x]);
+    }
+    ora_set_field(Q_TORUS64);
+    size_t kw = (size_t)P->k * N * P->ks_levels * (P->n + 1);
+    c->ksk = (u64 *)malloc(kw * 8);
+    memcpy(c->ksk, ksk, kw * 8);
+    return c;
+}
+void ora_tctx_destroy(ora_tctx *c) { if (!c) return; ora_fctx_destroy(c->f); free(c->bsk); free(c->ksk); free(c); }
+
+F_CLONES static void t_keyswitch(const ora_tctx *c, const u64 *in, u64 *out) {
+    const ora_params *P = &c->P;
+    uint32_t n = P->n, kN = P->k << P->log_N, lk = P->ks_levels;
+    i64 dig[64];
+    for (uint32_t x = 0; x <= n; x++) out[x] = 0;
+    for (uint32_t j = 0; j < kN; j++) {
+        ora_decompose(in[j], lk, P->ks_base_log, dig);
+        for (uint32_t lev = 0; lev < lk; lev++) {
+            if (!dig[lev]) continue;
+            const u64 d = (u64)dig[lev];
+            const u64 *row = c->ksk + ((size_t)j * lk + lev) * (n + 1);
+            for (uint32_t x = 0; x <= n; x++) out[x] -= d * row[x];   /* mod 2^64 */
+        }
+    }
+    out[n] += in[kN];
+}
+static void t_br_init(const ora_tctx *c, const u64 *lwe, const u64 *tv, f_scratch *s) {
+    const ora_params *P = &c->P;
+    uint32_t n = P->n, N = 1u << P->log_N, k = P->k;
+    uint32_t bt = ora_modswitch(lwe[n], P->log_N + 1);
+    for (uint32_t x = 0; x < (k + 1) * N; x++) s->acc[x] = 0.0;
+    for (uint32_t j = 0; j < N; j++) { /* X^(-bt) * tv; test polynomials are multiples of 2^16 */
+        uint32_t pos = (j + 2 * N - bt) & (2 * N - 1);
+        double v = (double)((i64)tv[j] >> 16);
+        if (pos < N) s->acc[(size_t)k * N + pos] = v; else s->acc[(size_t)k * N + pos - N] = t_mod48(-v);
+    }
+}
+F_CLONES static void t_br_step(const ora_tctx *c, const u64 *lwe, uint32_t i, f_scratch *s) {
+    const ora_params *P = &c->P;
+    uint32_t N = 1u << P->log_N, k = P->k, l = P->bs_levels, rows = (k + 1) * l;
+    const double sc = 1.0 / (double)((u64)1 << (48 - l * P->bs_base_log)), B = (double)((u64)1 << P->bs_base_log), Binv = 1.0 / B;
+    double *acc = s->acc, *dec = s->dec, *res = s->res;
+    uint32_t at = ora_modswitch(lwe[i], P->log_N + 1);
+    if (at == 0) return;
+    for (uint32_t comp = 0; comp <= k; comp++) {
+        const double *a = acc + (size_t)comp * N;
+        double *d0 = dec + (size_t)comp * l * N, *rot = res;
+        {
+            const uint32_t b = at & (N - 1);
+            const double sg = at < N ? 1.0 : -1.0;
+            for (uint32_t x = 0; x < b; x++) rot[x] = -sg * a[x + N - b];
+            for (uint32_t x = b; x < N; x++) rot[x] = sg * a[x - b];
+        }
+        /* the oracle's rule on the 64-bit word (ora_decompose): centred, rounded half up to its top l * Bg bits - here on word / 2^16 */
+        for (uint32_t x = 0; x < N; x++) d0[x] = __builtin_floor(__builtin_fma(t_mod48(rot[x] - a[x]), sc, 0.5));
+        for (int lev = (int)l - 1; lev >= 1; lev--) {
+            double *dl_ = d0 + (size_t)lev * N;
+            for (uint32_t x = 0; x < N; x++) {
+                double r = d0[x], rn = __builtin_floor(__builtin_fma(r, Binv, 0.5));
+                dl_[x] = __builtin_fma(-B, rn, r);
+                d0[x] = rn;
+            }
+        }
+    }
+    for (uint32_t r = 0; r < rows; r++) {
+        double *d = dec + (size_t)r * N;
+        f_ntt_fwd(c->f, d);
+        for (uint32_t x = 0; x < N; x++) d[x] = f_red(d[x]);
+    }
+    const double *g = c->bsk + (size_t)i * rows * (k + 1) * 2 * N;
+    for (uint32_t oc = 0; oc <= k; oc++)
+        for (int j = 0; j < 2; j++) {
+            double *o = res;
+            for (uint32_t x = 0; x < N; x++) o[x] = 0.0;
+            for (uint32_t r = 0; r < rows; r++) {
+                const double *b = g + (((size_t)r * (k + 1) + oc) * 2 + j) * N, *d = dec + (size_t)r * N;
+                for (uint32_t x = 0; x < N; x++) o[x] += f_mul(d[x], b[x]);
+            }
+            for (uint32_t x = 0; x < N; x++) o[x] = f_red(o[x]);
+            f_ntt_inv(c->f, o);
+            double *a = acc + (size_t)oc * N;
+            if (j == 0) for (uint32_t x = 0; x < N; x++) a[x] = t_mod48(a[x] + f_red(o[x]));   /* the limb's exact integer, |.| < p / 2 */
+            else for (uint32_t x = 0; x < N; x++) {
+                double v = f_red(o[x]);
+                v = __builtin_fma(-0x1p24, __builtin_rint(v * 0x1p-24), v);                    /* x 2^24 mod 2^48: the low 24 bits survive */
+                a[x] = t_mod48(__builtin_fma(v, 0x1p24, a[x]));
+            }
+        }
+}
+static void t_br_extract(const ora_tctx *c, f_scratch *s, u64 *out) {
+    uint32_t N = 1u << c->P.log_N, k = c->P.k;
+    for (uint32_t j = 0; j < k; j++) {
+        const double *A = s->acc + (size_t)j * N;
+        out[(size_t)j * N] = t_word(A[0]);
+        for (uint32_t x = 1; x < N; x++) out[(size_t)j * N + x] = (u64)0 - t_word(A[N - x]);
+    }
+    out[(size_t)k * N] = t_word(s->acc[(size_t)k * N]);
+}
+/* same contract as ora_pbs_batch (ks_out optional); selects the torus */
+void ora_tfast_pbs_batch(const ora_tctx *c, const u64 *in, const u64 *tvs, const uint32_t *tv_ids, uint32_t count, u64 *out, u64 *ks_out) {
+    ora_set_field(Q_TORUS64);
+    uint32_t n = c->P.n, N = 1u << c->P.log_N, big = c->P.k * N + 1;
+    uint32_t groups = (count + F_GROUP - 1) / F_GROUP;
+#pragma omp parallel
+    {
+        f_scratch s[F_GROUP];
+        for (int g = 0; g < F_GROUP; g++) f_scratch_make(c->f, &s[g]);
+#pragma omp for schedule(dynamic, 1)
+        for (uint32_t gi = 0; gi < groups; gi++) {
+            const uint32_t first = gi * F_GROUP, m = count - first < F_GROUP ? count - first : F_GROUP;
+            for (uint32_t g = 0; g < m; g++) {
+                t_keyswitch(c, in + (size_t)(first + g) * big, s[g].small);
+                if (ks_out) memcpy(ks_out + (size_t)(first + g) * (n + 1), s[g].small, (n + 1) * 8);
+                t_br_init(c, s[g].small, tvs + (size_t)tv_ids[first + g] * N, &s[g]);
+            }
+            for (uint32_t i = 0; i < n; i++)
+                for (uint32_t g = 0; g < m; g++) t_br_step(c, s[g].small, i, &s[g]);
+            for (uint32_t g = 0; g < m; g++) t_br_extract(c, &s[g], out + (size_t)(first + g) * big);
         }
         for (int g = 0; g < F_GROUP; g++) f_scratch_free(&s[g]);
     }

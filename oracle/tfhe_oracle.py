@@ -93,6 +93,7 @@ def lib():
         _lib = C.CDLL(SO)
         _lib.ora_ctx_create.restype = C.c_void_p
         _lib.ora_fctx_create.restype = C.c_void_p
+        _lib.ora_tctx_create.restype = C.c_void_p
         _lib.ora_modswitch.restype = C.c_uint32
         _lib.ora_num_threads.restype = C.c_int
         _lib.ora_modulus.restype = C.c_uint64
@@ -262,20 +263,22 @@ class Ctx:
 
 
 class FastCtx:
-    """The CPU baseline of bench.py (49-bit field only): same PBS, same bits as Ctx.pbs, written for speed (f64 exact
-    arithmetic, vectorisable loops, no allocation per call).  tests/test_oracle_tfhe.py holds it to Ctx.pbs."""
+    """The CPU baseline of bench.py: same PBS, same bits as Ctx.pbs, written for speed (f64 exact arithmetic, vectorisable loops,
+    no allocation per call).  49-bit field, and the 2^64 torus at its default set (bootstrap key at 48 bits = two 24-bit limbs,
+    base 2^10: exact limb sums mod 2^49 - 720895).  tests/test_oracle_tfhe.py holds it to Ctx.pbs on both."""
 
     def __init__(self, P, bsk, ksk):
         self.P = P
         bsk, ksk = u64(bsk), u64(ksk)
-        h = lib().ora_fctx_create(C.byref(P), _p(bsk), _p(ksk))
+        self.torus = P.q_bits == TORUS64
+        h = (lib().ora_tctx_create if self.torus else lib().ora_fctx_create)(C.byref(P), _p(bsk), _p(ksk))
         if not h:
-            raise ValueError("the fast path exists for q_bits = 49 only")
+            raise ValueError("the fast path exists for q_bits = 49 and for the 2^64 torus with a 48-bit key in base <= 2^10 (N = 1024)")
         self.h = C.c_void_p(h)
 
     def close(self):
         if self.h:
-            lib().ora_fctx_destroy(self.h)
+            (lib().ora_tctx_destroy if self.torus else lib().ora_fctx_destroy)(self.h)
             self.h = None
 
     def __del__(self):
@@ -290,8 +293,8 @@ class FastCtx:
         ids = np.ascontiguousarray(tv_ids, dtype=np.uint32)
         out = np.zeros_like(cts)
         ks = np.zeros((cts.shape[0], self.P.n + 1), np.uint64) if want_ks else None
-        lib().ora_fast_pbs_batch(self.h, _p(cts), _p(tvs), _p(ids), C.c_uint32(cts.shape[0]), _p(out),
-                                 _p(ks) if want_ks else None)
+        (lib().ora_tfast_pbs_batch if self.torus else lib().ora_fast_pbs_batch)(
+            self.h, _p(cts), _p(tvs), _p(ids), C.c_uint32(cts.shape[0]), _p(out), _p(ks) if want_ks else None)
         return (out, ks) if want_ks else out
 
 

@@ -1,0 +1,74 @@
+"""CPU checks of the index algebra of the two floating-point transforms of the 2^64-torus kernels, on their numpy models
+(tools/fft_wave_model.py = csrc/fft_wave_f64.hpp: 512 = 8 x 8 x 8 with two LDS exchanges; tools/fft_half_model.py =
+csrc/fft_half_f64.hpp: two 256-point halves, 4 x 4 x 4 x 4 with register / lane-bit transposes): forward against the definition
+A_k = sum_j (a_j + i a_{j+512}) zeta^j omega^(jk), round trip, and one CMUX-sized sum of products rounding to the exact integers.
+The HIP code follows the models step by step; tests/test_gpu_torus_fft.py holds the kernels to the oracle on the GPU."""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+
+
+def _definition(a):
+    j = np.arange(512)
+    ang = np.pi * (j.astype(np.longdouble)) / 1024
+    u = (a[:512] + 1j * a[512:]) * (np.cos(ang).astype(float) + 1j * np.sin(ang).astype(float))
+    return np.array([np.sum(u * np.exp(2j * np.pi * j * k / 512)) for k in range(512)])
+
+
+def _exact_negacyclic_sum(d, k):
+    n = d.shape[1]
+    acc = np.zeros(n, dtype=object)
+    for p in range(d.shape[0]):
+        full = np.convolve(d[p].astype(np.int64).astype(object), k[p].astype(np.int64).astype(object))
+        full = np.concatenate([full, np.zeros(2 * n - len(full), dtype=object)])
+        acc += full[:n] - full[n:2 * n]
+    return acc.astype(float)
+
+
+def test_wave_transform_model():
+    import fft_wave_model as m
+    rng = np.random.default_rng(1)
+    a = rng.integers(-512, 512, 1024).astype(float)
+    V = m.forward(a)
+    got = np.zeros(512, complex)
+    for c in range(8):
+        got[m.freq_of(c, m.LANES)] = V[c]
+    assert np.abs(got - _definition(a)).max() < 1e-6
+    assert np.abs(m.inverse(V) - a).max() < 1e-9
+    d = rng.integers(-512, 512, (6, 1024)).astype(float)
+    k = rng.integers(-(1 << 23), 1 << 23, (6, 1024)).astype(float)
+    acc = [np.zeros(64, complex) for _ in range(8)]
+    for p in range(6):
+        D, K = m.forward(d[p]), m.forward(k[p])
+        acc = [acc[c] + D[c] * K[c] for c in range(8)]
+    r = m.inverse(acc)
+    exact = _exact_negacyclic_sum(d, k)
+    assert np.all(np.rint(r) == exact) and np.abs(r - exact).max() < 2.0 ** -9
+
+
+def test_half_transform_model():
+    import fft_half_model as m
+    rng = np.random.default_rng(2)
+    a = rng.integers(-512, 512, 1024).astype(float)
+    assert np.abs(m.full_from_halves(a) - _definition(a)).max() < 1e-6
+    d = rng.integers(-512, 512, (6, 1024)).astype(float)
+    k = rng.integers(-(1 << 23), 1 << 23, (6, 1024)).astype(float)
+    Y = sum(m.full_from_halves(d[p]) * m.full_from_halves(k[p]) for p in range(6))
+    out = np.zeros(1024)
+    S, D = [None] * 4, [None] * 4
+    for r in range(4):
+        f = m.slot_freq(r, m.LANES)
+        S[r] = Y[f] + Y[f + 256]
+        D[r] = (Y[f] - Y[f + 256]) * np.conj(m.zeta_pow(4 * f))
+    for h, v in ((0, S), (1, D)):
+        w = m.inverse_half(v, h)
+        for r in range(4):
+            idx = 2 * (m.LANES + 64 * r) + h
+            out[idx] = w[r].real
+            out[idx + 512] = w[r].imag
+    exact = _exact_negacyclic_sum(d, k)
+    assert np.all(np.rint(out) == exact) and np.abs(out - exact).max() < 2.0 ** -9

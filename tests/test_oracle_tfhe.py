@@ -355,6 +355,42 @@ def test_fast_path_equals_generic_path(field49):
         to.FastCtx(to.default_params(q_bits=64, n=4), np.zeros((4, 6, 2, 1024), np.uint64), np.zeros((1024, 8, 5), np.uint64))
 
 
+def test_torus_fast_path_equals_generic_path():
+    """FastCtx on the 2^64 torus (48-bit key as two 24-bit limbs, exact limb sums mod 2^49 - 720895 in doubles, accumulator as
+    word / 2^16 in a double) against the generic path (Goldilocks transforms of the key's 32-bit halves, u64 accumulator) on the
+    same rounded key: identical words, keyswitch included; adversarial rows (random masks, extreme words, zeros)."""
+    to.set_field(to.TORUS64)
+    try:
+        for kw in (dict(n=20), dict(n=9, bs_levels=2, ks_levels=5, ks_base_log=6)):
+            P = to.default_params(q_bits=to.TORUS64, **kw)
+            assert P.bs_base_log == 10 and to.default_bsk_precision(P) == 48
+            K = to.keygen(P, 78)
+            bsk = to.round_key(K.bsk, 48)
+            slow, fast = to.Ctx(P, bsk, K.ksk), to.FastCtx(P, bsk, K.ksk)
+            dl = 59
+            tvs = np.stack([to.make_test_vector(10, 4, np.arange(-8, 8), dl), to.make_test_vector(10, 4, RNG.integers(-8, 8, 16), dl)])
+            msgs = RNG.integers(-8, 8, 11)                      # a full group of 8 and a ragged one
+            ct = to.lwe_encrypt(K.sk_big, P.glwe_noise, 78, 0, to.encode(msgs, dl))
+            ct[3, :1024] = RNG.integers(0, 1 << 63, 1024, dtype=np.uint64) * np.uint64(2) + RNG.integers(0, 2, 1024, dtype=np.uint64)
+            ct[4, :1024] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            ct[5, :] = 0
+            ct[6, :1024] = np.uint64(1 << 63)
+            ids = (np.arange(11) % 2).astype(np.uint32)
+            a, ka = slow.pbs(ct, tvs, ids, want_ks=True)
+            b, kb = fast.pbs(ct, tvs, ids, want_ks=True)
+            assert np.array_equal(ka, kb) and np.array_equal(a, b)
+            ok = [0, 1, 2, 7, 8, 9, 10]
+            tabs = [np.arange(-8, 8), None]
+            dec = to.decode(to.lwe_phase(K.sk_big, b[ok]), dl)
+            assert [int(d) for d, i in zip(dec, ok) if i % 2 == 0] == [int(tabs[0][msgs[i] + 8]) for i in ok if i % 2 == 0]
+            slow.close(); fast.close()
+        with pytest.raises(ValueError):   # the exact (unrounded) key has no two-limb form
+            P = to.default_params(q_bits=to.TORUS64, n=4)
+            to.FastCtx(P, to.keygen(P, 1).bsk, to.keygen(P, 1).ksk)
+    finally:
+        to.set_field(49)
+
+
 # ------------------------------------------------------------------ unrolled bootstrap key (two coefficients per step)
 
 @pytest.mark.parametrize("q_bits,n", [(49, 16), (49, 15), (64, 16), (to.TORUS64, 15)])
