@@ -24,6 +24,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "lane_transpose.hpp"
+
 namespace fftw {
 
 constexpr int LOG_N = 10;
@@ -103,6 +105,29 @@ __device__ __forceinline__ void dft8(C (&x)[8]) {
     x[7] = fma_h(e2, e3, -h);
 }
 
+#ifndef BMI_FFT_EX1
+#define BMI_FFT_EX1 0   // exchange 1 (lane bits 5..3 <-> register index): 0 = through LDS, 1 = v_permlane32/16_swap + DPP
+#endif
+#ifndef BMI_FFT_EX2
+#define BMI_FFT_EX2 0   // exchange 2 (lane bits 2..0 <-> register index): 0 = through LDS, 1 = DPP moves
+#endif
+// register bit t <-> lane bit LO + t (t = 0, 1, 2) of the 8 complex registers
+template <int LO>
+__device__ __forceinline__ void transpose8(C (&v)[8], int lane) {
+    static_for<0, 4>([&](auto R) {
+        lanetr::tr_double<LO + 2>(v[R].r, v[R + 4].r, lane);
+        lanetr::tr_double<LO + 2>(v[R].i, v[R + 4].i, lane);
+    });
+    static_for<0, 4>([&](auto Q) {
+        constexpr int r = (Q & 1) + 4 * (Q >> 1);
+        lanetr::tr_double<LO + 1>(v[r].r, v[r + 2].r, lane);
+        lanetr::tr_double<LO + 1>(v[r].i, v[r + 2].i, lane);
+    });
+    static_for<0, 4>([&](auto Q) {
+        lanetr::tr_double<LO>(v[2 * Q].r, v[2 * Q + 1].r, lane);
+        lanetr::tr_double<LO>(v[2 * Q].i, v[2 * Q + 1].i, lane);
+    });
+}
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
@@ -126,25 +151,33 @@ __device__ __forceinline__ void forward(double (&x)[16], int lane, const double 
     dft8<false>(v);
     static_for<0, 8>([&](auto K) { v[K] = cmul<false>(v[K], w[K].x, w[K].y); });
     const int r1 = ex1_row(lane), a = lane & 7, base = ex2_base(lane);
-    wave_sync();
-    static_for<0, 8>([&](auto K) { sc[K * ROWC + lane] = double2{v[K].r, v[K].i}; });
-    wave_sync();
-    static_for<0, 8>([&](auto B) {
-        const double2 t = sc[r1 + 8 * B];
-        v[B] = C{t.x, t.y};
-    });
+    if constexpr (BMI_FFT_EX1) {
+        transpose8<3>(v, lane);
+    } else {
+        wave_sync();
+        static_for<0, 8>([&](auto K) { sc[K * ROWC + lane] = double2{v[K].r, v[K].i}; });
+        wave_sync();
+        static_for<0, 8>([&](auto B) {
+            const double2 t = sc[r1 + 8 * B];
+            v[B] = C{t.x, t.y};
+        });
+    }
     static_for<1, 8>([&](auto D) { w[D] = tw2[TW_T2 / 2 + D * 8 + a]; });
     mid();
     sched_fence();
     dft8<false>(v);
     static_for<1, 8>([&](auto D) { v[D] = cmul<false>(v[D], w[D].x, w[D].y); });
-    wave_sync();
-    static_for<0, 8>([&](auto D) { sc[base + D * 8 + ((a + D) & 7)] = double2{v[D].r, v[D].i}; });
-    wave_sync();
-    static_for<0, 8>([&](auto A) {
-        const double2 t = sc[base + a * 8 + ((A + a) & 7)];
-        v[A] = C{t.x, t.y};
-    });
+    if constexpr (BMI_FFT_EX2) {
+        transpose8<0>(v, lane);
+    } else {
+        wave_sync();
+        static_for<0, 8>([&](auto D) { sc[base + D * 8 + ((a + D) & 7)] = double2{v[D].r, v[D].i}; });
+        wave_sync();
+        static_for<0, 8>([&](auto A) {
+            const double2 t = sc[base + a * 8 + ((A + a) & 7)];
+            v[A] = C{t.x, t.y};
+        });
+    }
     dft8<false>(v);
     static_for<0, 8>([&](auto Cc) {
         x[Cc] = v[Cc].r;
@@ -163,24 +196,32 @@ __device__ __forceinline__ void inverse(double (&x)[16], int lane, const double 
     C v[8];
     static_for<0, 8>([&](auto Cc) { v[Cc] = C{x[Cc], x[Cc + 8]}; });
     dft8<true>(v);   // over c -> a
-    wave_sync();
-    static_for<0, 8>([&](auto A) { sc[base + a * 8 + ((A + a) & 7)] = double2{v[A].r, v[A].i}; });
-    wave_sync();
-    static_for<0, 8>([&](auto D) {
-        const double2 t = sc[base + D * 8 + ((a + D) & 7)];
-        v[D] = C{t.x, t.y};
-    });
+    if constexpr (BMI_FFT_EX2) {
+        transpose8<0>(v, lane);
+    } else {
+        wave_sync();
+        static_for<0, 8>([&](auto A) { sc[base + a * 8 + ((A + a) & 7)] = double2{v[A].r, v[A].i}; });
+        wave_sync();
+        static_for<0, 8>([&](auto D) {
+            const double2 t = sc[base + D * 8 + ((a + D) & 7)];
+            v[D] = C{t.x, t.y};
+        });
+    }
     static_for<1, 8>([&](auto D) { v[D] = cmul<true>(v[D], w[D].x, w[D].y); });
     static_for<0, 8>([&](auto K) { w[K] = tw2[TW_T1 / 2 + K * 64 + lane]; });
     sched_fence();
     dft8<true>(v);   // over d -> b
-    wave_sync();
-    static_for<0, 8>([&](auto B) { sc[r1 + 8 * B] = double2{v[B].r, v[B].i}; });
-    wave_sync();
-    static_for<0, 8>([&](auto K) {
-        const double2 t = sc[K * ROWC + lane];
-        v[K] = C{t.x, t.y};
-    });
+    if constexpr (BMI_FFT_EX1) {
+        transpose8<3>(v, lane);
+    } else {
+        wave_sync();
+        static_for<0, 8>([&](auto B) { sc[r1 + 8 * B] = double2{v[B].r, v[B].i}; });
+        wave_sync();
+        static_for<0, 8>([&](auto K) {
+            const double2 t = sc[K * ROWC + lane];
+            v[K] = C{t.x, t.y};
+        });
+    }
     static_for<0, 8>([&](auto K) { v[K] = cmul<true>(v[K], w[K].x, w[K].y); });
     dft8<true>(v);   // over k2 -> r
     x[0] = v[0].r * (1.0 / 512);
