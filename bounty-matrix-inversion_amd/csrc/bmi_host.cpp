@@ -1161,10 +1161,9 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
                                                  count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }
-        // with the floating-point-transform kernels one round of 256 one-workgroup bootstraps (4.5 ms) beats the wave-pair kernel
-        // (8.4 ms up to 1,024 ciphertexts), two rounds (9.0 ms) do not
-        const uint32_t thr = c->d_bsk_fft ? 256 : c->lat_threshold;
-        const bool lat_t = c->variant == 2 || c->variant == 4 || c->variant == 6 || (c->variant == 0 && count <= thr);
+        // (floating-point-transform kernels: two rounds of 256 one-workgroup bootstraps, 7.7 ms, still beat the wave-pair kernel's
+        // 8.4 ms up to 1,024 ciphertexts; three rounds do not)
+        const bool lat_t = c->variant == 2 || c->variant == 4 || c->variant == 6 || (c->variant == 0 && count <= c->lat_threshold);
         if (c->variant == 6 && !c->d_bsk_fft)
             return fail(c, -1, "kernel variant 6 needs the bootstrap key at 48 bits of precision in base 2^10 (the torus default)");
         if (lat_t && c->d_bsk_fft && c->variant != 4) {   // latency form through the floating-point transform (variant 4 pins the exact one)

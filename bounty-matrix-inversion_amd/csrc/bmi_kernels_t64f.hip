@@ -253,11 +253,14 @@ __global__ void __launch_bounds__(128 * TF_CTS)
 //   B  all 1,024 threads = (limb j, output polynomial o, slot q): E + O' and E - O' of the 2L digit transforms, the two complex
 //      multiply-accumulates per row against this thread's key words (own key copy: per slot the pair F_k, F_{k+256} side by
 //      side; requested before phase A, landing under it), then the sum and the twisted difference for the inverse halves
-//   C  wavefronts 0 .. 7 = (limb, o, parity): inverse half, nearest integer, shift into place and ONE LDS atomic add per
+//   C  wavefronts 0 .. 7 = (limb, o, parity): inverse half, nearest integer, shift into place and ONE LDS atomic add (f64) per
 //      coefficient into the accumulator (the two limbs of a coefficient meet there)
+// The accumulator is the exact integer word / 2^16 in a double, as in the wave-pair kernel, but only re-centred mod 2^48 every
+// LF_RECENTRE steps (the atomic adds cannot reduce): 2^47 + 8 (2^45 + 2^47) < 2^51 keeps every sum exact.
 constexpr int LF_THREADS = 1024;
 constexpr int LF_MAX_L = 3;
 constexpr int LF_HALF = N / 2;
+constexpr int LF_RECENTRE = 8;
 constexpr int LF_LDS_WORDS = ffth::HT_WORDS + 2 * N + 2 * LF_MAX_L * N + 2 * 2 * N + BMI_AT_WORDS;
 static_assert(LF_LDS_WORDS <= BMI_LDS_WORDS_MAX, "LF_LDS_WORDS exceeds the 160 KB of LDS");
 
@@ -308,11 +311,14 @@ __global__ void __launch_bounds__(LF_THREADS)
     k_blind_rotate_lat_t64f(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids, const u64 *__restrict__ luts,
                             const double *__restrict__ bsk_latf, const double *__restrict__ g_tw_h, u64 *__restrict__ out,
                             uint32_t count, uint32_t n) {
-    constexpr int LIMBS = Scheme<48>::LIMBS, LB = Scheme<48>::BITS, PRE = Scheme<48>::PRE;
+    constexpr int LIMBS = Scheme<48>::LIMBS, LB = Scheme<48>::BITS, PRE = Scheme<48>::PRE, AB = 64 - PRE;
     static_assert(2.0 * L * N * (double)(1ull << (BG - 1)) * (double)(1ull << (LB - 1)) <= 0x1p45, "limb sums must stay below 2^45");
-    static_assert(LIMBS == 2 && L <= LF_MAX_L, "two limbs, at most three levels");
+    static_assert(LIMBS == 2 && L <= LF_MAX_L && L * BG < AB, "two limbs, at most three levels");
     extern __shared__ double lds[];
-    u64 *acc = reinterpret_cast<u64 *>(lds + ffth::HT_WORDS);               // [2 components][2 parities][512] words mod 2^64
+    double *acc = lds + ffth::HT_WORDS;                                     // [2 components][2 parities][512]: word / 2^16, exact, |.| < 2^51
+    auto mod_ab = [](double t) {   // centred residue mod 2^AB of an exact integer |t| < 2^53 (ties to the negative end, like the u64 word)
+        return __builtin_fma(-(double)(1ull << AB), __builtin_floor(__builtin_fma(t, 1.0 / (double)(1ull << AB), 0.5)), t);
+    };
     double2 *tiles = reinterpret_cast<double2 *>(lds + ffth::HT_WORDS + 2 * N);   // [2L rows][2 halves][256 slots] complex
     double2 *SD = tiles + LF_MAX_L * N;                                     // [limb][output][S, D][256 slots] complex
     uint16_t *at = reinterpret_cast<uint16_t *>(SD + 2 * N);
@@ -328,8 +334,8 @@ __global__ void __launch_bounds__(LF_THREADS)
         const uint32_t nn = tid;  // coefficient index
         const uint32_t e = (nn + bt) & (2 * N - 1);
         const u64 v = tv[e & (N - 1)];
-        acc[acc_slot(nn)] = 0;
-        acc[N + acc_slot(nn)] = (e & N) ? (u64)0 - v : v;
+        acc[acc_slot(nn)] = 0.0;
+        acc[N + acc_slot(nn)] = (double)((i64)((e & N) ? (u64)0 - v : v) >> PRE);     // test polynomials are multiples of 2^(59 or so)
     }
     __syncthreads();
     const int mj = tid >> 9, mo = (tid >> 8) & 1, mq = tid & 255;   // phase B: limb, output polynomial, slot
@@ -347,19 +353,22 @@ __global__ void __launch_bounds__(LF_THREADS)
         });
         if (wave < 4 * L) {
             const int c = wave / (2 * L), lev = (wave % (2 * L)) >> 1, h = wave & 1;
-            const u64 *ac = acc + c * N;
+            const double *ac = acc + c * N;
             double x[8];   // re[r] = x[r], im[r] = x[r + 4]
-            u64 vr[8], vs[8];
+            double vr[8], vs[8];
+            // coefficient m_J = 2 (lane + 64 (J & 3)) + h + 512 (J >> 2); its rotated source e_J = m_J - a_t mod 2N: half of it is
+            // t0 + 64 (J & 3) + 256 (J >> 2) - the low 9 bits are the slot inside the parity block, bit 9 is the sign
+            const uint32_t e0 = (2 * lane + h + 2 * N - a_t) & (2 * N - 1);
+            const uint32_t t0 = e0 >> 1, pbase = (e0 & 1) * LF_HALF;
             static_for<0, 8>([&](auto J) {
-                const uint32_t m = 2 * (lane + 64 * (J & 3)) + h + 512 * (J >> 2);
-                vr[J] = ac[acc_slot((m + 2 * N - a_t) & (N - 1))];
-                vs[J] = ac[acc_slot(m)];
+                const uint32_t t = t0 + 64 * (J & 3) + 256 * (J >> 2);
+                vr[J] = ac[pbase + (t & (LF_HALF - 1))];
+                vs[J] = ac[h * LF_HALF + lane + 64 * (J & 3) + 256 * (J >> 2)];
             });
             static_for<0, 8>([&](auto J) {
-                const uint32_t m = 2 * (lane + 64 * (J & 3)) + h + 512 * (J >> 2);
-                const uint32_t e = (m + 2 * N - a_t) & (2 * N - 1);
-                const u64 v = (e & N) ? (u64)0 - vr[J] : vr[J];
-                double r = t64::rounded_top<L, BG>(v - vs[J]);                          // round half up to L BG bits
+                const uint32_t t = t0 + 64 * (J & 3) + 256 * (J >> 2);
+                const double dd = mod_ab(((t >> 9) & 1) ? -vr[J] - vs[J] : vr[J] - vs[J]);   // the centred lift of the u64 difference, / 2^PRE
+                double r = __builtin_floor(__builtin_fma(dd, 1.0 / (double)(1ull << (AB - L * BG)), 0.5));   // round half up to L BG bits
                 double d = r;                                                          // digit `lev`, balanced [-2^(BG-1), 2^(BG-1))
 #pragma unroll
                 for (int s = L - 1; s > 0; s--) {
@@ -405,24 +414,33 @@ __global__ void __launch_bounds__(LF_THREADS)
             double re[4], im[4];
             if (h) ffth::inverse_half<1>(v, re, im, lane, lds);
             else ffth::inverse_half<0>(v, re, im, lane, lds);
-            unsigned long long *ao = reinterpret_cast<unsigned long long *>(acc + o * N);
-            const int sh = PRE + LB * j;
+            double *ao = acc + o * N + h * LF_HALF + lane;
+            auto place = [&](double v) {   // the limb's exact integer (|.| < 2^45: nearest integer of the transform's output), shifted into place
+                double xr = __builtin_rint(v);
+                if (j == 0) return xr;
+                constexpr double W = (double)(1ull << (AB - LB));   // x 2^LB mod 2^AB: only the low AB - LB bits survive the shift
+                xr = __builtin_fma(-W, __builtin_rint(xr * (1.0 / W)), xr);
+                return xr * (double)(1ull << LB);
+            };
             static_for<0, 4>([&](auto R) {
-                // the limb's exact integers (|.| < 2^45: nearest integers of the transform's outputs), shifted into place
-                const uint32_t m = 2 * (lane + 64 * R) + h;
-                atomicAdd(ao + acc_slot(m), (unsigned long long)(f64_to_word(__builtin_rint(re[R])) << sh));
-                atomicAdd(ao + acc_slot(m + 512), (unsigned long long)(f64_to_word(__builtin_rint(im[R])) << sh));
+                atomicAdd(ao + 64 * R, place(re[R]));          // coefficient 2 (lane + 64 R) + h
+                atomicAdd(ao + 64 * R + 256, place(im[R]));    // ... + 512
             });
         }
         __syncthreads();
+        if (i % LF_RECENTRE == LF_RECENTRE - 1) {   // (uniform) keep the accumulator's magnitude below 2^51
+            acc[tid] = mod_ab(acc[tid]);
+            acc[N + tid] = mod_ab(acc[N + tid]);
+            __syncthreads();
+        }
     }
     u64 *o = out + (size_t)ct * (N + 1);
     {
         const uint32_t nn = tid;
-        const u64 a0 = acc[acc_slot(nn)];
+        const u64 a0 = f64_to_word(mod_ab(acc[acc_slot(nn)])) << PRE;
         if (nn == 0) {
             o[0] = a0;
-            o[N] = acc[N + acc_slot(0)];
+            o[N] = f64_to_word(mod_ab(acc[N + acc_slot(0)])) << PRE;
         } else {
             o[N - nn] = (u64)0 - a0;
         }

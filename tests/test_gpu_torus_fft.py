@@ -79,11 +79,11 @@ def test_float_transform_kernels_bit_exact_every_batch_shape(eng, variant, count
 
 
 def test_auto_dispatch_takes_the_float_transform_kernels(eng):
-    """variant 0 on the torus default set = variant 6 up to 256 ciphertexts, variant 5 beyond: same words either way (all
+    """variant 0 on the torus default set = variant 6 up to 512 ciphertexts, variant 5 beyond: same words either way (all
     kernels are exact), so the check is on agreement at both sides of the threshold and on the refusals"""
     from bmi_amd import tfhe
     to, octx, _, _ = _oracle(eng)
-    for count in (256, 257):
+    for count in (512, 513):
         _, ids, tvs, _, sel, small = _batch(eng, octx, count, 7 + count)
         got = eng.blind_rotate_host(small, ids[sel])
         pick = np.array([0, 1, 2, 3, count - 1])
