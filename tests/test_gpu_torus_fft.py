@@ -100,6 +100,21 @@ def test_auto_dispatch_takes_the_float_transform_kernels(eng):
         e49.close()
 
 
+def test_half_transforms_on_the_gpu_against_the_definition(tmp_path):
+    """tests/hip/fft_half_check.hip: the two 256-point half transforms of the latency kernel (register swaps and DPP moves instead
+    of LDS exchanges) against the folded transform's definition evaluated in long double, and the inverse halves on a round trip"""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fft_half_check")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-o", exe,
+                    os.path.join(repo, "tests", "hip", "fft_half_check.hip")], check=True, capture_output=True, timeout=600)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.startswith("ok"), p.stdout + p.stderr
+    fwd, back = (float(x) for x in p.stdout.split()[1:3])
+    assert fwd < 1e-9 and back < 1e-10
+
+
 def test_exact_key_has_no_float_transform_copy():
     """the error bound of the transform is stated for 24-bit limbs against base-2^10 digits: a context with the exact 64-bit key
     (three 22-bit limbs against base 2^15) keeps the exact transform, and pinning variant 5 / 6 there is an error, not a fallback"""
