@@ -339,6 +339,7 @@ __global__ void __launch_bounds__(LF_THREADS)
     }
     __syncthreads();
     const int mj = tid >> 9, mo = (tid >> 8) & 1, mq = tid & 255;   // phase B: limb, output polynomial, slot
+    uint32_t since_centred = 0;   // steps taken since the accumulator was last reduced mod 2^48
 
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t a_t = at[i];
@@ -428,7 +429,8 @@ __global__ void __launch_bounds__(LF_THREADS)
             });
         }
         __syncthreads();
-        if (i % LF_RECENTRE == LF_RECENTRE - 1) {   // (uniform) keep the accumulator's magnitude below 2^51
+        if (++since_centred == LF_RECENTRE) {   // (uniform: counts the steps actually taken) keep the accumulator's magnitude below 2^51
+            since_centred = 0;
             acc[tid] = mod_ab(acc[tid]);
             acc[N + tid] = mod_ab(acc[N + tid]);
             __syncthreads();
