@@ -956,6 +956,10 @@ int bmi_lut_register(bmi_ctx *c, const int64_t *table, uint32_t msg_bits, uint32
     const uint32_t N = c->N;
     if (msg_bits == 0 || (1u << msg_bits) * 2 > N) return fail(c, -1, "msg_bits out of range for N");
     if (out_delta_log >= c->f.bits - 1) return fail(c, -1, "out_delta_log out of range");
+    if (c->t64() && out_delta_log < 22)
+        // the torus kernels on a rounded key (48 / 42 bits) keep the accumulator as a multiple of 2^16 / 2^22: a table encoded
+        // below that scale would lose its low bits - and sits ~2^40 below the noise anyway
+        return fail(c, -1, "out_delta_log below 22 on the 2^64 torus: test polynomials must be multiples of 2^22");
     if (c->n_luts == c->lut_cap) return fail(c, -1, "LUT table full");
     // Signed messages on the whole negacyclic circle: box width w = N / 2^p, boxes centred on m*w.
     const uint32_t M = 1u << msg_bits, Mh = M >> 1, w = N >> msg_bits, half = w >> 1;

@@ -134,7 +134,8 @@ int bmi_phase(const bmi_ctx *ctx, const uint64_t *ct_in, uint32_t count, uint64_
 /* replaces a table look-up definition (fhe.univariate, base_p_arrays.py:365, and every non-linear
  * Tracer operator).  table[m + 2^(msg_bits-1)] = f(m) for signed m in [-2^(msg_bits-1), 2^(msg_bits-1));
  * the looked-up value is returned encoded as f(m) * 2^out_delta_log.  The input ciphertext of a PBS
- * using this LUT must encode m * 2^(q_bits-1-msg_bits).  Returns the id used by the batch calls. */
+ * using this LUT must encode m * 2^(q_bits-1-msg_bits).  Returns the id used by the batch calls.
+ * On the 2^64 torus out_delta_log >= 22 (the kernels on a rounded bootstrap key keep accumulators as multiples of 2^16 / 2^22). */
 int bmi_lut_register(bmi_ctx *ctx, const int64_t *table, uint32_t msg_bits, uint32_t out_delta_log, uint32_t *lut_id);
 /* the N-coefficient test polynomial built for a LUT (host copy; test hook) */
 int bmi_lut_get(const bmi_ctx *ctx, uint32_t lut_id, uint64_t *test_vector);

@@ -94,6 +94,8 @@ def test_auto_dispatch_takes_the_float_transform_kernels(eng):
         pick = np.array([0, 1, 2, 3, count - 1])
         assert np.array_equal(got[pick], octx.blind_rotate(small[pick], tvs, sel[pick]))
     octx.close()
+    with pytest.raises(tfhe.BmiError):   # accumulators on the rounded key are multiples of 2^16: no table below that scale
+        eng.lut_register(np.arange(-8, 8), 4, 15)
     e49 = tfhe.Engine(tfhe.default_params(q_bits=49))
     try:
         for v in (5, 6):
