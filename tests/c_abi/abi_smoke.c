@@ -98,6 +98,24 @@ int main(void) {
     CHECK(bmi_encrypt(ctx, msgs, 5, 59, ct) == 0 && bmi_pbs_batch_host(ctx, ct, ids, 5, out) == 0, "torus pbs");
     CHECK(bmi_decrypt(ctx, out, 5, 59, dec) == 0, "torus decrypt");
     for (int i = 0; i < 5; i++) CHECK(dec[i] == table[msgs[i] + 8], "torus LUT value");
+    {
+        /* the kernels whose exact limb products go through the f64 FFT (variants 5 / 6; what auto ran above) against the exact
+         * transform mod 2^49 - 720895 (variant 1 / 4): the same words; the test hook reports how far the FFT's limb sums were from
+         * the integers they were rounded to (far below 1/2) */
+        uint64_t *sm = (uint64_t *)malloc(5 * (S.n + 1) * 8), *r5 = (uint64_t *)malloc(5 * big * 8), *r1 = (uint64_t *)malloc(5 * big * 8);
+        double margin = -1.0;
+        CHECK(bmi_keyswitch_batch_host(ctx, ct, 5, sm) == 0, "torus keyswitch");
+        CHECK(bmi_set_kernel_variant(ctx, 5) == 0 && bmi_blind_rotate_batch_host(ctx, sm, ids, 5, r5) == 0, "fft wave-pair kernel");
+        CHECK(bmi_set_kernel_variant(ctx, 1) == 0 && bmi_blind_rotate_batch_host(ctx, sm, ids, 5, r1) == 0, "exact-transform wave-pair kernel");
+        CHECK(memcmp(r5, r1, 5 * big * 8) == 0 && memcmp(r5, out, 5 * big * 8) == 0, "fft route == exact-transform route == auto");
+        CHECK(bmi_set_kernel_variant(ctx, 6) == 0 && bmi_blind_rotate_batch_host(ctx, sm, ids, 5, r5) == 0 && memcmp(r5, r1, 5 * big * 8) == 0,
+              "fft latency kernel");
+        CHECK(bmi_set_kernel_variant(ctx, 0) == 0, "auto");
+        CHECK(bmi_fft_margin_host(ctx, sm, ids, 5, r5, &margin) == 0 && memcmp(r5, r1, 5 * big * 8) == 0 && margin > 0.0 && margin < 1.0 / 512,
+              "fft rounding margin");
+        CHECK(bmi_lut_register(ctx, table, 4, 15, &lut) < 0, "tables below 2^22 refused on the torus");
+        free(sm); free(r5); free(r1);
+    }
     /* the unrolled torus kernel: the unrolled key is derived from the secret keys held; other ciphertext bits, same messages */
     CHECK(bmi_set_bsk_unroll(ctx, 2) == 0 && bmi_pbs_batch_host(ctx, ct, ids, 5, ct2) == 0, "unrolled torus pbs");
     CHECK(bmi_decrypt(ctx, ct2, 5, 59, dec) == 0 && memcmp(out, ct2, 5 * big * 8) != 0, "unrolled torus decrypt");
