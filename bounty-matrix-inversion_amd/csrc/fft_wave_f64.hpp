@@ -6,8 +6,11 @@
 // is the value of a(X) at the root zeta^(4k+1) of X^1024 + 1 (the other 512 roots are the conjugates: a is real), so a
 // pointwise product of two such vectors followed by the inverse is the negacyclic product.  Why a floating-point transform may
 // carry exact integer arithmetic here: the products summed per limb (6 polynomials of digits |d| <= 2^9 against balanced 24-bit
-// key limbs) are integers below 2^45, and the rounding error of this transform on them stays below 2^-11 (measured; model
-// tools/fft_wave_model.py; the a-priori bound of the error analysis of floating-point FFT products is 0.38 < 1/2), so
+// key limbs) are integers below 2^45, and the rounding error of this transform on them stays below 2^-11 (measured:
+// bmi_fft_margin_host; model: tools/fft_wave_model.py).  A priori: the error analysis of floating-point FFT products (Percival
+// 2003) bounds one product's error by ||d|| ||k|| ((1 + eps)^(3n) (1 + eps sqrt 5)^(3n + 1) (1 + beta)^(3n) - 1) with n = log2 of
+// the length, here <= 2^14 * 2^28 * 1.2e-14 = 0.053 per product, 0.32 < 1/2 for the six of a limb sum (digits and limbs at their
+// largest magnitudes in every coefficient), so
 // rounding the inverse to the nearest integer returns the exact sum - the result does not depend on the order of the
 // floating-point operations, and the oracle's integer arithmetic is the specification.
 //
