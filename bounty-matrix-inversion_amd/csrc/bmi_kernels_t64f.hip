@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(128 * TF_CTS)
                         x = __builtin_fma(-W, __builtin_rint(x * (1.0 / W)), x);
                         accf[lane + 64 * J] = mod_ab(__builtin_fma(x, (double)(1ull << (LB * j)), accf[lane + 64 * J]));
                     } else {
-                        accf[lane + 64 * J] = mod_ab(accf[lane + 64 * J] + x);
+                        accf[lane + 64 * J] += x;   // (reduced mod 2^AB with the last limb: 2^47 + 2^45 + 2^47 stays exact)
                     }
                 });
                 pin();
