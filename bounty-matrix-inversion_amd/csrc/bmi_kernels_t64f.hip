@@ -35,7 +35,10 @@ namespace {
 
 using t64::f64_to_word;
 using t64::Scheme;
-constexpr int TF_CTS = 4;
+#ifndef BMI_T64F_CTS
+#define BMI_T64F_CTS 4      // ciphertexts (wavefront pairs) per workgroup: 4 fill the CU's LDS; 3 and 2 measured slower per ciphertext
+#endif
+constexpr int TF_CTS = BMI_T64F_CTS;
 constexpr int TF_LDS_WORDS = TW_WORDS + 2 * TF_CTS * (SCRATCH_WORDS + N) + TF_CTS * BMI_AT_WORDS + 4 * TF_CTS;
 static_assert(TF_LDS_WORDS <= BMI_LDS_WORDS_MAX, "TF_LDS_WORDS exceeds the 160 KB of LDS");
 static_assert(SCRATCH_WORDS >= N, "a tile carries 512 complex partial sums to the partner");
@@ -147,6 +150,7 @@ __global__ void __launch_bounds__(128 * TF_CTS)
         double2 kb[2][8];
         static_for<0, L>([&](auto LEV) {
             constexpr int lev = L - 1 - LEV;  // least significant digit first
+#ifndef BMI_T64F_NOPIN_FWD
             pin();
 #if BMI_T64F_PRIO
             __builtin_amdgcn_s_setprio(lev + 1);
@@ -166,6 +170,7 @@ __global__ void __launch_bounds__(128 * TF_CTS)
             }
             forward(X[lev], lane, lds, tile);
         });
+#endif
 #if BMI_T64F_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
