@@ -150,7 +150,6 @@ __global__ void __launch_bounds__(128 * TF_CTS)
         double2 kb[2][8];
         static_for<0, L>([&](auto LEV) {
             constexpr int lev = L - 1 - LEV;  // least significant digit first
-#ifndef BMI_T64F_NOPIN_FWD
             pin();
 #if BMI_T64F_PRIO
             __builtin_amdgcn_s_setprio(lev + 1);
@@ -170,7 +169,6 @@ __global__ void __launch_bounds__(128 * TF_CTS)
             }
             forward(X[lev], lane, lds, tile);
         });
-#endif
 #if BMI_T64F_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
