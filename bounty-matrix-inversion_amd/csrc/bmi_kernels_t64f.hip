@@ -33,6 +33,19 @@ namespace {
 #define BMI_T64F_PRIO 1     // issue priority steps down through the forward transforms (3, 2, 1), 0 in the limb loop
 #endif
 
+#ifdef BMI_PHASE_PROF   // make -C csrc prof; tools/phase_prof_t64f.py
+__device__ unsigned long long g_phase_f[128];
+#define PH_DECL() unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = clock64()
+#define PH_MARK(k)                               \
+    do {                                         \
+        const unsigned long long t_ = clock64(); \
+        ph_[k] += t_ - tl_;                      \
+        tl_ = t_;                                \
+    } while (0)
+#else
+#define PH_DECL()
+#define PH_MARK(k)
+#endif
 using t64::f64_to_word;
 using t64::Scheme;
 #ifndef BMI_T64F_CTS
@@ -113,10 +126,13 @@ __global__ void __launch_bounds__(128 * TF_CTS)
 
     uint32_t hand = 0;   // handshake counter of the pair (one per inverse transform)
     double dev = 0.0;    // STATS: largest |value - nearest integer| this lane has rounded away
+    PH_DECL();
     for (uint32_t i = 0; i < n; i++) {
+        PH_MARK(7);
 #if BMI_T64F_RESYNC
         if (i % BMI_T64F_RESYNC == 0) __syncthreads();
 #endif
+        PH_MARK(0);   // resync barrier
         const uint32_t a_t = at[i];
         // this wavefront's L GGSW rows: [row = L c + lev][column][limb][N]
         const double *bsk_c = bsk + ((size_t)i * 4 * L + c * 2 * L) * LIMBS * N;
@@ -138,6 +154,7 @@ __global__ void __launch_bounds__(128 * TF_CTS)
                 r[J] = __builtin_floor(__builtin_fma(d, 1.0 / (double)(1ull << (AB - L * BG)), 0.5));   // round half up to L BG bits
             });
         }
+        PH_MARK(1);   // accumulator reads, difference, rounding
         double X[L][16];   // the L digit polynomials, evaluation layout, live across the limb loop
         // key rows in the order they are multiplied: t = limb * 2 L + q; q < L: (level q, partner's column c^1) - its partial sum is
         // published while the own column (q >= L: level q - L, column c) is still being multiplied.  A row is 8 complex words per
@@ -172,6 +189,7 @@ __global__ void __launch_bounds__(128 * TF_CTS)
 #if BMI_T64F_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+        PH_MARK(2);   // digits + L forward transforms
         double acc[16];
         static_for<0, LIMBS * 2 * L>([&](auto T) {
             constexpr int t = T, j = t / (2 * L), q = t % (2 * L), lev = q % L, cur = t & 1;
@@ -200,7 +218,9 @@ __global__ void __launch_bounds__(128 * TF_CTS)
             }
             pin();
             if constexpr (q == 2 * L - 1) {
+                PH_MARK(3);   // 2L rows of products (+ publishing the partner's partial)
                 pair_wait(f_pub_partner, hand);
+                PH_MARK(4);   // waiting for the partner's partial
                 static_for<0, 8>([&](auto P) {
                     const double2 p = reinterpret_cast<const double2 *>(ptile)[P * 64 + lane];
                     acc[P] += p.x;
@@ -208,7 +228,9 @@ __global__ void __launch_bounds__(128 * TF_CTS)
                 });
                 pair_post(f_ack, hand);          // release: the reads above have landed
                 pair_wait(f_ack_partner, hand);  // the partner has read this tile: the inverse transform may overwrite it
+                PH_MARK(5);   // adding the partner's partial, acknowledging
                 inverse(acc, lane, lds, tile);
+                PH_MARK(6);   // inverse transform
                 if constexpr (t + 1 < LIMBS * 2 * L) {
                     static_for<0, 8>([&](auto P) { kb[cur ^ 1][P] = row_ptr(t + 1)[P * 64 + lane]; });
                     pin();
@@ -231,6 +253,11 @@ __global__ void __launch_bounds__(128 * TF_CTS)
         });
     }
 
+#ifdef BMI_PHASE_PROF
+    PH_MARK(7);
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k_ = 0; k_ < 8; k_++) g_phase_f[wave * 8 + k_] = ph_[k_];
+#endif
     if constexpr (STATS) atomicMax(stat, (unsigned long long)__double_as_longlong(dev));   // non-negative doubles order like their bit patterns
     if (!live) return;
     wave_sync();
@@ -453,6 +480,12 @@ __global__ void __launch_bounds__(LF_THREADS)
 }
 
 }  // namespace
+
+#ifdef BMI_PHASE_PROF
+extern "C" int bmi_debug_phase_prof_t64f(unsigned long long *out64) {
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase_f), sizeof(unsigned long long) * 128);
+}
+#endif
 
 namespace bmit {
 
