@@ -160,5 +160,8 @@ def test_rounding_margin_of_the_limb_sums(kw):
         assert 0.0 < dist < 2.0 ** -9, dist
         e.set_kernel_variant(1)
         assert np.array_equal(out, e.blind_rotate_host(small, ids))
+        e.set_kernel_variant(6)   # the latency form at this shape (random words first)
+        assert np.array_equal(out[:40], e.blind_rotate_host(small[:40], ids[:40]))
+        assert np.array_equal(out[600:640], e.blind_rotate_host(small[600:640], ids[600:640]))
     finally:
         e.close()
