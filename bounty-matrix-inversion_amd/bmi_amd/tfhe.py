@@ -186,7 +186,8 @@ def default_params(q_bits=None, **kw):
 
 def preset_params(name, **kw):
     """named parameter set of the library: "north_star", "north_star_torus64", "north_star_goldilocks", "secure128"
-    (n 742, N 2048: the 128-bit-secure set, include/bmi_tfhe.h)"""
+    (n 742, N 2048: the 128-bit-secure set on the 49-bit field) and "secure128_torus" (the same on q = 2^64, Concrete's
+    modulus, l = 3 x 10 bits); include/bmi_tfhe.h"""
     P = Params()
     if load_library().bmi_preset_params(name.encode(), C.byref(P)) != 0:
         raise BmiError(f"unknown parameter preset {name!r}")

@@ -23,6 +23,7 @@
 #include "ntt_wave_f64.hpp"
 #include "fft_half_f64.hpp"
 #include "fft_wave_f64.hpp"
+#include "fft_quarter_f64.hpp"
 #include "t64_common.hpp"
 
 using gl::i64;
@@ -198,6 +199,7 @@ struct bmi_ctx {
     double *d_tw_half = nullptr, *d_bsk_lat = nullptr;          // 49-bit field: tables and key copy of the split-transform latency kernel
     double *d_tw_fft = nullptr, *d_bsk_fft = nullptr;           // 2^64 torus, key at 48 bits: tables and key copy of the floating-point-transform wave-pair kernel (bmi_kernels_t64f.hip)
     double *d_tw_fh = nullptr, *d_bsk_latf = nullptr;           // ... and of its latency form (half transforms, fft_half_f64.hpp; key in slot-pair order)
+    double *d_tw_fq = nullptr, *d_bsk_w = nullptr;              // 2^64 torus at N = 2048, key at 46 bits: tables and key copy of bmi_kernels_t64w.hip (quarter transforms, fft_quarter_f64.hpp)
     double *d_tw_wide = nullptr;                                // N = 2048: T / T^-1 of the even/odd combination (d_bsk_lat then holds the wide key copy)
     // bootstrap-key unrolling (49-bit field at N = 1024 / 2048, 2^64 torus; bmi_set_bsk_unroll): per pair of LWE coefficients the GGSW encryptions of
     // s s', s (1 - s'), (1 - s) s'; host copy in the standard domain, device copy in the slot order of the latency kernel
@@ -362,12 +364,13 @@ std::vector<u64> build_twiddles_quad(const Fq &f) {
 
 // precision a torus context stores its bootstrap key at unless bmi_set_bsk_precision says otherwise: 48 bits (two 24-bit limbs)
 // where the decomposition base leaves room for it (Bg <= 2^10: the default torus set), else the exact key (three 22-bit limbs)
-int default_bsk_precision(const bmi_params &P) { return P.bs_base_log <= 10 ? 48 : 64; }
+// (N = 2048: 46 bits, two 23-bit limbs - the length at which the floating-point transform's error bound still certifies the rounding)
+int default_bsk_precision(const bmi_params &P) { return P.log_N == 11 ? 46 : (P.bs_base_log <= 10 ? 48 : 64); }
 
 bool params_supported(const bmi_params &P, std::string &why) {
-    if (P.q_bits == BMI_Q_TORUS64 && P.log_N != 10) { why = "the 2^64 torus has a HIP kernel for N = 1024 only"; return false; }
-    if (P.log_N != 10 && !((P.log_N == 11 || P.log_N == 12) && P.q_bits == 49)) {
-        why = "log_N must be 10 (N = 1024), or 11 / 12 (N = 2048 / 4096) on the 49-bit field";
+    if (P.q_bits == BMI_Q_TORUS64 && P.log_N != 10 && P.log_N != 11) { why = "the 2^64 torus has HIP kernels for N = 1024 and N = 2048"; return false; }
+    if (P.log_N != 10 && !((P.log_N == 11 || P.log_N == 12) && P.q_bits == 49) && !(P.log_N == 11 && P.q_bits == BMI_Q_TORUS64)) {
+        why = "log_N must be 10 (N = 1024), 11 (N = 2048: 49-bit field or 2^64 torus) or 12 (N = 4096: 49-bit field)";
         return false;
     }
     if (P.k != 1) { why = "only k = 1 has a HIP kernel in this build"; return false; }
@@ -375,10 +378,11 @@ bool params_supported(const bmi_params &P, std::string &why) {
     const bool lb_f64 = lb_default || (P.bs_levels == 2 && P.bs_base_log == 15) || (P.bs_levels == 1 && P.bs_base_log == 23);
     // (2, 2^15) and (1, 2^23): the templated 49-bit kernels (N = 1024 wave-pair / latency kernels, N = 2048), and (2, 2^15) on the torus
     const bool ok_lb = (lb_default && P.q_bits != BMI_Q_TORUS64) || (P.q_bits == 49 && P.log_N <= 11 && lb_f64) ||
-                       (P.q_bits == BMI_Q_TORUS64 && bmit::shape_supported(default_bsk_precision(P), P.bs_levels, P.bs_base_log));
+                       (P.q_bits == BMI_Q_TORUS64 && P.log_N == 10 && bmit::shape_supported(default_bsk_precision(P), P.bs_levels, P.bs_base_log)) ||
+                       (P.q_bits == BMI_Q_TORUS64 && P.log_N == 11 && bmit::shape_supported_wide(default_bsk_precision(P), P.bs_levels, P.bs_base_log));
     if (!ok_lb) {
         why = "(l, Bg) must be (3, 2^15); the 49-bit field at N <= 2048 also takes (2, 2^15) and (1, 2^23), the 2^64 torus (3 or 2, 2^10) "
-              "and (3 or 2, 2^15)";
+              "and, at N = 1024, (3 or 2, 2^15)";
         return false;
     }
     if (P.n == 0 || P.n > BMI_MAX_LWE_N) { why = "n must be in [1, 1024]"; return false; }
@@ -420,6 +424,14 @@ int bmi_preset_params(const char *name, bmi_params *out) {
         // bits (output noise 2^-19.5: the circuits' linear combinations amplify it up to 75x), keyswitch 8 x 2 bits (its noise,
         // set by the LWE noise that security dictates, is what bounds the look-up margin: finer digits = less of it).
         *out = bmi_params{742, 11, 1, 2, 15, 8, 2, 49, 7.069849454709433e-6, std::ldexp(1.0, -44)};
+        return 0;
+    }
+    if (s == "secure128_torus") {
+        // the same two security-relevant pairs (n = 742 at LWE noise 2^-17.11; GLWE of size 2048 at noise 2^-44 >= 2.94e-16) on
+        // Concrete's own modulus q = 2^64.  Decompositions: bootstrap 3 x 10 bits against a key stored at 46 bits of precision
+        // (two 23-bit limbs: exact limb sums through the floating-point transform, fft_quarter_f64.hpp) - output noise 2^-22.9,
+        // below the 49-bit preset's 2^-19.5; keyswitch 8 x 2 bits as there.
+        *out = bmi_params{742, 11, 1, 3, 10, 8, 2, BMI_Q_TORUS64, 7.069849454709433e-6, std::ldexp(1.0, -44)};
         return 0;
     }
     return -1;
@@ -506,7 +518,14 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
         if (hipMemcpy(c->d_root_pow, rpd.data(), rpd.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(root powers) failed");
     }
-    if (c->wide() || c->quad()) {
+    if (c->t64() && c->wide()) {   // tables of the quarter transforms (fft_quarter_f64.hpp): powers of zeta = exp(i pi / 2048)
+        std::vector<double> tq(fftq::QT_WORDS);
+        fftq::build_tables(tq.data());
+        if (hipMalloc(&c->d_tw_fq, tq.size() * 8) != hipSuccess) return bail("hipMalloc(quarter-fft twiddles) failed");
+        if (hipMemcpy(c->d_tw_fq, tq.data(), tq.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+            return bail("hipMemcpy(quarter-fft twiddles) failed");
+    }
+    if ((c->wide() || c->quad()) && !c->t64()) {
         const std::vector<double> tw = to_centred_doubles(c->quad() ? build_twiddles_quad(c->f) : build_twiddles_wide(c->f));
         if (hipMalloc(&c->d_tw_wide, tw.size() * 8) != hipSuccess) return bail("hipMalloc(wide twiddles) failed");
         if (hipMemcpy(c->d_tw_wide, tw.data(), tw.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
@@ -525,7 +544,8 @@ void bmi_ctx_destroy(bmi_ctx *c) {
                     (void *)c->d_io_a, (void *)c->d_io_b, (void *)c->d_io_ids, c->d_ks_partial,
                     (void *)c->d_ks_limbs, (void *)c->d_ks_digits, (void *)c->d_ks_sums, (void *)c->d_tw_half,
                     (void *)c->d_bsk_lat, (void *)c->d_tw_wide, (void *)c->d_bsk3_lat, (void *)c->d_root_pow,
-                    (void *)c->d_tw_fft, (void *)c->d_bsk_fft, (void *)c->d_tw_fh, (void *)c->d_bsk_latf})
+                    (void *)c->d_tw_fft, (void *)c->d_bsk_fft, (void *)c->d_tw_fh, (void *)c->d_bsk_latf, (void *)c->d_tw_fq,
+                    (void *)c->d_bsk_w})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -753,7 +773,15 @@ int upload_eval_keys(bmi_ctx *c) {
     HIP_OK(c, hipMalloc(&d_tmp, bsk_words * sizeof(u64)));
     HIP_OK(c, hipMemcpy(d_tmp, c->bsk_std.data(), bsk_words * sizeof(u64), hipMemcpyHostToDevice));
     int rc = 0;
-    if (c->t64()) {  // 2^64 torus: bsk_limbs transform-domain limb polynomials per key polynomial
+    if (c->t64() && c->wide()) {  // 2^64 torus at N = 2048: ONE key copy, two limb polynomials per key polynomial in the order of bmi_kernels_t64w.hip
+        if (c->d_bsk_w) { (void)hipFree(c->d_bsk_w); c->d_bsk_w = nullptr; }
+        if (hipMalloc(&c->d_bsk_w, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) {
+            (void)hipFree(d_tmp);
+            return fail(c, -2, "hipMalloc(torus N = 2048 key) failed");
+        }
+        rc = bmit::launch_bsk_to_wide(d_tmp, c->d_bsk_w, c->d_tw_fq, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
+        if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_wide (torus) launch failed"); }
+    } else if (c->t64()) {  // 2^64 torus: bsk_limbs transform-domain limb polynomials per key polynomial
         if (c->d_bsk) { (void)hipFree(c->d_bsk); c->d_bsk = nullptr; }
         if (hipMalloc(&c->d_bsk, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) {
             (void)hipFree(d_tmp);
@@ -888,7 +916,14 @@ int bmi_export_keys(const bmi_ctx *c, uint64_t *sk_small, uint64_t *sk_big, uint
 
 int bmi_key_bytes(const bmi_ctx *c, uint64_t *bsk_bytes, uint64_t *ksk_bytes) {
     if (!c) return -1;
-    if (bsk_bytes) *bsk_bytes = (u64)c->P.n * c->rows * (c->P.k + 1) * c->N * 8 * (c->t64() ? c->bsk_limbs() : 1);
+    if (bsk_bytes) {   // every resident device copy (one per kernel family that is selectable on this context), plus the unrolled key
+        const u64 one = (u64)c->P.n * c->rows * (c->P.k + 1) * c->N * 8 * (c->t64() ? c->bsk_limbs() : 1);
+        u64 copies = 0;
+        for (const void *p : {(const void *)c->d_bsk, (const void *)c->d_bsk_lat, (const void *)c->d_bsk_fft, (const void *)c->d_bsk_latf,
+                              (const void *)c->d_bsk_w})
+            copies += p != nullptr;
+        *bsk_bytes = one * copies + (c->have_bsk3 ? (u64)c->bsk3_words() * 8 * (c->t64() ? c->bsk_limbs() : 1) : 0);
+    }
     if (ksk_bytes) *ksk_bytes = (u64)c->big_n * c->P.ks_levels * (c->P.n + 1) * 8;
     return 0;
 }
@@ -956,10 +991,10 @@ int bmi_lut_register(bmi_ctx *c, const int64_t *table, uint32_t msg_bits, uint32
     const uint32_t N = c->N;
     if (msg_bits == 0 || (1u << msg_bits) * 2 > N) return fail(c, -1, "msg_bits out of range for N");
     if (out_delta_log >= c->f.bits - 1) return fail(c, -1, "out_delta_log out of range");
-    if (c->t64() && out_delta_log < 22)
-        // the torus kernels on a rounded key (48 / 42 bits) keep the accumulator as a multiple of 2^16 / 2^22: a table encoded
-        // below that scale would lose its low bits - and sits ~2^40 below the noise anyway
-        return fail(c, -1, "out_delta_log below 22 on the 2^64 torus: test polynomials must be multiples of 2^22");
+    if (c->t64() && c->bsk_prec != 64 && out_delta_log < (uint32_t)(64 - c->bsk_prec))
+        // the torus kernels on a rounded key (48 / 46 / 42 bits) keep the accumulator as a multiple of 2^16 / 2^18 / 2^22: a table
+        // encoded below that scale would lose its low bits - and sits ~2^40 below the noise anyway.  (The exact key has no such grid.)
+        return fail(c, -1, "out_delta_log below 64 - (bootstrap-key precision) on the 2^64 torus: test polynomials must be multiples of the key's grid");
     if (c->n_luts == c->lut_cap) return fail(c, -1, "LUT table full");
     // Signed messages on the whole negacyclic circle: box width w = N / 2^p, boxes centred on m*w.
     const uint32_t M = 1u << msg_bits, Mh = M >> 1, w = N >> msg_bits, half = w >> 1;
@@ -995,8 +1030,15 @@ int bmi_lut_get(const bmi_ctx *c, uint32_t lut_id, uint64_t *test_vector) {
 int bmi_set_bsk_precision(bmi_ctx *c, uint32_t bits) {
     if (!c) return -1;
     if (!c->t64()) return fail(c, -1, "the bootstrap-key precision option exists on the 2^64 torus only");
-    if (!t64::precision_ok((int)bits)) return fail(c, -1, "bootstrap-key precision must be 64 (exact), 48 or 42 bits");
+    if (!t64::precision_ok((int)bits)) return fail(c, -1, "bootstrap-key precision must be 64 (exact), 48, 46 or 42 bits");
     if (c->have_keys) return fail(c, -1, "set the bootstrap-key precision before generating or importing keys");
+    if (c->wide()) {
+        if (!bmit::shape_supported_wide((int)bits, c->P.bs_levels, c->P.bs_base_log))
+            return fail(c, -1, "at N = 2048 the torus kernel takes the key at 46 bits of precision (two 23-bit limbs) only: the length at which "
+                               "the floating-point transform's error bound certifies the rounding (fft_quarter_f64.hpp)");
+        c->bsk_prec = (int)bits;
+        return 0;
+    }
     if (!bmit::shape_supported((int)bits, c->P.bs_levels, c->P.bs_base_log))
         return fail(c, -1, "no kernel for this precision at this decomposition: base 2^10 takes 48 (default) or 64 bits, base 2^15 takes 64 "
                            "(default) or 42 bits (a limb sum must stay below p/2: t64_common.hpp)");
@@ -1017,6 +1059,8 @@ int bmi_set_bsk_unroll(bmi_ctx *c, uint32_t factor) {
     if (factor != 1 && factor != 2) return fail(c, -1, "the unrolling factor is 1 or 2");
     if (factor == 2 && !((c->f64() && !c->quad()) || c->t64()))
         return fail(c, -1, "bootstrap-key unrolling has HIP kernels for the 49-bit field at N = 1024 and N = 2048 and for the 2^64 torus only");
+    if (factor == 2 && c->t64() && c->wide())
+        return fail(c, -1, "bootstrap-key unrolling has no HIP kernel on the 2^64 torus at N = 2048");
     if (factor == 2 && c->t64() && !bmit::shape_supported_unrolled(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log))
         return fail(c, -1, "on the 2^64 torus the unrolled kernel takes the 48-bit key at base 2^10 (the default torus set): the limb sums of "
                            "its three scaled products must stay below p/2");
@@ -1034,8 +1078,8 @@ int bmi_set_bsk_unroll(bmi_ctx *c, uint32_t factor) {
 
 int bmi_import_bsk_unrolled(bmi_ctx *c, const uint64_t *bsk3) {
     if (!c || !bsk3) return -1;
-    if (!((c->f64() && !c->quad()) || c->t64()))
-        return fail(c, -1, "bootstrap-key unrolling has HIP kernels for the 49-bit field at N = 1024 and N = 2048 and for the 2^64 torus only");
+    if (!((c->f64() && !c->quad()) || (c->t64() && !c->wide())))
+        return fail(c, -1, "bootstrap-key unrolling has HIP kernels for the 49-bit field at N = 1024 and N = 2048 and for the 2^64 torus at N = 1024 only");
     if (!c->have_keys) return fail(c, -1, "no keys: import or generate the key set first");
     const size_t words = c->bsk3_words();
     for (size_t i = 0; i < words; i++)
@@ -1158,6 +1202,11 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     // with wave-pair work, the throughput kernel beyond that (49-bit field: the exchange-once form).
     const bool latency = c->variant == 2 || (c->variant == 0 && count <= c->lat_threshold);
     int rc;
+    if (c->t64() && c->wide()) {   // 2^64 torus at N = 2048: one kernel (one workgroup per ciphertext) for every batch size
+        rc = bmit::launch_blind_rotate_wide(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_w, c->d_tw_fq, d_out, count, c->P.n,
+                                            c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, nullptr, (hipStream_t)stream);
+        return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+    }
     if (c->t64()) {   // 2^64 torus: latency kernel (one workgroup per ciphertext) for small batches, wave pairs beyond
         if (c->unroll == 2) {   // unrolled key: one kernel (one workgroup per ciphertext) for every batch size
             if (!c->have_bsk3) return fail(c, -1, "unrolling selected but the context holds no unrolled key: generate keys after bmi_set_bsk_unroll, or bmi_import_bsk_unrolled");
@@ -1375,8 +1424,9 @@ int bmi_fft_margin_host(bmi_ctx *c, const uint64_t *small_in, const uint32_t *lu
                         double *max_distance) {
     if (!c || !small_in || !lut_ids || !out || !max_distance) return -1;
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
-    if (!c->d_bsk_fft)
-        return fail(c, -1, "the floating-point-transform kernels exist on the 2^64 torus with the bootstrap key at 48 bits in base 2^10");
+    if (!c->d_bsk_fft && !c->d_bsk_w)
+        return fail(c, -1, "the floating-point-transform kernels exist on the 2^64 torus with the bootstrap key at 48 bits (N = 1024) or 46 bits "
+                           "(N = 2048) in base 2^10");
     if (int bad = check_lut_ids(c, lut_ids, count)) return bad;
     HIP_OK(c, hipSetDevice(c->device));
     int rc = ensure_io(c, count);
@@ -1389,8 +1439,10 @@ int bmi_fft_margin_host(bmi_ctx *c, const uint64_t *small_in, const uint32_t *lu
     if (e == hipSuccess) e = hipMemcpyAsync(c->d_small, small_in, (size_t)count * (c->P.n + 1) * 8, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->d_io_ids, lut_ids, count * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess)
-        e = (hipError_t)bmit::launch_blind_rotate_fft(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_fft, c->d_tw_fft, c->d_io_b,
-                                                      count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, d_stat, c->stream);
+        e = c->d_bsk_w ? (hipError_t)bmit::launch_blind_rotate_wide(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_w, c->d_tw_fq, c->d_io_b,
+                                                                    count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, d_stat, c->stream)
+                       : (hipError_t)bmit::launch_blind_rotate_fft(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_fft, c->d_tw_fft, c->d_io_b,
+                                                                   count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, d_stat, c->stream);
     unsigned long long bits = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(out, c->d_io_b, (size_t)count * (c->big_n + 1) * 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&bits, d_stat, 8, hipMemcpyDeviceToHost, c->stream);

@@ -15,6 +15,9 @@
 //                                          error (2^15.x per word, summed over the GLWE key's set bits: 2^18.7 per row) stays
 //                                          under the key noise 2^20 - output noise 2^-22.6 against 2^-19.85 of (Bg 2^15, exact)
 //   42 bits  2 limbs of 21 bits, PRE = 22  round 2's throughput option at Bg = 2^15 (effective key noise 2^-39.3)
+//   46 bits  2 limbs of 23 bits, PRE = 18  N = 2048 (the secure128_torus set, Bg = 2^10, l = 3) through the floating-point
+//                                          transform only (bmi_kernels_t64w.hip): a limb sum 2 l N 2^9 2^22 = 2^44.6 keeps the
+//                                          a-priori error bound of the 1,024-point transform below 1/2 (fft_quarter_f64.hpp)
 #pragma once
 #include <stdint.h>
 
@@ -34,10 +37,11 @@ template <int PREC> struct Scheme;
 template <> struct Scheme<64> { static constexpr int LIMBS = 3, BITS = 22, PRE = 0; };
 template <> struct Scheme<48> { static constexpr int LIMBS = 2, BITS = 24, PRE = 16; };
 template <> struct Scheme<42> { static constexpr int LIMBS = 2, BITS = 21, PRE = 22; };
+template <> struct Scheme<46> { static constexpr int LIMBS = 2, BITS = 23, PRE = 18; };
 
-T64_HD bool precision_ok(int prec) { return prec == 64 || prec == 48 || prec == 42; }
+T64_HD bool precision_ok(int prec) { return prec == 64 || prec == 48 || prec == 46 || prec == 42; }
 T64_HD int limbs_of(int prec) { return prec == 64 ? 3 : 2; }
-T64_HD int limb_bits(int prec) { return prec == 64 ? 22 : (prec == 48 ? 24 : 21); }
+T64_HD int limb_bits(int prec) { return prec == 64 ? 22 : prec / 2; }
 T64_HD int limb_pre(int prec) { return 64 - prec; }
 // largest bootstrap base log a precision admits: 2 l N 2^(b-1) 2^(BITS-1) < p/2 at l = 3, N = 1024 means b + BITS <= 37;
 // the unrolled step needs b + BITS <= 34

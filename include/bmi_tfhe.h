@@ -76,6 +76,10 @@ int bmi_default_params_for(uint32_t q_bits, bmi_params *out);
  *                           sit at ~8.7 sigma of keyswitch + mod-switch noise (measured, tests/test_gpu_parity.py: a
  *                           failure probability of ~2^-58 each; that set's own target is 2^-40).  What compiler.compile's parameter
  *                           optimiser guarantees for the reference (main.py:66) - here a fixed, documented set.
+ *   "secure128_torus"       the same security-relevant pairs (n 742 at 2^-17.1; GLWE 2048 at 2^-44) on Concrete's own modulus
+ *                           q = 2^64: N 2048, k 1, l 3 x 10 bits, keyswitch 8 x 2 bits, bootstrap key stored at 46 bits of
+ *                           precision (two 23-bit limbs; exact limb sums through the floating-point transform,
+ *                           k_blind_rotate_w_t64f).  Output noise 2^-22.9 (the 49-bit preset: 2^-19.5).
  * The north-star sets keep n = 630 as BASELINE.json prescribes; their noise is sized for correctness, NOT for 128-bit
  * security. */
 int bmi_preset_params(const char *name, bmi_params *out);
@@ -203,6 +207,9 @@ int bmi_set_kernel_variant(bmi_ctx *ctx, int variant);
  *       summed over the ~N/2 set bits of the GLWE key: 2^18.7) stay under the key noise 2^20, and the finer base more than
  *       pays for them - bootstrap output noise 2^-22.6 against 2^-19.85 of (Bg = 2^15, exact key), measured on the formula
  *       (tests/test_gpu_parity.py).  The only precision the unrolled torus kernel takes (bmi_set_bsk_unroll).
+ *   46  N = 2048 only (its default and only precision; "secure128_torus"): multiples of 2^18, two 23-bit limbs - the limb width at
+ *       which the a-priori error bound of the 1,024-point floating-point transform still certifies the rounding of a limb sum
+ *       (0.41 < 1/2, csrc/fft_quarter_f64.hpp; 24-bit limbs: 0.83).
  *   42  round 2's option at Bg = 2^15: multiples of 2^22, two 21-bit limbs; effective key noise 2^-39.3, output noise
  *       2^-15.15 - a throughput option for flat PBS batches, too noisy for the encrypted inverse.
  * The rounded key is the context's key from then on (bmi_export_keys / bmi_export_bsk_unrolled return it; results are
@@ -247,7 +254,8 @@ int bmi_circuit_prune(uint32_t n_in, uint32_t n_nodes, const int64_t *node_ptr, 
 int bmi_circuit_schedule(uint32_t n_in, uint32_t n_nodes, const int64_t *node_ptr, const int32_t *term_leaf,
                          uint32_t round_, uint32_t wide_round, int32_t *level_out, int32_t *depth_out);
 
-/* bytes of device memory held by the keys (bootstrap key NTT-domain, keyswitch key) */
+/* bytes of device memory held by the keys: every resident transform-domain copy of the bootstrap key (one per selectable kernel
+ * family, plus the unrolled key when present), and the keyswitch key in word form */
 int bmi_key_bytes(const bmi_ctx *ctx, uint64_t *bsk_bytes, uint64_t *ksk_bytes);
 
 #ifdef __cplusplus

@@ -72,3 +72,29 @@ def test_half_transform_model():
             out[idx + 512] = w[r].imag
     exact = _exact_negacyclic_sum(d, k)
     assert np.all(np.rint(out) == exact) and np.abs(out - exact).max() < 2.0 ** -9
+
+
+def test_quarter_transform_model():
+    """N = 2048 (csrc/fft_quarter_f64.hpp): four 256-point quarters + a radix-4 butterfly against the definition
+    A_k = sum_j (c_j + i c_{j+1024}) zeta^j omega^(jk), and one CMUX-sized sum of products (digits against 23-bit limbs, the key
+    side scaled by 1/2 as the key copy is) rounding to the exact integers"""
+    import fft_quarter_model as m
+    rng = np.random.default_rng(4)
+    c = rng.integers(-512, 512, 2048).astype(float)
+    assert np.abs(m.full_from_quarters(c) - m.definition(c)).max() < 1e-5
+    d = rng.integers(-512, 512, (6, 2048)).astype(float)
+    k = rng.integers(-(1 << 22), 1 << 22, (6, 2048)).astype(float)
+    Y = sum(m.full_from_quarters(d[p]) * (0.5 * m.full_from_quarters(k[p])) for p in range(6))
+    out = m.inverse_from_products(Y)
+    exact = _exact_negacyclic_sum(d, k)
+    assert np.all(np.rint(out) == exact) and np.abs(out - exact).max() < 2.0 ** -9
+
+
+def test_a_priori_rounding_bounds():
+    """tools/fft_bound.py: Percival's bound on a limb sum stays below 1/2 for both torus sets (the twist counted as a stage of its
+    own) and fails for 24-bit limbs at N = 2048 - which is why that set stores its key at 46 bits"""
+    import fft_bound as b
+    n1024, _ = b.limb_sum_bound(10, 3, 10, 24)
+    n2048, _ = b.limb_sum_bound(11, 3, 10, 23)
+    bad, _ = b.limb_sum_bound(11, 3, 10, 24)
+    assert 0.3 < n1024 < 0.5 and 0.3 < n2048 < 0.5 and bad > 0.5
