@@ -105,7 +105,8 @@ class EncryptedMatrixInversion:
     shape: Tuple[int, int]
 
     def __init__(self, n, sampler=None, qfloat_base=2, qfloat_len=32, qfloat_ints=16, true_division=False,
-                 tensorize=False, engine=None, device=0, shard_threshold=None, cache=True, unroll=False, q_bits=None):
+                 tensorize=False, engine=None, device=0, shard_threshold=None, cache=True, unroll=False, q_bits=None,
+                 params=None):
         """The reference's seven arguments (main.py:17-36), then: engine / device (the GPU context to use) and
         shard_threshold (with torch.distributed initialised on several ranks, levels at least this wide are split
         across the ranks' GPUs; None = every level wider than one kernel round, levels re-packed for the rank count,
@@ -113,7 +114,10 @@ class EncryptedMatrixInversion:
         coefficients per blind-rotation step (bmi_set_bsk_unroll; key noise 2^-41 so that the look-up margin of the default set
         is kept) - 2.6 ms per level instead of 3.6; q_bits (when this object creates the engine): the ciphertext modulus, None =
         the library's default (49-bit field), tfhe.TORUS64 = 2^64, the torus concrete-python computes on (its default set: Bg = 2^10,
-        bootstrap key at 48 bits of precision; with unroll=True the unrolled torus kernel, key noise unchanged)."""
+        bootstrap key at 48 bits of precision; with unroll=True the unrolled torus kernel, key noise unchanged); params (when
+        this object creates the engine): a named parameter set of the library ("secure128_torus", "secure128": the 128-bit-secure
+        sets, include/bmi_tfhe.h) or a tfhe.Params - what `fhe.Compiler.compile`'s parameter optimiser chooses for the reference
+        (main.py:53-66); it overrides q_bits."""
         self.shape = (n, n)
         self.qfloat_base, self.qfloat_len, self.qfloat_ints = qfloat_base, qfloat_len, qfloat_ints
         self.true_division, self.tensorize = true_division, tensorize
@@ -133,6 +137,9 @@ class EncryptedMatrixInversion:
         self.shard_threshold = shard_threshold
         self.unroll = bool(unroll)
         self.q_bits = q_bits
+        self.params = params
+        if engine is not None and params is not None:
+            raise ValueError("pass an engine or a parameter set, not both (the engine already has its parameters)")
         if engine is not None and q_bits is not None and engine.q_bits != q_bits:
             raise ValueError(f"q_bits={q_bits} but the engine passed in computes on q_bits={engine.q_bits}")
         if self.unroll and engine is not None and getattr(engine, "unroll", 1) != 2:
@@ -146,13 +153,20 @@ class EncryptedMatrixInversion:
             from . import tfhe  # raises BmiError when libbmi_tfhe.so or the GPU is missing: no CPU fallback
             # 4-bit look-ups: the north-star set (N = 1024); 5-bit ones (bases other than 2): N = 2048, same margin
             qb = self.q_bits
-            if self.msg_bits > 4 and qb not in (None, 49):
-                raise ValueError("look-ups wider than 4 bits need N >= 2048, which exists on the 49-bit field only")
-            params = tfhe.default_params(q_bits=qb) if self.msg_bits <= 4 else tfhe.default_params(q_bits=49, log_N=self.msg_bits + 6)
+            if self.params is not None:    # a named set of the library, or a tfhe.Params
+                params = tfhe.preset_params(self.params) if isinstance(self.params, str) else self.params
+            elif self.msg_bits <= 4:
+                params = tfhe.default_params(q_bits=qb)
+            elif self.msg_bits == 5 and qb == tfhe.TORUS64:   # 5-bit look-ups on the 2^64 torus: N = 2048 (k_blind_rotate_w_t64f)
+                params = tfhe.default_params(q_bits=tfhe.TORUS64, log_N=11)
+            elif qb in (None, 49):
+                params = tfhe.default_params(q_bits=49, log_N=self.msg_bits + 6)
+            else:
+                raise ValueError("look-ups wider than 5 bits need N = 4096, which exists on the 49-bit field only")
             if self.unroll:
                 if self.msg_bits > 4:
                     raise ValueError("bootstrap-key unrolling exists at N = 1024 (4-bit look-ups) only")
-                if params.q_bits == 49:     # three products per step: key noise 2^-41 keeps the default set's output noise
+                if params.q_bits == 49 and self.params is None:     # three products per step: key noise 2^-41 keeps the default set's output noise
                     params = tfhe.default_params(q_bits=49, glwe_noise=2.0 ** -41)
                 elif params.q_bits != tfhe.TORUS64:
                     raise ValueError("bootstrap-key unrolling exists on the 49-bit field and on the 2^64 torus")

@@ -579,58 +579,8 @@ def test_reference_functions_traced_unmodified_on_gpu(eng):
 
 
 
-def test_reference_whole_inverse_traced_unmodified_on_gpu():
-    """The reference's UNMODIFIED qfloat_matrix_inverse (tests/golden/ref_traced_inverse.json.gz, see the CPU test of the
-    same name) on ciphertexts: its unfused operator sequence needs 5-bit look-ups, so it runs on the N = 2048 parameter
-    set; 2x2 (len 20, ints 8: 2,395 PBS in 374 levels) on two matrices and 3x3 (len 30, ints 12: 34,032 PBS in 3,056
-    levels) on one, the 2x2 traced with lazy look-up fusion (306 levels) on two, decrypted digits against the reference's
-    plaintext outputs."""
-    import gzip
-    from bmi_amd import tfhe
-    from bmi_amd.circuit import Circuit
-    from bmi_amd.executor import Executor
-    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_traced_inverse.json.gz"), "rt") as f:
-        data = json.load(f)
-    e = tfhe.Engine(tfhe.default_params(q_bits=49, log_N=11))
-    try:
-        e.keygen(0x5EED)
-        dl = e.delta_log(5)
-        for case, n_vec in zip(data["cases"], (2, 1, 2)):
-            ex = Executor(Circuit.from_dict(case["circuit"]), e)
-            for v in case["vectors"][:n_vec]:
-                got = e.decrypt(ex.run(e.encrypt(v["inputs"], dl)), dl)
-                assert list(got) == v["expected"], case["name"]
-    finally:
-        e.close()
-
-
-def test_reference_own_fhe_tests_replayed_on_ciphertexts():
-    """The circuits the reference's own FHE test file compiled (tests/golden/ref_own_fhe_tests.json.gz, see the CPU test
-    of the same name) on ciphertexts: the inputs its tests used are encrypted, every look-up runs on the GPU (4-bit
-    circuits on the N = 1024 set, 5-bit ones on N = 2048), and the decrypted digits equal the outputs on which the
-    reference's own assertions passed."""
-    import gzip
-    from bmi_amd import tfhe
-    from bmi_amd.circuit import Circuit
-    from bmi_amd.executor import Executor
-    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_own_fhe_tests.json.gz"), "rt") as f:
-        data = json.load(f)
-    engines = {}
-    try:
-        for case in data["cases"]:
-            bits = case["msg_bits"]
-            if bits not in engines:
-                engines[bits] = tfhe.Engine(tfhe.default_params(q_bits=49, log_N={4: 10, 5: 11}[bits]))
-                engines[bits].keygen(0x5EED)
-            e = engines[bits]
-            ex = Executor(Circuit.from_dict(case["circuit"]), e)
-            dl = e.delta_log(bits)
-            for r in case["runs"]:
-                got = e.decrypt(ex.run(e.encrypt(r["inputs"], dl)), dl)
-                assert list(got) == r["outputs"], case["function"]
-    finally:
-        for e in engines.values():
-            e.close()
+# The reference's whole inverse traced unmodified, and the circuits of its own FHE test file, run on the reference back end's
+# modulus: tests/test_gpu_secure128_torus.py (q = 2^64, N = 2048).
 
 
 def test_shim_compiler_surface_runs_on_the_gpu(monkeypatch):
