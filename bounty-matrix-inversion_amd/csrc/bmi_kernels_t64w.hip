@@ -15,10 +15,12 @@
 //   B  all 1,024 threads = (output polynomial o, slot, tp): a pair of lanes 32 apart shares a slot - lane tp reads quarters tp and
 //      tp + 2 of each row, half a radix-4 butterfly each, ONE 2 x 2 transpose on lane bit 5 (v_permlane32_swap) completes it: two
 //      frequencies A_{kappa + 256 tp}, A_{kappa + 256 (tp + 2)} per thread and row, multiplied with both limbs' key words (32
-//      contiguous bytes per thread, row and limb; the first l rows requested before phase A, row r + l when row r is done);
+//      KiB per wavefront, row and limb; the first rows of a step are requested during the step before, row r + KD when row r is done);
 //      the inverse butterfly the same way back, times conj W_h -> the sums S_h (over the tiles, after a barrier)
-//   C  16 inverse tasks (limb, o, quarter): inverse quarter, nearest integer, shift into place, ONE LDS atomic add (f64) per
-//      coefficient into the accumulator (the two limbs of a coefficient meet there); re-centred mod 2^46 every 8 steps
+//   C  8 inverse tasks (o, quarter) on wavefronts 8 .. 15: the inverse quarters of BOTH limbs (two independent transforms in one
+//      wavefront), nearest integers, limb 1 shifted into place, one plain read-modify-write per coefficient of the accumulator
+//      (an LDS f64 atomic costs ~32 cycles per wavefront instruction: 128 of them per CMUX were 4.4 k cycles); re-centred mod 2^46
+//      every 8 steps
 #include <hip/hip_runtime.h>
 
 #include "bmi_internal.hpp"
@@ -39,6 +41,19 @@ using t64::Scheme;
 #ifndef BMI_T64W_KEY_ROWS_AHEAD
 #define BMI_T64W_KEY_ROWS_AHEAD 2   // key rows (of 2 l) a thread holds in registers: requested before phase A, then row r + this many when row r is done
 #endif
+#ifdef BMI_PHASE_PROF   // make -C csrc prof; tools/phase_prof_t64w.py
+__device__ unsigned long long g_phase_w[128];
+#define PH_DECL() unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = clock64()
+#define PH_MARK(k)                               \
+    do {                                         \
+        const unsigned long long t_ = clock64(); \
+        ph_[k] += t_ - tl_;                      \
+        tl_ = t_;                                \
+    } while (0)
+#else
+#define PH_DECL()
+#define PH_MARK(k)
+#endif
 constexpr int WN = 2048, WLOG = 11;
 constexpr int WQ = fftq::QUARTER;
 constexpr int WF_THREADS = 1024;
@@ -57,7 +72,7 @@ __device__ __forceinline__ uint32_t acc_slot(uint32_t n) { return (n & 3) * WF_R
 // standard-domain GGSW polynomials (u64 torus words, already rounded to the key precision) -> per (polynomial, limb) 1,024
 // complex words A_k / 2 in the order the multiplying threads read them: thread (w8 = slot / 32, lane) of phase B owns slot
 // p = 32 w8 + (lane & 31) and, with tp = lane >> 5, the frequencies kappa(p) + 256 (tp + 2 f), f = 0, 1 - complex word
-// (64 w8 + lane) 2 + f.  One workgroup of four wavefronts (the four quarters) per item.
+// 512 f + 64 w8 + lane (a wavefront's request is 1 KiB contiguous).  One workgroup of four wavefronts (the four quarters) per item.
 __global__ void __launch_bounds__(256) k_bsk_to_w_t64(const u64 *__restrict__ std_polys, double *__restrict__ w_polys,
                                                       const double *__restrict__ g_tw, uint32_t n_polys, int prec) {
     const int limbs = t64::limbs_of(prec);
@@ -91,7 +106,7 @@ __global__ void __launch_bounds__(256) k_bsk_to_w_t64(const u64 *__restrict__ st
         const int w8 = p >> 5, l5 = p & 31;
         static_for<0, 4>([&](auto T) {
             constexpr int tp = T & 1, f = T >> 1;
-            o[(w8 * 64 + tp * 32 + l5) * 2 + f] = double2{0.5 * A[T].r, 0.5 * A[T].i};
+            o[f * (WN / 4) + w8 * 64 + tp * 32 + l5] = double2{0.5 * A[T].r, 0.5 * A[T].i};
         });
     }
 }
@@ -137,20 +152,35 @@ __global__ void __launch_bounds__(WF_THREADS)
     const int mo = wave >> 3, w8 = wave & 7, tp = lane >> 5, mq = w8 * 32 + (lane & 31);
     uint32_t since_centred = 0;   // steps taken since the accumulator was last reduced mod 2^AB
     double dev = 0.0;             // STATS: largest |value - nearest integer| this lane has rounded away
+    PH_DECL();
 
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t a_t = at[i];
-        if (a_t == 0) continue;  // uniform over the workgroup
-        // key words of this thread: [row 2L][output 2][limb][(64 w8 + lane) 2 + f] complex
-        const double2 *kth = reinterpret_cast<const double2 *>(bsk_w + (size_t)i * 4 * L * LIMBS * WN) + (size_t)mo * LIMBS * (WN / 2) +
-                             (w8 * 64 + lane) * 2;
-        double2 kk[KD][LIMBS][2];   // rows 0 .. KD-1 now (they land under phase A), row r + KD when row r has been multiplied
+    // steps are the LWE coefficients that switch to a non-zero rotation (X^0 ACC - ACC = 0: the oracle skips those too)
+    auto next_step = [&](uint32_t i) {   // uniform over the workgroup
+        while (i < n && at[i] == 0) i++;
+        return i;
+    };
+    // key words of this thread at step i: [row 2L][output 2][limb][f][64 w8 + lane] complex
+    auto key_ptr = [&](uint32_t i) {
+        return reinterpret_cast<const double2 *>(bsk_w + (size_t)i * 4 * L * LIMBS * WN) + (size_t)mo * LIMBS * (WN / 2) + (w8 * 64 + lane);
+    };
+    // rows 0 .. KD-1 of a step are requested during the step BEFORE (after its products: they land under its inverse quarters and
+    // the next forward tasks), row r + KD when row r has been multiplied
+    double2 kk[KD][LIMBS][2];
+    auto request_first_rows = [&](const double2 *kth) {
         static_for<0, KD>([&](auto R) {
             static_for<0, LIMBS>([&](auto J) {
                 kk[R][J][0] = kth[((size_t)R * 2 * LIMBS + J) * (WN / 2)];
-                kk[R][J][1] = kth[((size_t)R * 2 * LIMBS + J) * (WN / 2) + 1];
+                kk[R][J][1] = kth[((size_t)R * 2 * LIMBS + J) * (WN / 2) + WN / 4];
             });
         });
+    };
+    uint32_t i = next_step(0);
+    if (i < n) request_first_rows(key_ptr(i));
+    while (i < n) {
+        const uint32_t a_t = at[i];
+        const double2 *kth = key_ptr(i);
+        const uint32_t i_next = next_step(i + 1);
+        PH_MARK(0);   // loop head, key requests
         auto forward_task = [&](const int T) {
             const int R = T >> 2, h = T & 3, c = R / L, lev = R % L;
             const double *ac = acc + c * WN;
@@ -191,11 +221,14 @@ __global__ void __launch_bounds__(WF_THREADS)
             static_for<0, 4>([&](auto R4) { tile[R4 * 64 + lane] = double2{v[R4].r, v[R4].i}; });
         };
         forward_task(wave);
+        PH_MARK(1);   // first forward task
         if constexpr (8 * L > 16) {
             pin();
             if (wave < 8 * L - 16) forward_task(16 + wave);
         }
+        PH_MARK(2);   // second forward task (wavefronts 0 .. 8 L - 17)
         __syncthreads();
+        PH_MARK(3);   // barrier A -> B
         C s_lo[LIMBS], s_hi[LIMBS];
         {
             C y[LIMBS][2];
@@ -219,7 +252,7 @@ __global__ void __launch_bounds__(WF_THREADS)
                 if constexpr (R + KD < 2 * L) {
                     static_for<0, LIMBS>([&](auto J) {
                         kk[R % KD][J][0] = kth[((size_t)(R + KD) * 2 * LIMBS + J) * (WN / 2)];
-                        kk[R % KD][J][1] = kth[((size_t)(R + KD) * 2 * LIMBS + J) * (WN / 2) + 1];
+                        kk[R % KD][J][1] = kth[((size_t)(R + KD) * 2 * LIMBS + J) * (WN / 2) + WN / 4];
                     });
                 }
                 pin();   // one row at a time: neither the next rows' tile reads nor their key requests move up (registers)
@@ -239,6 +272,9 @@ __global__ void __launch_bounds__(WF_THREADS)
                 s_hi[J] = fftq::cmul<true>(u - w, wh.x, wh.y);
             });
         }
+        if (i_next < n) request_first_rows(key_ptr(i_next));   // (uniform) the next step's first rows
+        pin();
+        PH_MARK(4);   // products of 2 L rows, inverse butterfly, next key requests
         __syncthreads();   // every thread has read the tiles: the sums may overwrite them
         static_for<0, LIMBS>([&](auto J) {
             double2 *sd = SD + (size_t)((J * 2 + mo) * 4) * WQ + mq;
@@ -246,37 +282,49 @@ __global__ void __launch_bounds__(WF_THREADS)
             sd[(tp + 2) * WQ] = double2{s_hi[J].r, s_hi[J].i};
         });
         __syncthreads();
-        {
-            const int j = wave >> 3, o = (wave >> 2) & 1, h = wave & 3;
-            const double2 *sd = SD + (size_t)((j * 2 + o) * 4 + h) * WQ;
-            C v[4];
-            static_for<0, 4>([&](auto R) {
-                const double2 t = sd[R * 64 + lane];
-                v[R] = C{t.x, t.y};
+        PH_MARK(5);   // barrier, the sums to LDS, barrier
+        if (wave >= 8) {   // (wavefronts 0 .. 7 ran two forward tasks where L = 3)
+            const int o = (wave >> 2) & 1, h = wave & 3;
+            double re[LIMBS][4], im[LIMBS][4];
+            static_for<0, LIMBS>([&](auto J) {
+                const double2 *sd = SD + (size_t)((J * 2 + o) * 4 + h) * WQ;
+                C v[4];
+                static_for<0, 4>([&](auto R) {
+                    const double2 t = sd[R * 64 + lane];
+                    v[R] = C{t.x, t.y};
+                });
+                fftq::inverse_quarter(v, re[J], im[J], lane, lds);
             });
-            double re[4], im[4];
-            fftq::inverse_quarter(v, re, im, lane, lds);
             double *ao = acc + o * WN + h * WF_RES + lane;
-            auto place = [&](double v) {   // the limb's exact integer (|.| < 2^45: nearest integer of the transform's output), shifted into place
-                double xr = __builtin_rint(v);
-                if constexpr (STATS) dev = __builtin_fmax(dev, __builtin_fabs(v - xr));
-                if (j == 0) return xr;
-                constexpr double W = (double)(1ull << (AB - LB));   // x 2^LB mod 2^AB: only the low AB - LB bits survive the shift
-                xr = __builtin_fma(-W, __builtin_rint(xr * (1.0 / W)), xr);
-                return xr * (double)(1ull << LB);
+            // a limb's exact integer (|.| < 2^45: nearest integer of the transform's output); limb 1 shifted into place: x 2^LB mod 2^AB,
+            // of which only the low AB - LB bits survive
+            auto place = [&](double v0, double v1) {
+                const double x0 = __builtin_rint(v0);
+                double x1 = __builtin_rint(v1);
+                if constexpr (STATS) dev = __builtin_fmax(dev, __builtin_fmax(__builtin_fabs(v0 - x0), __builtin_fabs(v1 - x1)));
+                constexpr double W = (double)(1ull << (AB - LB));
+                x1 = __builtin_fma(-W, __builtin_rint(x1 * (1.0 / W)), x1);
+                return __builtin_fma(x1, (double)(1ull << LB), x0);
             };
             static_for<0, 4>([&](auto R) {
-                atomicAdd(ao + 64 * R, place(re[R]));          // coefficient 4 (lane + 64 R) + h
-                atomicAdd(ao + 64 * R + 256, place(im[R]));    // ... + 1024
+                ao[64 * R] += place(re[0][R], re[1][R]);              // coefficient 4 (lane + 64 R) + h
+                ao[64 * R + 256] += place(im[0][R], im[1][R]);        // ... + 1024
             });
         }
+        PH_MARK(6);   // inverse quarters of both limbs, rounding, accumulation
         __syncthreads();
         if (++since_centred == WF_RECENTRE) {   // (uniform: counts the steps actually taken) keep the accumulator's magnitude below 2^51
             since_centred = 0;
             static_for<0, 4>([&](auto Q) { acc[tid + WF_THREADS * Q] = mod_ab(acc[tid + WF_THREADS * Q]); });
             __syncthreads();
         }
+        PH_MARK(7);   // closing barrier (+ re-centring every eighth step)
+        i = i_next;
     }
+#ifdef BMI_PHASE_PROF
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k_ = 0; k_ < 8; k_++) g_phase_w[wave * 8 + k_] = ph_[k_];
+#endif
     if constexpr (STATS) atomicMax(stat, (unsigned long long)__double_as_longlong(dev));   // non-negative doubles order like their bit patterns
     u64 *o = out + (size_t)ct * (WN + 1);
     static_for<0, 2>([&](auto Q) {
@@ -292,6 +340,12 @@ __global__ void __launch_bounds__(WF_THREADS)
 }
 
 }  // namespace
+
+#ifdef BMI_PHASE_PROF
+extern "C" int bmi_debug_phase_prof_t64w(unsigned long long *out128) {
+    return (int)hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_phase_w), sizeof(unsigned long long) * 128);
+}
+#endif
 
 namespace bmit {
 
