@@ -287,6 +287,9 @@ __global__ void __launch_bounds__(128 * TF_CTS)
 //      coefficient into the accumulator (the two limbs of a coefficient meet there)
 // The accumulator is the exact integer word / 2^16 in a double, as in the wave-pair kernel, but only re-centred mod 2^48 every
 // LF_RECENTRE steps (the atomic adds cannot reduce): 2^47 + 8 (2^45 + 2^47) < 2^51 keeps every sum exact.
+#ifndef BMI_LATF_ATOMIC
+XX
+#endif
 constexpr int LF_THREADS = 1024;
 constexpr int LF_MAX_L = 3;
 constexpr int LF_HALF = N / 2;
@@ -434,6 +437,7 @@ __global__ void __launch_bounds__(LF_THREADS)
             sd[LF_HALF / 2 + mq] = double2{d.r, d.i};
         }
         __syncthreads();
+#if BMI_LATF_ATOMIC
         if (wave < 4 * LIMBS) {
             const int j = wave >> 2, o = (wave >> 1) & 1, h = wave & 1;
             const double2 *sd = SD + (size_t)(j * 2 + o) * LF_HALF + h * (LF_HALF / 2);
@@ -458,6 +462,36 @@ __global__ void __launch_bounds__(LF_THREADS)
                 atomicAdd(ao + 64 * R + 256, place(im[R]));    // ... + 512
             });
         }
+#else
+        if (wave >= 12) {   // (wavefronts 12 .. 15 had no forward task) = (output polynomial, parity): the inverse halves of BOTH limbs
+            const int o = (wave >> 1) & 1, h = wave & 1;
+            double re[LIMBS][4], im[LIMBS][4];
+            static_for<0, LIMBS>([&](auto J) {
+                const double2 *sd = SD + (size_t)(J * 2 + o) * LF_HALF + h * (LF_HALF / 2);
+                ffth::C v[4];
+                static_for<0, 4>([&](auto R) {
+                    const double2 t = sd[R * 64 + lane];
+                    v[R] = ffth::C{t.x, t.y};
+                });
+                if (h) ffth::inverse_half<1>(v, re[J], im[J], lane, lds);
+                else ffth::inverse_half<0>(v, re[J], im[J], lane, lds);
+            });
+            double *ao = acc + o * N + h * LF_HALF + lane;
+            // a limb's exact integer (|.| < 2^45: nearest integer of the transform's output); limb 1 shifted into place: x 2^LB mod 2^AB,
+            // of which only the low AB - LB bits survive
+            auto place = [&](double v0, double v1) {
+                const double x0 = __builtin_rint(v0);
+                double x1 = __builtin_rint(v1);
+                constexpr double W = (double)(1ull << (AB - LB));
+                x1 = __builtin_fma(-W, __builtin_rint(x1 * (1.0 / W)), x1);
+                return __builtin_fma(x1, (double)(1ull << LB), x0);
+            };
+            static_for<0, 4>([&](auto R) {
+                ao[64 * R] += place(re[0][R], re[1][R]);              // coefficient 2 (lane + 64 R) + h
+                ao[64 * R + 256] += place(im[0][R], im[1][R]);        // ... + 512
+            });
+        }
+#endif
         __syncthreads();
         if (++since_centred == LF_RECENTRE) {   // (uniform: counts the steps actually taken) keep the accumulator's magnitude below 2^51
             since_centred = 0;
