@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(128 * TF_CTS)
 // The accumulator is the exact integer word / 2^16 in a double, as in the wave-pair kernel, but only re-centred mod 2^48 every
 // LF_RECENTRE steps (the atomic adds cannot reduce): 2^47 + 8 (2^45 + 2^47) < 2^51 keeps every sum exact.
 #ifndef BMI_LATF_ATOMIC
-XX
+#define BMI_LATF_ATOMIC 1   // phase C of the latency form: 1 = eight tasks (limb, output, parity) meeting by LDS f64 atomics, 0 = four tasks (output, parity) on wavefronts 12-15 running both limbs' inverse halves with plain read-modify-writes (A/B r04: 3.80 / 4.01 ms for 1 / 256 against 3.60 / 3.95 - four wavefronts leave the SIMDs idle; kept as an option)
 #endif
 constexpr int LF_THREADS = 1024;
 constexpr int LF_MAX_L = 3;
