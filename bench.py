@@ -1,32 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py — PBS throughput of the MI355X-native TFHE engine (BASELINE.json metric "PBS/sec per GPU").
+"""bench.py - PBS throughput of the MI355X-native TFHE engine (BASELINE.json metric "PBS/sec per GPU + encrypted n x n inverse
+wall-clock").
 
-`value` = whole-job PBS/s (the first half of BASELINE.json's metric) on the 2^64 TORUS, the ciphertext modulus Concrete - the
-reference's back end - computes on (since round 3 the fastest modulus here as well: exact limb products through an f64 FFT);
-the encrypted-inverse wall-clocks (the second half) are reported under config.encrypted_inverse_wall_clock* at N = 1.
-
-One "step" = one pass of the hot path (keyswitch -> mod-switch -> blind rotation -> sample extraction)
-over one batch of B synthetic ciphertexts per GPU, inputs already resident in HBM, at the north-star
-parameter set (n=630, N=1024, k=1, l=3).  The batch shards over GPUs with no data-path collective
-(independent ciphertexts; keys replicated) -> "scaling": "weak".
+`value` = whole-job PBS/s on the 2^64 TORUS (the ciphertext modulus Concrete, the reference's back end, computes on) at the
+north-star set (n=630, N=1024, k=1, l=3).  One "step" = one pass of the hot path (keyswitch -> mod-switch -> blind rotation ->
+sample extraction) over one batch of B synthetic ciphertexts per GPU, inputs already resident in HBM.  The batch shards over GPUs
+with no data-path collective (independent ciphertexts; keys replicated) -> "scaling": "weak".
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Started without a launcher (`WORLD_SIZE` unset) and with --gpus N > 1, it starts the N ranks itself (a
-torch.distributed.run child process, one rank per GPU, before this process touches a GPU) and exits with the child's
-code; it never prints a line for fewer GPUs than were asked for.
+Started without a launcher (`WORLD_SIZE` unset) and with --gpus N > 1, it starts the N ranks itself (a torch.distributed.run child
+process, one rank per GPU, before this process touches a GPU) and exits with the child's code; it never prints a line for fewer
+GPUs than were asked for.  Rank 0 prints ONE JSON line:
 
-Rank 0 prints ONE JSON line.  `roofline` follows the north star's definition (bootstrap-key bytes per PBS,
-no-reuse convention, against peak HBM bandwidth) for the dominant kernel (blind rotation), whose launch
-duration is measured live with events on the launch stream; `alu` adds the vector-ALU view the path is
-really bound by.  `cpu_baseline` times the oracle's fast path (exact f64 arithmetic, vectorised 32 x 32
-transforms, OpenMP over the batch; bit-identical to the generic oracle, re-checked on a sample inside the run) on this
-box's host cores, on a bounded sample of the same ciphertexts (N=1, rank 0 only).  `p49_field` / `torus64_unrolled_key` /
-`unrolled_key_49` / `roofline_q64_goldilocks` repeat the batch on the 49-bit prime field (rounds 1-2's headline: top-level
-value_p49 / frac_p49 ...), with the unrolled keys, and on the Goldilocks field; value_torus64 / frac_torus64 repeat the headline;
-`config.output_noise` compares the timed outputs' noise with the analytic CGGI variance; `roofline.alu` states the fraction of
-the vector-ALU issue roof (static instruction counts x live rate / 1,024 SIMDs x sampled shader clock).
+* top level: the contract's fields, then the scalars to quote - inverse_{2x2,3x3,4x4}_s (headline engine, evaluate wall-clock),
+  secure128_torus_{pbs_per_s, latency_ms_1, latency_ms_256, inverse_*_s} (the 128-bit-secure set on q = 2^64), value_p49 /
+  value_torus64_unrolled / inverse_3x3_s_{torus64_unrolled, p49_unrolled} (the other engines);
+* `roofline`: the PHYSICAL bound of the dominant kernel (f64 vector issue: static instruction counts x live launch rate against
+  1,024 SIMDs x the sampled shader clock), kernel_ms by events on the launch stream, kernel_cycles_per_cmux, `traffic` (HBM bytes
+  per launch, profiled); the north star's HBM-read convention (bootstrap-key bytes per PBS, no reuse, vs 8 TB/s) is
+  `roofline.north_star` / `roofline.north_star_frac`;
+* `cpu_baseline`: the oracle's fast path (exact f64 arithmetic, OpenMP over the batch; bit-identical to the generic oracle and to
+  the GPU, re-checked inside the run) on this box's host cores, on a bounded sample of the same ciphertexts (N=1, rank 0 only);
+* legs (N=1, rank 0; objects `secure128_torus`, `p49_field`, `torus64_unrolled_key`, `unrolled_key_49`; `--goldilocks-leg` adds the
+  Goldilocks kernels): PBS/s, kernel time, output noise against the CGGI formula, latency of 1 and 256, inverse wall-clocks.
 """
 import argparse
 import json
@@ -138,6 +136,69 @@ def rehearse_plumbing(args, rank, world):
     dist.destroy_process_group()
 
 
+INV_COMPACT = ("evaluate_s", "ms_per_level", "pbs", "depth", "matches_plaintext_circuit", "sharded_levels", "ranks")
+
+
+def compact(res):
+    """the printed line: long explanatory strings and the per-stage timings of the inverse legs stay in bench_details.json"""
+    def inv(d):
+        if not isinstance(d, dict):
+            return d
+        return {k: ({f: v[f] for f in INV_COMPACT if f in v} if isinstance(v, dict) and "evaluate_s" in v else v) for k, v in d.items()}
+
+    def leg(d):
+        if not isinstance(d, dict):
+            return d
+        out = {k: v for k, v in d.items() if k not in ("key", "arithmetic", "reference_readme_64core_cpu_run_s")}
+        if "encrypted_inverse_wall_clock" in out:
+            out["encrypted_inverse_wall_clock"] = inv(out["encrypted_inverse_wall_clock"])
+        if isinstance(out.get("alu"), dict):
+            out["alu"] = {k: v for k, v in out["alu"].items() if k in ("bound", "frac", "achieved", "peak", "unit", "sclk_mhz")}
+        return out
+
+    r = dict(res)
+    cfg = dict(res.get("config", {}))
+    for k in list(cfg):
+        if k.startswith("encrypted_inverse_wall_clock_") and k != "encrypted_inverse_wall_clock_sharded":
+            del cfg[k]                       # copies of the legs' reports
+    for k in ("encrypted_inverse_wall_clock", "encrypted_inverse_wall_clock_sharded"):
+        if k in cfg:
+            cfg[k] = inv(cfg[k])
+    rb = cfg.get("reference_readme_benchmark")
+    if isinstance(rb, dict) and "error" not in rb:
+        cfg["reference_readme_benchmark"] = {k: {f: v.get(f) for f in ("encrypt_run_decrypt_s", "total_cold_s", "speedup_run", "speedup_total_cold",
+                                                                      "matches_plaintext_circuit")} | {"reference_run_s": v["reference_readme"]["run_s"]}
+                                             for k, v in rb.items()}
+    cfg.pop("arithmetic", None)
+    cfg.pop("keys", None)
+    cfg.pop("multi_gpu_placement", None) if res.get("n_gpus", 1) == 1 else None
+    r["config"] = cfg
+    rl = dict(res.get("roofline", {}))
+    if isinstance(rl.get("alu"), dict):
+        rl["alu"] = {k: v for k, v in rl["alu"].items() if k not in ("sclk_source", "source", "valu_busy_source")}
+    rl.pop("traffic_source", None)
+    if isinstance(rl.get("north_star"), dict):
+        rl["north_star"] = {k: v for k, v in rl["north_star"].items() if k != "convention"}
+    r["roofline"] = rl
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):
+        r["cpu_baseline"] = {k: v for k, v in cb.items() if k not in ("host", "concrete")}
+    for k in ("secure128_torus", "torus64", "p49_field", "torus64_unrolled_key", "unrolled_key_49", "roofline_q64_goldilocks"):
+        if k in r:
+            r[k] = leg(r[k])
+    r["details"] = "gpurun_out/bench_details.json (every leg in full)"
+
+    def sig(o, top=True):   # nested floats to 5 significant digits (the top-level scalars stay as measured)
+        if isinstance(o, dict):
+            return {k: (v if (top and isinstance(v, float)) else sig(v, False)) for k, v in o.items()}
+        if isinstance(o, list):
+            return [sig(v, False) for v in o]
+        if isinstance(o, float) and o == o and abs(o) not in (0.0, float("inf")):
+            return float(f"{o:.5g}")
+        return o
+    return sig(r)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,15 +216,21 @@ def main():
     ap.add_argument("--no-readme-benchmark", action="store_true",
                     help="skip the reference's README benchmark configurations (2x2 / 3x3 low precision, ~20 s with cold compiles)")
     ap.add_argument("--no-second-field", action="store_true",
-                    help="skip the short extra legs that report PBS/s on the 2^64 torus and on the Goldilocks field (N=1, rank 0)")
-    ap.add_argument("--inverse-sizes", default="2,3,4", help="matrix sizes of the encrypted-inverse leg (N=1, rank 0): "
-                    "BASELINE configs 2, 3, 4 (~45 s together, most of it tracing the circuits); 8 takes ~2 min more")
+                    help="skip the extra legs (N=1, rank 0): the 128-bit-secure torus set, the 49-bit field, the unrolled keys")
+    ap.add_argument("--goldilocks-leg", action="store_true",
+                    help="also time the Goldilocks-field kernels (an independent implementation, 4x slower; never the product path)")
+    ap.add_argument("--no-secure-leg", action="store_true", help="skip the secure128_torus leg (n 742, N 2048 on q = 2^64)")
+    ap.add_argument("--inverse-sizes", default=None, help="matrix sizes of the encrypted-inverse legs: default 2,3,4 at N=1 (BASELINE "
+                    "configs 2, 3, 4 on rank 0; 8 takes ~2 min more) and 8 for --inverse-sharded (config 5: the one whose levels are wide "
+                    "enough to split)")
     ap.add_argument("--inverse-sharded", action="store_true",
                     help="N > 1 only (opt-in): also run the encrypted-inverse leg with its wide levels split across the "
                          "ranks (executor.py; one RCCL all-gather per split level)")
     ap.add_argument("--shard-threshold", type=int, default=None,
                     help="narrowest level that is split across ranks (default: every level wider than one kernel round)")
     args = ap.parse_args()
+    sharded_sizes = args.inverse_sizes or "8"
+    args.inverse_sizes = args.inverse_sizes or "2,3,4"
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -243,8 +310,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     clock.stop()
+    per_rank_s = [elapsed]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_s = [float(x.item()) for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     br_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
@@ -263,6 +334,7 @@ def main():
                  "(an integer below 2^45, transform error below 2^-11) rounded to the nearest integer and recombined mod 2^64 - the same "
                  "words as the oracle's integer arithmetic; keyswitch: int8 matrix cores"}
     DTYPE = {64: "u64", 49: "f64", 65: "u64/f64"}
+    CTS_PER_WG = {64: 2, 49: 4, 65: 4}       # ciphertexts per workgroup of the wave-pair kernels (one workgroup per compute unit)
 
     def key_weights(e):
         sk_small, sk_big = e.export_keys()[:2]
@@ -334,6 +406,26 @@ def main():
     alu = alu_roof(KERNEL[eng.q_bits], br_ms, B, P.n)
     alu["valu_busy_frac_profiled"] = valu_busy
     alu["valu_busy_source"] = "profiled-static (waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, profiles/hbm_traffic.json)"
+
+    def cycles_per_cmux(kernel_ms, count, n_lwe, cts_per_wg, clock_mhz):
+        """shader-clock cycles one workgroup spends per blind-rotation step: launch time x clock / (steps x workgroup rounds per CU)"""
+        rounds = -(-count // (cts_per_wg * 256))
+        return kernel_ms * 1e-3 * clock_mhz * 1e6 / (n_lwe * rounds)
+
+    north_star = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                  "algorithmic_bytes_per_pbs": BSK_BYTES_PER_PBS,
+                  "convention": "bootstrap-key bytes per PBS (no reuse) x PBS per launch / launch time vs peak HBM: BASELINE.json's figure "
+                                "(1e5 PBS/s = 0.774); not a physical roof - the key is shared by the batch and stays in L2 / MALL"}
+    # `roofline` is the PHYSICAL bound of the dominant kernel (vector issue: static instruction counts x live launch rate against
+    # 1,024 SIMDs x the sampled shader clock); the north star's HBM-read convention sits beside it as `north_star` / `north_star_frac`
+    roofline = {"bound": "valu_issue_f64", "achieved": alu.get("achieved"), "peak": alu.get("peak"), "unit": alu.get("unit", "SIMD issue cycles/s"),
+                "frac": alu.get("frac"), "traffic": traffic,
+                "traffic_vs_algorithmic": (None if traffic is None else traffic / (BSK_BYTES_PER_PBS * B)),
+                "traffic_source": "profiled-static: rocprofv3 --pmc pass of this command, profiles/hbm_traffic.json",
+                "kernel": KERNEL[eng.q_bits], "kernel_ms": br_ms,
+                "kernel_cycles_per_cmux": cycles_per_cmux(br_ms, B, P.n, CTS_PER_WG[eng.q_bits], sclk_mhz),
+                "sclk_mhz": sclk_mhz,
+                "north_star_frac": achieved_gbs / HBM_PEAK_GBS, "north_star": north_star, "alu": alu}
     res = {
         "metric": "PBS/sec per GPU + encrypted n x n inverse wall-clock (n=2,3,4)", "value": value, "unit": "PBS/s",
         "n_gpus": world, "world_size_seen": (dist.get_world_size() if dist is not None else 1),
@@ -344,23 +436,15 @@ def main():
                                f"(Bg=2^{P.bs_base_log}, ks 8x4 bits), q_bits={eng.q_bits}, 4-bit signed messages, 2 LUTs (identity, random)",
                    "arithmetic": ARITH[eng.q_bits],
                    "keys": "bmi_keygen_insecure_deterministic(0x5EED): one key set replicated on every rank without an exchange",
-                   "batch_per_gpu": B, "pbs_per_gpu_per_s": value / world, "verified_decrypt": verified,
+                   "batch_per_gpu": B, "pbs_per_gpu_per_s": value / world,
+                   "per_rank_pbs_per_s": [B * args.steps / t for t in per_rank_s],
+                   "verified_decrypt": verified,
                    "output_noise": output_noise(eng, out, want) if rank == 0 else None,
-                   "derived_reference_pbs_per_s_64core_cpu": "35-69 (derived, BASELINE.md §1)"},
-        "roofline": {"bound": "hbm", "physical_bound": ("f64 vector issue, LDS stores and L1 key intake together (each about half busy; DESIGN.md section 4): see `alu`"
-                                                       if eng.q_bits == 65 else "valu issue (f64): see `alu`"),
-                     "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "measured_hbm_frac": (None if traffic is None else traffic / (br_ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
-                     "traffic_source": "profiled-static: rocprofv3 --pmc pass of this command, profiles/hbm_traffic.json "
-                                       "(counters cannot be read from inside the process)",
-                     "convention": "north star: bootstrap-key bytes per PBS (no reuse) x PBS per launch / launch time vs peak "
-                                   "HBM; NOT a physical roof here - the key is shared by the batch and stays in L2/MALL "
-                                   "(measured traffic is ~1 % of it); the binding resource is under `alu`, whose frac is a "
-                                   "fraction of a physical roof",
-                     "kernel": KERNEL[eng.q_bits], "kernel_ms": br_ms,
-                     "algorithmic_bytes_per_pbs": BSK_BYTES_PER_PBS,
-                     "alu": alu},
+                   "multi_gpu_placement": "PBS batches shard over the ranks (contiguous ranges, no data-path collective); the encrypted "
+                                          "inverses of configs 2-4 are placed on ONE GPU by design (their levels are at most 256-1,024 wide: "
+                                          "one kernel round); --inverse-sharded splits the wide levels of the 8x8 across the ranks",
+                   "derived_reference_pbs_per_s_64core_cpu": "35-69 (derived, BASELINE.md section 1)"},
+        "roofline": roofline,
     }
 
     def latency_ms(e, d_small_x, d_ids_x, d_out_x, cnt):
@@ -411,6 +495,7 @@ def main():
         # Goldilocks times the generic path
         fast = eng.q_bits == 49 or (eng.q_bits == 65 and eng.bsk_precision == 48 and P.bs_base_log <= 10)
         octx = (to.FastCtx if fast else to.Ctx)(to.default_params(q_bits=eng.q_bits), bsk, ksk)
+        probe = octx.pbs(ct[:threads], tvs, lut_sel[:threads].astype(np.uint32))   # (first call: thread start-up, tables)
         t1 = time.perf_counter()
         probe = octx.pbs(ct[:threads], tvs, lut_sel[:threads].astype(np.uint32))
         per = (time.perf_counter() - t1)
@@ -427,14 +512,9 @@ def main():
             slow.close()
         res["cpu_baseline"] = {"value": sample / cpu_s, "unit": "PBS/s", "cores": threads, "host": host_info, "kind": "port",
                                "ms_per_pbs_per_thread": cpu_s / sample * threads * 1e3,
-                               "sample": f"first {sample} ciphertexts of the same batch, same keys/LUTs, oracle/tfhe_oracle.c "
-                                         + (("fast path (exact f64 arithmetic mod 2^49-720895, vectorised 32 x 32 four-step transforms, no "
-                                             "allocation per call; AVX-512/AVX2 clones)" if eng.q_bits == 49 else
-                                             "fast path on the torus (48-bit key as two 24-bit limbs, every limb sum exact mod 2^49-720895 in "
-                                             "f64 through the vectorised 32 x 32 four-step transforms - the arithmetic of the GPU's "
-                                             "exact-transform kernel -, accumulator as word / 2^16 in f64; AVX-512/AVX2 clones)")
-                                            if fast else "generic exact path")
-                                         + f", OpenMP over the batch, {cpu_s:.1f} s",
+                               "sample": f"first {sample} ciphertexts of the same batch, same keys / LUTs; oracle/tfhe_oracle.c "
+                                         + ("fast path (exact f64 arithmetic mod 2^49-720895; the torus as two 24-bit limbs; AVX-512 clones)" if fast
+                                            else "generic exact path") + f", OpenMP over the batch, {cpu_s:.1f} s",
                                "fast_path_matches_generic_path": self_check,
                                "gpu_matches_bit_for_bit": bit_exact,
                                "concrete": "Concrete not present (import concrete fails: not installed, no network)"}
@@ -445,9 +525,11 @@ def main():
         # the same batch on the 2^64 torus (Concrete's own ciphertext modulus: a first-class result, also printed at the top level as
         # value_torus64 / frac_torus64), with the unrolled keys, and on the Goldilocks field: 1 warm-up + 3 timed steps each, kernel
         # time by events; reported beside the headline, never `value`
-        def leg(qb, unroll=False, inverses=False):
+        def leg(qb, unroll=False, inverses=False, preset=None, batch=None):
             kw = {"glwe_noise": 2.0 ** -41} if (unroll and qb == 49) else {}
-            e2 = tfhe.Engine(tfhe.default_params(q_bits=qb, **kw), device=dev_index)
+            e2 = tfhe.Engine(tfhe.preset_params(preset) if preset else tfhe.default_params(q_bits=qb, **kw), device=dev_index)
+            B = batch or args.batch          # (shadows the headline's batch inside this leg)
+            msgs_l, lut_sel_l, want_l = msgs[:B], lut_sel[:B], want[:B]
             try:
                 if unroll:
                     e2.set_bsk_unroll(2)
@@ -455,10 +537,10 @@ def main():
                 dl2 = e2.delta_log()
                 i2 = e2.lut_register(np.arange(-8, 8), 4, dl2)
                 r2 = e2.lut_register(rnd_table, 4, dl2)
-                ct2 = e2.encrypt(msgs, dl2)
+                ct2 = e2.encrypt(msgs_l, dl2)
                 d_in2 = torch.from_numpy(ct2.view(np.int64)).to(dev)
-                d_ids2 = torch.from_numpy(np.where(lut_sel == 0, i2, r2).astype(np.int32)).to(dev)
-                d_small2 = torch.empty((B, P.small), dtype=torch.int64, device=dev)
+                d_ids2 = torch.from_numpy(np.where(lut_sel_l == 0, i2, r2).astype(np.int32)).to(dev)
+                d_small2 = torch.empty((B, e2.P.small), dtype=torch.int64, device=dev)
                 d_out2 = torch.empty_like(d_in2)
                 e2.pbs(d_in2, d_ids2, B, d_out2, stream)
                 torch.cuda.synchronize()
@@ -478,24 +560,31 @@ def main():
                 ck.stop()
                 kms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
                 out2 = d_out2.cpu().numpy().view(np.uint64)
-                ok2 = bool(np.array_equal(e2.decrypt(out2, dl2), want))
+                ok2 = bool(np.array_equal(e2.decrypt(out2, dl2), want_l))
                 Pe = e2.P
                 plain_key_bytes = Pe.n * 4 * Pe.bs_levels * Pe.N * 8
                 gbs = plain_key_bytes * B / (kms * 1e-3) / 1e9
-                kname = ({49: "k_blind_rotate_lat2u_49<3, 15>", 65: "k_blind_rotate_lat2u_t64<3, 10, 48>"}[qb] if unroll else KERNEL[qb])
-                rep = {"q_bits": qb, "pbs_per_s": B / dt, "ms_per_step": dt * 1e3, "verified_decrypt": ok2,
-                       "bs_base_log": int(Pe.bs_base_log), "bsk_precision_bits": int(e2.bsk_precision),
-                       "output_noise": output_noise(e2, out2, want, unrolled=unroll),
-                       "kernel": kname, "kernel_ms": kms, "achieved": gbs,
-                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "arithmetic": ARITH[qb],
-                       "frac_convention": "north star: the PLAIN bootstrap key's bytes per PBS (61,931,520 B, no reuse) x PBS per launch / "
-                                          "launch time vs 8 TB/s - the figure BASELINE.json's target (1e5 PBS/s = 0.774) is stated in"}
+                kname = ("k_blind_rotate_w_t64f<3, 10, 46, false>" if (qb == 65 and Pe.N == 2048) else
+                         {49: "k_blind_rotate_lat2u_49<3, 15>", 65: "k_blind_rotate_lat2u_t64<3, 10, 48>"}[qb] if unroll else KERNEL[qb])
+                one_wg_per_ct = unroll or Pe.N > 1024
+                sm, ss = ck.result()
+                rep = {"q_bits": qb, "params": {"n": int(Pe.n), "N": int(Pe.N), "k": int(Pe.k), "l": int(Pe.bs_levels), "log2_Bg": int(Pe.bs_base_log),
+                                                "ks": f"{Pe.ks_levels}x{Pe.ks_base_log} bits", "log2_lwe_noise": round(float(np.log2(Pe.lwe_noise)), 2),
+                                                "log2_glwe_noise": round(float(np.log2(Pe.glwe_noise)), 2)},
+                       "batch": B, "pbs_per_s": B / dt, "ms_per_step": dt * 1e3, "verified_decrypt": ok2,
+                       "bsk_precision_bits": int(e2.bsk_precision),
+                       "output_noise": output_noise(e2, out2, want_l, unrolled=unroll),
+                       "kernel": kname, "kernel_ms": kms,
+                       "kernel_cycles_per_cmux": cycles_per_cmux(kms, B, (Pe.n + 1) // 2 if unroll else Pe.n, 1 if one_wg_per_ct else CTS_PER_WG[qb], sm),
+                       "sclk_mhz": sm,
+                       "north_star": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                      "algorithmic_bytes_per_pbs": plain_key_bytes},
+                       "frac": gbs / HBM_PEAK_GBS}
                 if unroll:
                     own = (Pe.n + 1) // 2 * 3 * 4 * Pe.bs_levels * Pe.N * 8
                     rep["frac_own_key_bytes"] = own * B / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS
                     rep["own_key_bytes_per_pbs"] = own
-                else:   # wave-pair kernels: static instruction count x live rate against the issue roof at the clock sampled here
-                    sm, ss = ck.result()
+                elif not one_wg_per_ct:   # wave-pair kernels: static instruction count x live rate against the issue roof at the clock sampled here
                     c = isa.get(kname)
                     if c:
                         cyc = float(c["valu_issue_cycles"]) * 2 * Pe.n * B / (kms * 1e-3)
@@ -511,12 +600,13 @@ def main():
                     # the oracle's blind rotation (plain or unrolled mode) on a few ciphertexts of the batch: bit for bit
                     from oracle import tfhe_oracle as to
                     _, _, bsk_u, ksk_u = e2.export_keys()
-                    oc = to.Ctx(to.default_params(q_bits=qb), bsk_u, ksk_u)
+                    to.set_field(qb)
+                    oc = to.Ctx(to.Params(**{f: getattr(Pe, f) for f, _ in tfhe.Params._fields_}), bsk_u, ksk_u)
                     if unroll:
                         oc.set_bsk_unrolled(e2.export_bsk_unrolled())
                     tv2 = np.stack([e2.lut_get(i2), e2.lut_get(r2)])
-                    pick = np.arange(0, B, max(1, B // 6))[:6]
-                    wantu = oc.pbs(ct2[pick], tv2, lut_sel[pick].astype(np.uint32), unrolled=unroll)
+                    pick = np.arange(0, B, max(1, B // 6))[:(2 if Pe.N > 1024 else 6)]
+                    wantu = oc.pbs(ct2[pick], tv2, lut_sel_l[pick].astype(np.uint32), unrolled=unroll)
                     rep["bit_exact_vs_oracle"] = bool(np.array_equal(wantu, out2[pick]))
                     oc.close()
                     to.set_field(eng.q_bits)
@@ -529,26 +619,47 @@ def main():
                 e2.close()
 
         INV_FIELDS = ("len", "ints", "evaluate_s", "end_to_end_s", "ms_per_level", "pbs", "depth", "matches_plaintext_circuit")
-        legs = (("torus64", 65, False, False), ("p49_field", 49, False, True), ("torus64_unrolled_key", 65, True, True),
-                ("unrolled_key_49", 49, True, True), ("roofline_q64_goldilocks", 64, False, False))
-        for name, qb, un, inv in legs:
-            if qb == eng.q_bits and not un:
+        # (name, q_bits, unrolled key, inverse wall-clocks, preset, batch)
+        legs = [("torus64", 65, False, False, None, None), ("p49_field", 49, False, True, None, None),
+                ("torus64_unrolled_key", 65, True, True, None, None), ("unrolled_key_49", 49, True, True, None, None)]
+        if not args.no_secure_leg:
+            legs.insert(0, ("secure128_torus", 65, False, True, "secure128_torus", min(B, 2048)))
+        if args.goldilocks_leg:
+            legs.append(("roofline_q64_goldilocks", 64, False, False, None, None))
+        for name, qb, un, inv, preset, bt in legs:
+            if qb == eng.q_bits and not un and preset is None:
                 continue
             try:
-                res[name] = leg(qb, un, inv)
+                res[name] = leg(qb, un, inv, preset, bt)
             except Exception as e:  # reported, never hidden
                 res[name] = {"q_bits": qb, "error": repr(e)}
+
+        def inv_scalars(prefix, inv):
+            if isinstance(inv, dict):
+                for k, v in inv.items():
+                    if isinstance(v, dict) and "evaluate_s" in v:
+                        res[f"{prefix}inverse_{k}_s"] = v["evaluate_s"]
+
+        if "kernel_ms" in res.get("secure128_torus", {}):
+            st = res["secure128_torus"]
+            st["key"] = ("preset secure128_torus: n 742 at LWE noise 2^-17.1, N 2048 at GLWE noise 2^-44 (the 128-bit-secure pairs of TFHE-rs' "
+                         "PARAM_MESSAGE_2_CARRY_2_KS_PBS) on q = 2^64; (l, Bg) = (3, 2^10), key stored at 46 bits (two 23-bit limbs), exact limb "
+                         "sums through the folded 1,024-point f64 FFT; one workgroup of 16 wavefronts per ciphertext")
+            res["secure128_torus_pbs_per_s"] = st["pbs_per_s"]
+            res["secure128_torus_latency_ms_1"] = st.get("latency_ms_1")
+            res["secure128_torus_latency_ms_256"] = st.get("latency_ms_256")
+            inv = st.get("encrypted_inverse_wall_clock")
+            inv_scalars("secure128_torus_", inv)
+            if isinstance(inv, dict):
+                st["reference_readme_64core_cpu_run_s"] = {"2x2_len23_ints9": 85.0, "3x3_len23_ints9": "1349-1768",
+                                                           "note": "README.md:129-141: concrete-python 2.1.0 at its 128-bit defaults, `low` "
+                                                                   "precision (len 23, ints 9); the sizes here are BASELINE's (20, 8) / (30, 12) / (40, 16)"}
         if "kernel_ms" in res.get("torus64", {}):
-            res["torus64"]["key"] = ("the torus parameter set: (l, Bg) = (3, 2^10), bootstrap key stored at 48 bits of precision (two 24-bit "
-                                     "limbs, bmi_set_bsk_precision); CGGI's plain blind rotation")
-            # first-class torus results (Concrete's own ciphertext modulus)
             res["value_torus64"] = res["torus64"]["pbs_per_s"]
             res["frac_torus64"] = res["torus64"]["frac"]
             res["alu_frac_torus64"] = res["torus64"].get("alu", {}).get("frac")
             res["latency_ms_torus64"] = res["torus64"]["latency_ms_1"]
         if "kernel_ms" in res.get("p49_field", {}):
-            res["p49_field"]["key"] = ("the 49-bit prime field q = 2^49 - 720895 (rounds 1-2's headline): (l, Bg) = (3, 2^15), exact transform mod q "
-                                       "in f64; CGGI's plain blind rotation")
             res["value_p49"] = res["p49_field"]["pbs_per_s"]
             res["frac_p49"] = res["p49_field"]["frac"]
             res["alu_frac_p49"] = res["p49_field"].get("alu", {}).get("frac")
@@ -557,28 +668,26 @@ def main():
             if isinstance(inv, dict):
                 res["config"]["encrypted_inverse_wall_clock_p49"] = {k: {f: v.get(f) for f in INV_FIELDS} for k, v in inv.items()}
         if "kernel_ms" in res.get("torus64_unrolled_key", {}):
-            res["torus64_unrolled_key"]["key"] = ("the same set with the unrolled bootstrap key (1.5 x the plain key), two LWE coefficients per "
-                                                  "step; key noise unchanged (2^-44): output noise 2^-22.7")
             res["value_torus64_unrolled"] = res["torus64_unrolled_key"]["pbs_per_s"]
             res["frac_torus64_unrolled"] = res["torus64_unrolled_key"]["frac"]
             res["latency_ms_torus64_unrolled"] = res["torus64_unrolled_key"]["latency_ms_1"]
             inv = res["torus64_unrolled_key"].get("encrypted_inverse_wall_clock")
             if isinstance(inv, dict):
                 res["config"]["encrypted_inverse_wall_clock_torus64_unrolled_key"] = {k: {f: v.get(f) for f in INV_FIELDS} for k, v in inv.items()}
-                res["inverse_3x3_s_torus64"] = inv.get("3x3", {}).get("evaluate_s")
+                res["inverse_3x3_s_torus64_unrolled"] = inv.get("3x3", {}).get("evaluate_s")
         if "kernel_ms" in res.get("unrolled_key_49", {}):
-            res["unrolled_key_49"]["key"] = ("unrolled bootstrap key, 1.5 x the plain key (92.9 MB); glwe_noise 2^-41 (plain default: 2^-40) "
-                                             "keeps the output noise of the default set; `frac` uses the PLAIN key's bytes per PBS (north-star "
-                                             "convention), `frac_own_key_bytes` the unrolled key's")
             inv = res["unrolled_key_49"].get("encrypted_inverse_wall_clock")
             if isinstance(inv, dict):   # the wall-clocks to quote for EncryptedMatrixInversion(unroll=True)
                 res["config"]["encrypted_inverse_wall_clock_unrolled_key"] = {k: {f: v.get(f) for f in INV_FIELDS} for k, v in inv.items()}
+                res["inverse_3x3_s_p49_unrolled"] = inv.get("3x3", {}).get("evaluate_s")
 
     if not args.no_inverse and rank == 0 and world == 1:
         try:
             from bmi_amd import inverse_bench
             sizes = tuple(int(x) for x in args.inverse_sizes.split(",") if x)
             res["config"]["encrypted_inverse_wall_clock"] = inverse_bench.run(eng, sizes)
+            for k, v in res["config"]["encrypted_inverse_wall_clock"].items():   # the headline engine's wall-clocks, first class
+                res[f"inverse_{k}_s"] = v["evaluate_s"]
         except Exception as e:  # reported, never hidden
             res["config"]["encrypted_inverse_wall_clock"] = {"error": repr(e)}
         if not args.no_readme_benchmark:
@@ -589,12 +698,22 @@ def main():
 
     if args.inverse_sharded and world > 1:
         from bmi_amd import inverse_bench
-        sizes = tuple(int(x) for x in args.inverse_sizes.split(",") if x)
+        sizes = tuple(int(x) for x in sharded_sizes.split(",") if x)
         rep = inverse_bench.run(eng, sizes, shard_threshold=args.shard_threshold)   # collective: every rank calls it
         res["config"]["encrypted_inverse_wall_clock_sharded"] = rep
+        for k, v in rep.items():
+            res[f"inverse_{k}_s_sharded_{world}gpu"] = v["evaluate_s"]
+            res[f"inverse_{k}_sharded_levels"] = v.get("sharded_levels")
 
     if rank == 0:
-        print(json.dumps(res))
+        # the complete report goes to gpurun_out/bench_details.json (scratch; merged back by gpurun); the printed line keeps the
+        # contract's fields, the scalars to quote and a compact form of every leg, so that a tail of stdout still holds all of it
+        try:
+            os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+            json.dump(res, open(os.path.join(REPO, "gpurun_out", "bench_details.json"), "w"), indent=1)
+        except Exception:
+            pass
+        print(json.dumps(compact(res)))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
