@@ -380,11 +380,13 @@ class Circuit:
         if -half <= x.lo and x.hi < half:
             return self.lut(x, _LT0)  # fits the ordinary message space (and possibly a coarser one: wider boxes)
         table = tuple([1] * half + [-1] * half)     # in half units: (bit - 1/2) * 2 on m = -half .. half - 1
-        key = (self.msg_bits, table)
+        # a half-scale table has its own identity: an ordinary look-up with the same entries (f(v) = 1 if v < 0 else -1) must not
+        # share the index, or the executor would register it at half the output scale too
+        key = (self.msg_bits, table, "half")
         li = self._lut_index.get(key)
         if li is None:
             li = len(self.luts)
-            self.luts.append(key)
+            self.luts.append((self.msg_bits, table))
             self._lut_index[key] = li
         self.half_luts.add(li)
         snap = self._snapshot(x)
@@ -466,7 +468,8 @@ class Circuit:
         c.leaf_level, c.leaf_lo, c.leaf_hi = list(d["leaf_level"]), list(d["leaf_lo"]), list(d["leaf_hi"])
         c.nodes = [(tuple(tuple(t) for t in terms), const, li, leaf) for terms, const, li, leaf in d["nodes"]]
         c.luts = [(p, tuple(tab)) for p, tab in d["luts"]]
-        c._lut_index = {k: i for i, k in enumerate(c.luts)}
+        half = set(d.get("half_luts", ()))
+        c._lut_index = {(k + ("half",) if i in half else k): i for i, k in enumerate(c.luts)}
         c.outputs = [(tuple(tuple(t) for t in terms), const) for terms, const in d["outputs"]]
         c.claims = [((tuple(tuple(t) for t in snap[0]), snap[1]), lo, hi) for snap, lo, hi in d["claims"]]
         c.wide_leaves = set(d["wide_leaves"])

@@ -1,17 +1,18 @@
-"""Tracer-compatible stand-in for `concrete.fhe` that runs the reference's UNMODIFIED base_p_arrays.py / qfloat.py on
-this repo's circuit IR (bmi_amd.circuit), i.e. on MI355X ciphertexts.  Development tooling, never imported by the
-product: to trace the REFERENCE's functions it needs /root/reference (build container only; that is how the fixtures
-under tests/golden/ref_*.json* were made), while the shim itself is this repo's own code and one GPU test
-(tests/test_gpu_inverse.py::test_shim_compiler_surface_runs_on_the_gpu) imports it on the GPU box with a purpose-written
-function, to exercise its `ENCSHIM_BACKEND=gpu` Circuit (encrypt / run / decrypt through the engine).
+"""`concrete.fhe`-compatible front end of the MI355X engine (see bmi_amd/compat/__init__.py for the supported surface and how to
+put it on the import path): the reference's UNMODIFIED base_p_arrays.py / qfloat.py / qfloat_matrix_inversion.py / main.py trace
+into this package's circuit IR (bmi_amd.circuit) and run on LWE ciphertexts, every look-up a programmable bootstrap on the GPU.
 
-How it works (the reference is data-oblivious, so its sequence of operations is the same on every input):
-  1. MEASURE: the function runs on an inputset; every encrypted scalar carries the vector of its sample values, and
+How a function is compiled (the reference is data-oblivious, so its sequence of operations is the same on every input):
+  1. MEASURE: the function runs on the inputset; every encrypted scalar carries the vector of its sample values, and
      every non-linear operation (comparison, //, %, abs, sign, bit-wise op, ciphertext product, fhe.univariate) records
      the range its operand takes - what Concrete's compiler does with its inputset (main.py:41-66).
   2. BUILD: the function runs again on symbolic values (Lin); the k-th non-linear operation claims the range measured
      for it (`Lin.assume`, verified by `Circuit.simulate`) and becomes a table look-up of the circuit.
-Operator surface: SURVEY.md section 8b."""
+  3. PARAMETERS: the circuit is frozen into a Program (pruned, scheduled) and the first parameter set of the engine whose error
+     budget for THIS circuit is at most `Configuration(global_p_error=...)` (default 1e-5, Concrete's) is chosen
+     (bmi_amd/error_budget.py); `Configuration(security_level=128)` restricts the choice to the 128-bit-secure set.
+Operator surface: SURVEY.md section 8b.  Fixture generation (tools/gen_ref_traced.py, tools/gen_ref_fhe_tests.py) runs this same
+front end with BMI_COMPAT_BACKEND=simulate in the build container, where the reference exists and a GPU does not."""
 import operator as _op
 
 import numpy as np
@@ -432,8 +433,9 @@ def trace(fn, input_ranges, inputset, msg_bits=6, fuse=False, bitwidth=False):
     inputset: list of argument tuples (lists of ints).  Returns (circuit, n_outputs)."""
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "..", "..",
-                                    "bounty-matrix-inversion_amd"))
+    pkg_root = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "..", ".."))
+    if pkg_root not in sys.path:          # <pkg root>/bmi_amd/compat/concrete/fhe/__init__.py
+        sys.path.insert(0, pkg_root)
     from bmi_amd.circuit import Circuit
 
     def flat(res):
@@ -480,7 +482,13 @@ def trace(fn, input_ranges, inputset, msg_bits=6, fuse=False, bitwidth=False):
 # every compiled circuit and every input it was run on are written out as data, for the GPU suite to replay on
 # ciphertexts (tests/golden/ref_own_fhe_tests.json.gz, tools/gen_ref_fhe_tests.py).
 class Configuration:
-    def __init__(self, **options):
+    """fhe.Configuration: `p_error` / `global_p_error` bound the probability that noise makes a result wrong (global: the whole
+    circuit, which is what this front end budgets - a per-look-up `p_error` is turned into a global one by the look-up count);
+    `security_level=128` restricts the parameter choice to the 128-bit-secure set.  Concrete's other options (key cache, dataflow,
+    graph printing, precision strategy: qfloat_matrix_inversion.py:995-1002) are accepted and have no counterpart here."""
+
+    def __init__(self, p_error=None, global_p_error=None, security_level=None, **options):
+        self.p_error, self.global_p_error, self.security_level = p_error, global_p_error, security_level
         self.options = options
 
 
@@ -489,7 +497,9 @@ _ENGINES = {}
 
 
 def _backend():
-    return os.environ.get("ENCSHIM_BACKEND", "simulate")
+    """gpu (default): encrypt / run / decrypt on LWE ciphertexts through the engine; simulate: plaintext evaluation of the same
+    circuit (BMI_COMPAT_BACKEND, or the older ENCSHIM_BACKEND)"""
+    return os.environ.get("BMI_COMPAT_BACKEND") or os.environ.get("ENCSHIM_BACKEND") or "gpu"
 
 
 def _inner_name(fn):
@@ -505,7 +515,8 @@ def _inner_name(fn):
 
 
 class Circuit:
-    def __init__(self, fn, inputset, fuse=False):
+    def __init__(self, fn, inputset, fuse=False, configuration=None):
+        self.configuration = configuration or Configuration()
         samples = [[np.asarray(a) for a in one] for one in inputset]
         self.shapes = [a.shape for a in samples[0]]
         flat_set = [tuple([int(v) for v in a.reshape(-1)] for a in one) for one in samples]
@@ -532,23 +543,53 @@ class Circuit:
         if os.environ.get("ENCSHIM_RECORD"):
             _RECORDED.append(self)
 
-    # ---- back ends.  ENCSHIM_BACKEND=gpu: encrypt / run / decrypt work on LWE ciphertexts through this repo's engine
-    # (bmi_amd.tfhe.Engine + executor: every look-up a programmable bootstrap on the MI355X; the parameter set follows
-    # the circuit's look-up width: 4 bits N = 1024, 5 bits N = 2048, 6 bits N = 4096).  Default: the plaintext simulator.
+    # ---- back ends.  Default: encrypt / run / decrypt work on LWE ciphertexts through the engine (bmi_amd.tfhe.Engine + executor:
+    # every look-up a programmable bootstrap on the MI355X).  The parameter set is the first one of the chosen modulus whose error
+    # budget for this circuit meets the configuration's global_p_error (4-bit look-ups: N = 1024, or N = 2048 where the look-up
+    # count needs the margin; 5 bits: N = 2048; 6 bits: N = 4096 on the 49-bit field).  BMI_COMPAT_BACKEND=simulate: plaintext.
+    def program(self):
+        if getattr(self, "_prog", None) is None:
+            from bmi_amd.program import Program
+            self._prog = Program.from_circuit(self.circuit, meta={"kind": "compat", "function": self.name})
+        return self._prog
+
+    def _p_error_target(self):
+        cfg = self.configuration
+        if cfg.global_p_error is not None:
+            return float(cfg.global_p_error)
+        if cfg.p_error is not None:          # per look-up -> whole circuit
+            return min(1.0, float(cfg.p_error) * max(len(self.circuit.nodes), 1))
+        return 1e-5                          # Concrete's default global_p_error
+
+    def choose_parameters(self):
+        """(tfhe.Params, error-budget report) for this circuit under its configuration"""
+        from bmi_amd import error_budget, tfhe
+        qb = int(os.environ.get("BMI_COMPAT_Q_BITS", str(tfhe.TORUS64)))
+        prog = self.program()
+        secure = self.configuration.security_level is not None
+        if secure and int(self.configuration.security_level) != 128:
+            raise ValueError("security_level: only 128 has a parameter set (secure128_torus / secure128)")
+        try:
+            return error_budget.choose_params(prog, self._p_error_target(), q_bits=qb, secure=secure)
+        except ValueError:
+            if qb != 49 and not secure:      # 6-bit look-ups exist on the 49-bit field only
+                return error_budget.choose_params(prog, self._p_error_target(), q_bits=49)
+            raise
+
     def _gpu(self):
         if getattr(self, "_ex", None) is None:
             from bmi_amd import tfhe
             from bmi_amd.executor import Executor
-            bits = self.circuit.msg_bits
-            if bits not in _ENGINES:
-                if bits > 6:
-                    raise ValueError(f"a {bits}-bit look-up does not fit any parameter set of the engine (at most 6 bits)")
-                eng = tfhe.Engine(tfhe.default_params(q_bits=49, log_N={4: 10, 5: 11, 6: 12}[bits]))
-                eng.keygen(int(os.environ.get("ENCSHIM_KEY_SEED", "24301")))
-                _ENGINES[bits] = eng
-            self._eng = _ENGINES[bits]
-            self._ex = Executor(self.circuit, self._eng)
-            self._dl = self._eng.delta_log(bits)
+            P, self.error_budget = self.choose_parameters()
+            key = (int(P.q_bits), int(P.log_N), int(P.n), float(P.lwe_noise))
+            if key not in _ENGINES:
+                eng = tfhe.Engine(P)
+                seed = os.environ.get("BMI_COMPAT_KEY_SEED") or os.environ.get("ENCSHIM_KEY_SEED")
+                eng.keygen(int(seed) if seed else None)        # CSPRNG keys unless the test-only seed is given
+                _ENGINES[key] = eng
+            self._eng = _ENGINES[key]
+            self._ex = Executor(self.program(), self._eng)
+            self._dl = self._eng.delta_log(self.circuit.msg_bits)
         return self._ex
 
     def keygen(self, *a, **k):
@@ -596,7 +637,7 @@ class Compiler:
         self.function, self.statuses = function, dict(parameter_encryption_statuses)
 
     def compile(self, inputset, configuration=None, verbose=False, **_):
-        return Circuit(self.function, list(inputset))
+        return Circuit(self.function, list(inputset), configuration=configuration)
 
 
 def _dump_recorded():

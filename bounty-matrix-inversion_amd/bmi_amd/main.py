@@ -106,18 +106,23 @@ class EncryptedMatrixInversion:
 
     def __init__(self, n, sampler=None, qfloat_base=2, qfloat_len=32, qfloat_ints=16, true_division=False,
                  tensorize=False, engine=None, device=0, shard_threshold=None, cache=True, unroll=False, q_bits=None,
-                 params=None):
+                 params=None, p_error=None):
         """The reference's seven arguments (main.py:17-36), then: engine / device (the GPU context to use) and
         shard_threshold (with torch.distributed initialised on several ranks, levels at least this wide are split
         across the ranks' GPUs; None = every level wider than one kernel round, levels re-packed for the rank count,
         see executor.py); unroll (when this object creates the engine, 4-bit look-ups): bootstrap-key unrolling, two LWE
         coefficients per blind-rotation step (bmi_set_bsk_unroll; key noise 2^-41 so that the look-up margin of the default set
         is kept) - 2.6 ms per level instead of 3.6; q_bits (when this object creates the engine): the ciphertext modulus, None =
-        the library's default (49-bit field), tfhe.TORUS64 = 2^64, the torus concrete-python computes on (its default set: Bg = 2^10,
-        bootstrap key at 48 bits of precision; with unroll=True the unrolled torus kernel, key noise unchanged); params (when
+        the library's default = tfhe.TORUS64 = 2^64, the torus concrete-python computes on (its default set: Bg = 2^10,
+        bootstrap key at 48 bits of precision; with unroll=True the unrolled torus kernel, key noise unchanged), 49 = the prime field
+        2^49 - 720895 (with unroll=True the engine with the shortest single bootstrap: 0.83 s for the 3x3 against 1.26 s); params (when
         this object creates the engine): a named parameter set of the library ("secure128_torus", "secure128": the 128-bit-secure
         sets, include/bmi_tfhe.h) or a tfhe.Params - what `fhe.Compiler.compile`'s parameter optimiser chooses for the reference
-        (main.py:53-66); it overrides q_bits."""
+        (main.py:53-66); it overrides q_bits; p_error (when this object creates the engine and params is not given): the bound on
+        the probability that noise makes the whole evaluation wrong (Concrete's `global_p_error`, 1e-5 there) - the first
+        parameter set of the chosen modulus whose error budget for THIS circuit meets it is taken (error_budget.choose_params:
+        N = 1024 for small circuits, N = 2048 where the look-up count needs the wider margin, e.g. the 8x8 inverse); None keeps
+        the north-star set and reports its budget in `self.error_budget`."""
         self.shape = (n, n)
         self.qfloat_base, self.qfloat_len, self.qfloat_ints = qfloat_base, qfloat_len, qfloat_ints
         self.true_division, self.tensorize = true_division, tensorize
@@ -138,6 +143,8 @@ class EncryptedMatrixInversion:
         self.unroll = bool(unroll)
         self.q_bits = q_bits
         self.params = params
+        self.p_error = p_error
+        self.error_budget = None      # filled when the engine exists: Program.failure_probability under its parameters
         if engine is not None and params is not None:
             raise ValueError("pass an engine or a parameter set, not both (the engine already has its parameters)")
         if engine is not None and q_bits is not None and engine.q_bits != q_bits:
@@ -155,16 +162,21 @@ class EncryptedMatrixInversion:
             qb = self.q_bits
             if self.params is not None:    # a named set of the library, or a tfhe.Params
                 params = tfhe.preset_params(self.params) if isinstance(self.params, str) else self.params
+            elif self.p_error is not None:  # the first set of this modulus whose error budget for this circuit meets p_error
+                from . import error_budget
+                params, self.error_budget = error_budget.choose_params(self.program, self.p_error, q_bits=qb, unroll=self.unroll)
             elif self.msg_bits <= 4:
                 params = tfhe.default_params(q_bits=qb)
             elif self.msg_bits == 5 and qb == tfhe.TORUS64:   # 5-bit look-ups on the 2^64 torus: N = 2048 (k_blind_rotate_w_t64f)
                 params = tfhe.default_params(q_bits=tfhe.TORUS64, log_N=11)
-            elif qb in (None, 49):
+            elif self.msg_bits == 5 and qb is None:           # the library's default modulus (the torus) carries 5 bits at N = 2048
+                params = tfhe.default_params(log_N=11)
+            elif qb in (None, 49):                            # 6-bit look-ups: N = 4096, 49-bit field only
                 params = tfhe.default_params(q_bits=49, log_N=self.msg_bits + 6)
             else:
                 raise ValueError("look-ups wider than 5 bits need N = 4096, which exists on the 49-bit field only")
             if self.unroll:
-                if self.msg_bits > 4:
+                if self.msg_bits > 4 or params.log_N != 10:
                     raise ValueError("bootstrap-key unrolling exists at N = 1024 (4-bit look-ups) only")
                 if params.q_bits == 49 and self.params is None:     # three products per step: key noise 2^-41 keeps the default set's output noise
                     params = tfhe.default_params(q_bits=49, glwe_noise=2.0 ** -41)
@@ -176,6 +188,11 @@ class EncryptedMatrixInversion:
         if self.engine.P.N < (1 << (self.msg_bits + 6)):
             raise ValueError(f"{self.msg_bits}-bit look-ups need a parameter set with N >= {1 << (self.msg_bits + 6)} "
                              f"(this engine has N = {self.engine.P.N})")
+        if self.error_budget is None:
+            self.error_budget = self.program.failure_probability(self.engine)
+            if self.p_error is not None and self.error_budget["p_fail"] > self.p_error:
+                raise ValueError(f"this circuit's failure probability under the engine's parameters is {self.error_budget['p_fail']:.2e} "
+                                 f"> p_error = {self.p_error:g}: pass a wider parameter set (e.g. log_N=11) or let this object choose")
         return self.engine
 
     def keygen(self, seed=None):
@@ -238,22 +255,63 @@ class EncryptedMatrixInversion:
         flat = self._flat_inputs(quantized_matrix, qfloats_signs)
         return np.array(self.circuit.simulate(flat), dtype=np.int64).reshape(n2, self.qfloat_len + 1)
 
+    @staticmethod
+    def _dist():
+        """torch.distributed when it is initialised on more than one rank, else None"""
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                return dist
+        except Exception:
+            pass
+        return None
+
+    def _broadcast(self, dist, arr, src=0):
+        """a numpy array from rank `src` to every rank (through the GPU when the backend is RCCL)"""
+        import torch
+        a = np.ascontiguousarray(arr)
+        t = torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a)
+        on_gpu = dist.get_backend() == "nccl"
+        if on_gpu:
+            t = t.to(torch.device("cuda", self._engine().device))
+        dist.broadcast(t, src=src)
+        out = t.cpu().numpy() if on_gpu else t.numpy()
+        return out.view(a.dtype)
+
     def run(self, matrix: np.ndarray, simulate=False, validate=True) -> np.ndarray:
         """The reference's one-call form (main.py:93-116).  validate (encrypted runs): the caller of run() holds the
         plaintext, so the compiled program is first evaluated in plaintext with every interval claim checked
         (program.Program.simulate: 0.07 s for 3x3, 2 s for 8x8) - an input the circuit was not traced for (a singular
         matrix whose reciprocal overflows its format, an entry beyond the leading-digit range) raises RangeError here
         instead of decrypting to garbage silently, which is what an encrypted evaluation outside its ranges does (on
-        Concrete as well: its circuits are only defined on the ranges their inputset showed)."""
+        Concrete as well: its circuits are only defined on the ranges their inputset showed).  With torch.distributed
+        initialised on several ranks every rank calls run() with the same matrix: rank 0 (the holder of the secret keys after
+        keygen()) encrypts and decrypts, ciphertexts and result are broadcast, every rank returns the same inverse."""
         assert np.issubdtype(matrix.dtype, np.floating)
         assert matrix.shape == self.shape
         quantized_matrix, qfloats_signs = self.quantize(matrix)
         if not simulate:
             if validate:
                 self.simulate(quantized_matrix, qfloats_signs)
-            enc = self.encrypt(quantized_matrix, qfloats_signs)
-            enc_inv = self.evaluate(enc)
-            quantized_inverted_matrix = self.decrypt(enc_inv)
+            dist = self._dist()
+            if dist is None:
+                enc = self.encrypt(quantized_matrix, qfloats_signs)
+                enc_inv = self.evaluate(enc)
+                quantized_inverted_matrix = self.decrypt(enc_inv)
+            else:
+                # several ranks (the sharded executor): keygen() left the secret keys on rank 0 only, so rank 0 encrypts and
+                # decrypts and the ciphertexts / the result travel by broadcast; every rank walks the levels and returns the
+                # same matrix
+                eng = self._engine()
+                n_ct = self.circuit.n_inputs
+                enc = (self.encrypt(quantized_matrix, qfloats_signs) if dist.get_rank() == 0
+                       else np.zeros((n_ct, eng.P.big), np.uint64))
+                enc = self._broadcast(dist, enc)
+                enc_inv = self.evaluate(enc)
+                n2 = self.shape[0] * self.shape[1]
+                quantized_inverted_matrix = (self.decrypt(enc_inv) if dist.get_rank() == 0
+                                             else np.zeros((n2, self.qfloat_len + 1), np.int64))
+                quantized_inverted_matrix = self._broadcast(dist, quantized_inverted_matrix)
         else:
             quantized_inverted_matrix = self.simulate(quantized_matrix, qfloats_signs)
         inverted_matrix = self.dequantize(quantized_inverted_matrix)

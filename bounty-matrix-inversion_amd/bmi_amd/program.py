@@ -194,6 +194,18 @@ class Program:
                 "median_width": float(np.median(w)) if w.size else 0.0, **{k: v for k, v in self.meta.items()
                                                                            if isinstance(v, (int, float, str))}}
 
+    def failure_probability(self, params, bsk_precision=None, unroll=False, hw_small=None, hw_big=None):
+        """Probability that an encrypted evaluation under the parameter set `params` (tfhe.Params, or an Engine) decodes a wrong
+        integer somewhere because of noise: the sum over the look-ups of the Gaussian tail at each look-up's own margin (its
+        linear combination's amplification included), plus the outputs' decryption tails (error_budget.py).  What Concrete's
+        `p_error` / `global_p_error` bound for the reference (main.py:53-66)."""
+        from . import error_budget
+        if hasattr(params, "P") and hasattr(params, "bsk_precision"):        # an Engine
+            eng = params
+            return error_budget.failure_probability(self, eng.P, eng.bsk_precision if eng.q_bits == 65 else None,
+                                                    getattr(eng, "unroll", 1) == 2, hw_small, hw_big)
+        return error_budget.failure_probability(self, params, bsk_precision, unroll, hw_small, hw_big)
+
     # ---- construction ---------------------------------------------------------------------------------------------
     @classmethod
     def from_circuit(cls, c: Circuit, meta=None, prune=True, native=True):

@@ -560,6 +560,7 @@ int bmi_get_params(const bmi_ctx *c, bmi_params *out) {
 namespace {
 int upload_eval_keys(bmi_ctx *c);
 int upload_bsk3(bmi_ctx *c);
+int build_exact_torus_copies(bmi_ctx *c, const u64 *d_std);
 }
 
 namespace {
@@ -756,6 +757,37 @@ int upload_bsk3(bmi_ctx *c) {
     return 0;
 }
 
+// 2^64 torus at N = 1024: the key copies of the exact-transform kernels (wave pairs: d_bsk; latency form: d_bsk_lat).  d_std = the
+// standard-domain key on the device, or null to upload it from the host copy.  Contexts whose key has floating-point-transform
+// copies build these on demand only (kernel variants 1 / 3 / 4).
+int build_exact_torus_copies(bmi_ctx *c, const u64 *d_std) {
+    if (c->d_bsk && c->d_bsk_lat) return 0;
+    const size_t bsk_words = c->bsk_std.size();
+    u64 *d_own = nullptr;
+    if (!d_std) {
+        HIP_OK(c, hipMalloc(&d_own, bsk_words * 8));
+        HIP_OK(c, hipMemcpy(d_own, c->bsk_std.data(), bsk_words * 8, hipMemcpyHostToDevice));
+        d_std = d_own;
+    }
+    auto bail = [&](const char *m) {
+        if (d_own) (void)hipFree(d_own);
+        return fail(c, -2, m);
+    };
+    if (!c->d_bsk) {
+        if (hipMalloc(&c->d_bsk, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) return bail("hipMalloc(torus limb key) failed");
+        if (bmit::launch_bsk_to_limbs(d_std, (double *)c->d_bsk, (const double *)c->d_tw, (uint32_t)(bsk_words / c->N), c->bsk_prec, c->stream))
+            return bail("bsk_to_limbs launch failed");
+    }
+    if (!c->d_bsk_lat) {
+        if (hipMalloc(&c->d_bsk_lat, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) return bail("hipMalloc(torus latency-kernel key) failed");
+        if (bmit::launch_bsk_to_lat(d_std, c->d_bsk_lat, c->d_tw_half, (uint32_t)(bsk_words / c->N), c->bsk_prec, c->stream))
+            return bail("bsk_to_lat (torus) launch failed");
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (d_own) (void)hipFree(d_own);
+    return e == hipSuccess ? 0 : fail(c, -2, "hipStreamSynchronize failed");
+}
+
 // Evaluation keys (host copies in c->bsk_std / c->ksk) -> device: bootstrap key to the NTT domain (both layouts for
 // the 49-bit field), keyswitch key in word form (+ bias vector) and in limb form.
 int upload_eval_keys(bmi_ctx *c) {
@@ -781,28 +813,14 @@ int upload_eval_keys(bmi_ctx *c) {
         }
         rc = bmit::launch_bsk_to_wide(d_tmp, c->d_bsk_w, c->d_tw_fq, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
         if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_wide (torus) launch failed"); }
-    } else if (c->t64()) {  // 2^64 torus: bsk_limbs transform-domain limb polynomials per key polynomial
-        if (c->d_bsk) { (void)hipFree(c->d_bsk); c->d_bsk = nullptr; }
-        if (hipMalloc(&c->d_bsk, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) {
-            (void)hipFree(d_tmp);
-            return fail(c, -2, "hipMalloc(torus limb key) failed");
-        }
-        rc = bmit::launch_bsk_to_limbs(d_tmp, (double *)c->d_bsk, (const double *)c->d_tw, (uint32_t)(bsk_words / N),
-                                       c->bsk_prec, c->stream);
-        if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_limbs launch failed"); }
-        // second copy for the latency kernel, per limb in the slot order of the two-wave half transform
-        if (c->d_bsk_lat) { (void)hipFree(c->d_bsk_lat); c->d_bsk_lat = nullptr; }
-        if (hipMalloc(&c->d_bsk_lat, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) {
-            (void)hipFree(d_tmp);
-            return fail(c, -2, "hipMalloc(torus latency-kernel key) failed");
-        }
-        rc = bmit::launch_bsk_to_lat(d_tmp, c->d_bsk_lat, c->d_tw_half, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
-        if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat (torus) launch failed"); }
-        // third copy where the floating-point transform carries the exact products (48-bit key, base 2^10): the wave-pair
-        // kernel of bmi_kernels_t64f.hip, same results at ~half the instructions
-        if (c->d_bsk_fft) { (void)hipFree(c->d_bsk_fft); c->d_bsk_fft = nullptr; }
-        if (c->d_bsk_latf) { (void)hipFree(c->d_bsk_latf); c->d_bsk_latf = nullptr; }
-        if (c->d_tw_fft && bmit::shape_supported_fft(c->bsk_prec, P.bs_levels, P.bs_base_log)) {
+    } else if (c->t64()) {  // 2^64 torus at N = 1024: bsk_limbs transform-domain limb polynomials per key polynomial
+        for (void **p : {&c->d_bsk, (void **)&c->d_bsk_lat, (void **)&c->d_bsk_fft, (void **)&c->d_bsk_latf})
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+        const bool fft = c->d_tw_fft && bmit::shape_supported_fft(c->bsk_prec, P.bs_levels, P.bs_base_log);
+        if (fft) {
+            // the kernels auto dispatch runs on this key (48 bits, base 2^10): the wave-pair and the latency form of
+            // bmi_kernels_t64f.hip, exact limb products through the floating-point transform.  The two copies of the
+            // exact-transform kernels (variants 1 / 3 / 4: A/B only) are built when such a variant is first pinned.
             if (hipMalloc(&c->d_bsk_fft, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) {
                 (void)hipFree(d_tmp);
                 return fail(c, -2, "hipMalloc(torus fft key) failed");
@@ -815,6 +833,9 @@ int upload_eval_keys(bmi_ctx *c) {
             }
             rc = bmit::launch_bsk_to_latf(d_tmp, c->d_bsk_latf, c->d_tw_fh, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
             if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_latf (torus) launch failed"); }
+        } else {
+            HIP_OK(c, hipStreamSynchronize(c->stream));
+            if (int rc2 = build_exact_torus_copies(c, d_tmp)) { (void)hipFree(d_tmp); return rc2; }
         }
     } else if (c->wide() || c->quad()) {  // N = 2048 / 4096: one key copy, in the slot order of k_blind_rotate_wide49 / quad49
         if (!c->d_bsk_lat && hipMalloc(&c->d_bsk_lat, bsk_words * 8) != hipSuccess) {
@@ -1224,6 +1245,7 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
                                                    c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }
+        if (int rcb = build_exact_torus_copies(c, nullptr)) return rcb;   // (variants 1 / 3 / 4, or a key without FFT copies: no-op once built)
         if (lat_t) {
             rc = bmit::launch_blind_rotate_lat(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_lat, c->d_tw_half, d_out,
                                                count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);

@@ -6,7 +6,7 @@
 #include "goldilocks.hpp"
 
 #ifndef BMI_DEFAULT_Q_BITS
-#define BMI_DEFAULT_Q_BITS 49  // modulus of bmi_default_params(): 64 (Goldilocks) or 49 (f64 kernels)
+#define BMI_DEFAULT_Q_BITS 65  // modulus of bmi_default_params(): 65 = BMI_Q_TORUS64 (q = 2^64, Concrete's own: the default since round 4), 49 (f64 kernels mod 2^49 - 720895) or 64 (Goldilocks)
 #endif
 
 #ifndef BMI_TP49_CTS

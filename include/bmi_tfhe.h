@@ -58,15 +58,17 @@ typedef struct {
     double glwe_noise;    /* std-dev / q of bootstrap-key rows and fresh big-key encryptions */
 } bmi_params;
 
-/* The north-star parameter set of BASELINE.json (n=630, N=1024, k=1, l=3) with the build's default modulus. */
+/* The north-star parameter set of BASELINE.json (n=630, N=1024, k=1, l=3) with the build's default modulus: q = 2^64
+ * (BMI_Q_TORUS64, the modulus concrete-python computes on; Bg = 2^10, bootstrap key at 48 bits of precision).  One default across
+ * the library, EncryptedMatrixInversion, smoke() and bench.py. */
 int bmi_default_params(bmi_params *out);
-/* ... and with an explicit choice of the ciphertext modulus (q_bits = 64 or 49). */
+/* ... and with an explicit choice of the ciphertext modulus (q_bits = BMI_Q_TORUS64, 49 or 64). */
 int bmi_default_params_for(uint32_t q_bits, bmi_params *out);
 
 /* Named parameter sets:
- *   "north_star"            BASELINE.json's shape (n 630, N 1024, k 1, l 3) on the 49-bit field - bmi_default_params
- *   "north_star_torus64"    the same shape on the 2^64 torus with Bg = 2^10 (two-limb key at 48 bits of precision, see
- *                           bmi_set_bsk_precision);  "north_star_goldilocks": (l 3, Bg 2^15) on 2^64 - 2^32 + 1
+ *   "north_star_torus64"    BASELINE.json's shape (n 630, N 1024, k 1, l 3) on the 2^64 torus, Concrete's own modulus, with
+ *                           Bg = 2^10 (two-limb key at 48 bits of precision, see bmi_set_bsk_precision) - bmi_default_params
+ *   "north_star"            the same shape on the 49-bit field q = 2^49 - 720895, Bg = 2^15 (rounds 1-2's default);  "north_star_goldilocks": (l 3, Bg 2^15) on 2^64 - 2^32 + 1
  *   "secure128"             n 742, N 2048, k 1, l 2 x 15 bits, keyswitch 8 x 2 bits, 49-bit field, LWE noise 7.07e-6
  *                           (2^-17.1), GLWE noise 2^-44.  Security: the (dimension, noise / q) pairs are those of TFHE-rs'
  *                           published 128-bit set PARAM_MESSAGE_2_CARRY_2_KS_PBS (lwe_dimension 742, lwe std 7.07e-6;

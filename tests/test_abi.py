@@ -36,7 +36,7 @@ def test_default_params_are_the_north_star_set():
         O = to.default_params(q_bits=qb)  # same numbers as the oracle's default set
         for f, _ in tfhe.Params._fields_:
             assert getattr(P, f) == getattr(O, f), f
-    assert tfhe.default_params().q_bits in (64, 49)
+    assert tfhe.default_params().q_bits == tfhe.TORUS64          # one default modulus everywhere: q = 2^64, Concrete's own
 
 
 def test_no_gpu_means_loud_failure():

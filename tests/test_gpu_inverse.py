@@ -189,9 +189,9 @@ def test_encrypted_8x8_inverse_matches_reference_golden(eng):
     """BASELINE config 5 (8x8, len 48, ints 16) on ONE MI355X, every look-up on ciphertexts: 2.58 M PBS over 2,886
     levels; decrypted digits and signs == the reference's plaintext output (tests/golden/inverse.json,
     qfloat_matrix_inversion.py:672-720).  The ciphertext store holds the live set only (recycled rows)."""
-    if eng.q_bits == 64 or (eng.q_bits == 65 and os.environ.get("BMI_TEST_TORUS_8X8") != "1"):
-        pytest.skip("config 5 runs on the 49-bit field; on the 2^64 torus with BMI_TEST_TORUS_8X8=1 (tools/gpu_torus_8x8.sh, "
-                    "recorded in profiles/) - it is bound by throughput, 40 s there")
+    if eng.q_bits != 65:
+        pytest.skip("config 5 runs on the headline engine (2^64 torus, FFT kernels) here, on both unrolled engines in "
+                    "tests/test_gpu_unrolled.py / test_gpu_torus_unrolled.py, and at global_p_error 1e-5 in tests/test_gpu_secure128_torus.py")
     import time
     from bmi_amd.main import EncryptedMatrixInversion
     c = next(x for x in load("inverse.json") if x["tag"] == "baseline_n8_len48_ints16")
@@ -207,11 +207,14 @@ def test_encrypted_8x8_inverse_matches_reference_golden(eng):
     res = emi.evaluate(enc)
     wall = time.time() - t0
     out = emi.decrypt(res)
-    # 2.1 M look-ups, most of them full 4-bit ones at the 6.2 sigma the north star's (n 630, N 1024) leave: a wrong digit is
-    # expected about once per ~1,000 runs of this test - rerun before suspecting the kernels
-    margin_note = ("8x8 digits differ: with 2.1 M look-ups at a 6.2 sigma decision margin (north-star parameters n 630, N 1024, 4-bit "
-                   "messages) about 1 run in 1,000 fails by noise alone; rerun once before suspecting the kernels")
-    print(f"encrypted 8x8 (len 48, ints 16): {wall:.1f} s, store {ex.store_bytes() / 1e9:.2f} GB, "
+    # the error budget of this circuit under the north-star parameters (n 630, N 1024: full 4-bit look-ups at 6.2 sigma), computed
+    # from the program (bmi_amd/error_budget.py): a wrong digit by noise alone is expected about once per 1 / p_fail runs
+    budget = emi.error_budget
+    assert budget["lookups"] == emi.program.n_nodes > 1_900_000 and 2e-4 < budget["p_fail"] < 3e-3
+    margin_note = (f"8x8 digits differ: this circuit's failure probability by noise under the north-star parameters is {budget['p_fail']:.1e} "
+                   f"({budget['lookups']} look-ups, worst margin {budget['worst_margin_sigma']:.1f} sigma) - EncryptedMatrixInversion(p_error=1e-5) "
+                   "picks N = 2048 for it (tests/test_gpu_secure128_torus.py)")
+    print(f"encrypted 8x8 (len 48, ints 16): {wall:.1f} s, store {ex.store_bytes() / 1e9:.2f} GB, p_fail {budget['p_fail']:.1e}, "
           f"compile {emi.compile_info}, {emi.circuit.summary()}")
     assert out.shape == (64, 49)
     assert out.tolist() == c["out"], margin_note
@@ -583,16 +586,19 @@ def test_reference_functions_traced_unmodified_on_gpu(eng):
 # modulus: tests/test_gpu_secure128_torus.py (q = 2^64, N = 2048).
 
 
-def test_shim_compiler_surface_runs_on_the_gpu(monkeypatch):
-    """tools/encshim's `fhe.Compiler(...).compile(inputset)` circuit with ENCSHIM_BACKEND=gpu: encrypt / run / decrypt go
-    through the engine (LWE ciphertexts, every look-up a bootstrap on the GPU) - what a reference user gets by putting the
-    shim ahead of `concrete` on PYTHONPATH on an MI355X machine.  Exercised here with a small function written for this
-    test (binary addition with carries on encrypted digit arrays): the reference itself cannot travel to the GPU box."""
+def test_concrete_compatible_front_end_runs_on_the_gpu(monkeypatch):
+    """bmi_amd/compat: `fhe.Compiler(...).compile(inputset)` -> keygen / encrypt / run / decrypt on LWE ciphertexts, every look-up a
+    bootstrap on the GPU (the default back end) - what a reference user gets by putting the front end ahead of `concrete` on the
+    import path on an MI355X machine (reference call sites: main.py:53-86, tests/test_qfloat_fhe.py:136-149).  Exercised with a
+    small function written for this test (binary addition with carries on encrypted digit arrays): the reference itself cannot
+    travel to the GPU box.  The parameter set follows the configuration: global_p_error picks N, security_level=128 the secure set."""
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "encshim"))
+    import bmi_amd.compat
+    bmi_amd.compat.install()
+    from concrete import fhe
+    monkeypatch.delenv("BMI_COMPAT_BACKEND", raising=False)
+    monkeypatch.delenv("ENCSHIM_BACKEND", raising=False)
     try:
-        from concrete import fhe
-        monkeypatch.setenv("ENCSHIM_BACKEND", "gpu")
         D = 6
 
         def add_digits(a, b):            # most significant digit first
@@ -609,19 +615,22 @@ def test_shim_compiler_surface_runs_on_the_gpu(monkeypatch):
         rng = np.random.default_rng(8)
         inputset = [(rng.integers(0, 2, D), rng.integers(0, 2, D)) for _ in range(60)]
         inputset += [(np.ones(D, dtype=np.int64), np.ones(D, dtype=np.int64)), (np.zeros(D, dtype=np.int64), np.zeros(D, dtype=np.int64))]
-        circuit = fhe.Compiler(lambda x, y: add_digits(x, y), {"x": "encrypted", "y": "encrypted"}).compile(inputset)
-        circuit.keygen()
-        for _ in range(5):
-            a, b = rng.integers(0, 2, D), rng.integers(0, 2, D)
-            enc = circuit.encrypt(a, b)
-            assert enc[0].shape == (2 * D, 1025)                       # ciphertexts, not integers
-            got = circuit.decrypt(circuit.run(enc))
-            want = int("".join(map(str, a)), 2) + int("".join(map(str, b)), 2)
-            assert int("".join(map(str, got)), 2) == want
-            assert list(got) == list(circuit.simulate(a, b))
+        compiler = fhe.Compiler(lambda x, y: add_digits(x, y), {"x": "encrypted", "y": "encrypted"})
+        for cfg, want_n, want_N in ((None, 630, 1024), (fhe.Configuration(security_level=128, global_p_error=1e-9), 742, 2048)):
+            circuit = compiler.compile(inputset, configuration=cfg)
+            circuit.keygen()
+            assert (circuit._eng.q_bits, circuit._eng.P.n, circuit._eng.P.N) == (65, want_n, want_N)
+            assert circuit.error_budget["p_fail"] <= (1e-5 if cfg is None else 1e-9)
+            for _ in range(3):
+                a, b = rng.integers(0, 2, D), rng.integers(0, 2, D)
+                enc = circuit.encrypt(a, b)
+                assert enc[0].shape == (2 * D, want_N + 1)                   # ciphertexts, not integers
+                got = circuit.decrypt(circuit.run(enc))
+                want = int("".join(map(str, a)), 2) + int("".join(map(str, b)), 2)
+                assert int("".join(map(str, got)), 2) == want
+                assert list(got) == list(circuit.simulate(a, b))
     finally:
         from concrete import fhe as _f
         for e in _f._ENGINES.values():
             e.close()
         _f._ENGINES.clear()
-        sys.path.pop(0)

@@ -224,10 +224,10 @@ def test_unrolled_torus_output_noise_on_the_formula_and_timing(eng, capsys):
     assert 0.88 < ratio < 1.12
 
 
-@pytest.mark.parametrize("tag", ["baseline_n2_len20_ints8", "baseline_n3_len30_ints12", "baseline_n4_len40_ints16",
+@pytest.mark.parametrize("tag", ["baseline_n2_len20_ints8", "baseline_n3_len30_ints12", "baseline_n4_len40_ints16", "baseline_n8_len48_ints16",
                                  "overflow_digit_2x2", "overflow_digit_3x3", "uniform_3x3_small_truediv", "uniform_2x2_tensorize"])
 def test_encrypted_inverse_on_the_torus_with_the_unrolled_key_matches_reference_golden(tag, capsys):
-    """BASELINE configs 2-4, the overflow-digit cases and the true-division / tensorize modes on 2^64-torus ciphertexts with
+    """BASELINE configs 2-5, the overflow-digit cases and the true-division / tensorize modes on 2^64-torus ciphertexts with
     EncryptedMatrixInversion(q_bits=65, unroll=True): decrypted digits == the reference's plaintext QFloat output
     (tests/golden/inverse.json, generated from the reference)."""
     from bmi_amd.main import EncryptedMatrixInversion
@@ -242,12 +242,13 @@ def test_encrypted_inverse_on_the_torus_with_the_unrolled_key_matches_reference_
         q, s = emi.quantize(M)
         enc = emi.encrypt(q, s)
         emi._executor()
-        emi.evaluate(enc)                           # warm-up
+        if c["n"] < 8:
+            emi.evaluate(enc)                       # warm-up (skipped for the long 8x8 run)
         t0 = time.time()
         res = emi.evaluate(enc)
         wall = time.time() - t0
         out = emi.decrypt(res)
-        assert out.tolist() == c["out"]
+        assert out.tolist() == c["out"], f"circuit failure probability by noise under these parameters: {emi.error_budget['p_fail']:.1e}"
         with capsys.disabled():
             print(f"\ntorus, unrolled key, {tag}: evaluate {wall:.2f} s, {emi.circuit.summary()['depth']} levels, {wall / emi.circuit.summary()['depth'] * 1e3:.2f} ms per level")
     finally:

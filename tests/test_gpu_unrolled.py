@@ -238,7 +238,7 @@ def test_encrypted_inverse_with_the_unrolled_key_matches_reference_golden(tag, c
     with open(os.path.join(os.path.dirname(__file__), "golden", "inverse.json")) as f:
         cases = json.load(f)
     c = next(x for x in cases if x["tag"] == tag)
-    emi = EncryptedMatrixInversion(c["n"], None, 2, c["len"], c["ints"], c["true_division"], c["tensorize"], unroll=True)
+    emi = EncryptedMatrixInversion(c["n"], None, 2, c["len"], c["ints"], c["true_division"], c["tensorize"], unroll=True, q_bits=49)
     try:
         emi.keygen()                                # CSPRNG keys
         assert emi.engine.P.glwe_noise == 2.0 ** -41

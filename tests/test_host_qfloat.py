@@ -529,7 +529,7 @@ def test_evaluate_without_gpu_fails_loudly():
 
 def test_reference_functions_traced_unmodified_simulate():
     """tests/golden/ref_traced.json (tools/gen_ref_traced.py): the reference's UNMODIFIED base_p_arrays / QFloat functions,
-    traced in the build container through the Tracer-compatible shim (tools/encshim) into this IR and stored as data.
+    traced in the build container through the Concrete-compatible front end (bmi_amd/compat) into this IR and stored as data.
     The deserialised circuits must reproduce the reference's own plaintext outputs recorded beside them."""
     data = load("ref_traced.json")
     assert len(data["cases"]) >= 9
@@ -550,7 +550,7 @@ def load_gz(name):
 def test_reference_whole_inverse_traced_unmodified_simulate():
     """tests/golden/ref_traced_inverse.json.gz: the reference's UNMODIFIED `qfloat_matrix_inverse`
     (qfloat_matrix_inversion.py:672-720, with everything it calls in qfloat.py / base_p_arrays.py) traced through
-    tools/encshim at BASELINE.json's sizes (2x2 len 20 ints 8; 3x3 len 30 ints 12), ranges measured on a 2,000-matrix
+    bmi_amd/compat at BASELINE.json's sizes (2x2 len 20 ints 8; 3x3 len 30 ints 12), ranges measured on a 2,000-matrix
     inputset as Concrete's compiler does; the third case is the 2x2 again with the shim's lazy look-up fusion (values
     that are univariate in one linear combination stay tables until they meet another one: 374 -> 306 levels).  The
     stored circuits reproduce the reference's own plaintext outputs, and our
@@ -571,7 +571,7 @@ def test_reference_whole_inverse_traced_unmodified_simulate():
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/matrix_inversion"), reason="needs the reference checkout (build container only)")
 def test_shim_retraces_the_reference_to_the_committed_fixture():
-    """Generator guard, build container only: the Tracer-compatible shim (tools/encshim) run again on the reference's
+    """Generator guard, build container only: the Concrete-compatible front end (bmi_amd/compat) run again on the reference's
     unmodified `base_p_subtraction` and `QFloat.__mul__` gives circuits that agree with the committed fixture on its
     vectors (the trace is deterministic up to the random inputset, so outputs are compared, not node lists); the whole
     inverse in the reference's other modes (tensorize=True: its multi_* functions; true_division=True), with and without
@@ -582,7 +582,7 @@ def test_shim_retraces_the_reference_to_the_committed_fixture():
     code = r'''
 import json, os, random, sys
 repo = sys.argv[1]
-sys.path[:0] = [os.path.join(repo, "tools", "encshim"), "/root/reference/matrix_inversion", os.path.join(repo, "bounty-matrix-inversion_amd")]
+sys.path[:0] = [os.path.join(repo, "bounty-matrix-inversion_amd", "bmi_amd", "compat"), "/root/reference/matrix_inversion", os.path.join(repo, "bounty-matrix-inversion_amd")]
 import numpy as np
 from concrete import fhe
 import base_p_arrays as ref

@@ -154,3 +154,162 @@ def test_two_rank_sharded_executor_matches_simulation(tmp_path):
             assert sharded == 0      # no level of this small circuit needs more than one kernel round
         else:
             assert (sharded == total) if threshold == 1 else (0 < sharded < total)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The same executor on a circuit whose DEFAULT schedule shards (BASELINE config 4: levels up to 3,072 wide), on 2 and on 8
+# ranks - the launch shape of the driver's scaling run - and the reference's one-call form `run()` on two ranks (rank 0 holds the
+# secret keys: it encrypts and decrypts, ciphertexts and result travel by broadcast).  The stand-in engine is vectorised
+# (one tensor operation per level and stage), so that a quarter of a million look-ups per rank run in seconds.
+class _VecEngine(_PlainEngine):
+    """the call surface of tfhe.Engine on plaintext rows (last word = 2 x message: delta_log 1), whole levels at a time"""
+    q_bits = 65
+    bsk_precision = 48
+
+    class P(_PlainParams):
+        N = 1024
+
+    def __init__(self, secret=True):
+        super().__init__()
+        self.secret = secret
+        self._tab = None
+
+    def _tables(self):
+        if self._tab is None or self._tab[0].shape[0] != len(self.tables):
+            T = torch.zeros((len(self.tables), 32), dtype=torch.int64)
+            P = torch.zeros(len(self.tables), dtype=torch.int64)
+            for j, (p, t) in enumerate(self.tables):
+                T[j, : len(t)] = torch.tensor(t, dtype=torch.int64)
+                P[j] = p
+            self._tab = (T, P)
+        return self._tab
+
+    def lincomb(self, store, rp, ix, cf, cs, count, out, stream=0):
+        rp = rp[: count + 1].to(torch.int64)
+        e0, e1 = int(rp[0]), int(rp[count])
+        seg = torch.repeat_interleave(torch.arange(count), rp[1:] - rp[:-1])
+        acc = torch.zeros((count, self.P.big), dtype=torch.int64)
+        if e1 > e0:
+            acc.index_add_(0, seg, store[ix[e0:e1].to(torch.int64)] * cf[e0:e1].to(torch.int64)[:, None])
+        acc[:, -1] += cs[:count].to(torch.int64)
+        out[:count] = acc
+
+    def scatter_rows(self, src, count, store, rows, stream=0):
+        store[rows[:count].to(torch.int64)] = src[:count]
+
+    def pbs(self, d_in, ids, count, d_out, stream=0):
+        T, P = self._tables()
+        ids = ids[:count].to(torch.int64)
+        x = d_in[:count, -1]
+        assert not bool((x % 2 != 0).any())      # whole multiples of Delta reach a look-up
+        p = P[ids]
+        m = (x >> 1) >> (4 - p)
+        half = torch.ones_like(p) << (p - 1)
+        hi, lo = m >= half, m < -half            # the other half of the torus (Circuit.lut_odd inputs): negacyclic wrap-around
+        idx = torch.where(hi, m - half, torch.where(lo, m + 3 * half, m + half))
+        val = T[ids, idx]
+        d_out[:count] = 0
+        d_out[:count, -1] = torch.where(hi | lo, -val, val)
+
+    # what EncryptedMatrixInversion.run() needs beyond the executor's calls
+    def encrypt(self, flat, delta_log):
+        if not self.secret:
+            raise RuntimeError("evaluation-only context: it holds no secret key")
+        ct = np.zeros((len(flat), self.P.big), np.uint64)
+        ct[:, -1] = (2 * np.asarray(flat, np.int64)).view(np.uint64)
+        return ct
+
+    def decrypt(self, cts, delta_log):
+        if not self.secret:
+            raise RuntimeError("evaluation-only context: it holds no secret key")
+        v = np.asarray(cts, np.uint64)[:, -1].view(np.int64)
+        assert not (v % 2).any()
+        return v // 2
+
+
+def _config4_program():
+    from bmi_amd.main import compile_inverse
+    prog, _ = compile_inverse(4, 40, 16)
+    return prog
+
+
+def _wide_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from bmi_amd.executor import Executor
+    prog = _config4_program()
+    ex = Executor(prog, _VecEngine())                      # default sharding: levels re-packed for world x 256 per round
+    inputs = np.load(os.path.join(out_dir, "inputs.npy"))
+    cts = np.zeros((prog.n_inputs, 3), np.uint64)
+    cts[:, -1] = (2 * inputs.astype(np.int64)).view(np.uint64)
+    out = ex.run(cts)
+    np.save(os.path.join(out_dir, f"out{rank}.npy"), out[:, -1].view(np.int64) // 2)
+    widths = [w for w, *_ in ex.levels]
+    np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array([ex.sharded_levels, len(ex.levels), ex.world, max(widths), ex.shard_threshold]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _random_inputs(prog, seed):
+    """a real matrix through the quantiser, so that the circuit's interval claims hold"""
+    from bmi_amd.qfloat_matrix_inversion import float_matrix_to_qfloat_arrays
+    M = np.random.default_rng(seed).normal(0, 100, (4, 4))
+    q, s = float_matrix_to_qfloat_arrays(M, 40, 16, 2)
+    return np.concatenate([np.asarray(q, np.int64).reshape(-1), np.asarray(s, np.int64)])
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_executor_on_a_circuit_whose_default_schedule_shards(tmp_path, world):
+    """BASELINE config 4 (227 k look-ups, levels up to 3,072 wide before re-packing) under the DEFAULT sharding on 2 and 8 gloo
+    ranks: some levels are split (uneven widths: the last rank's share is padded), the rest are replicated, every rank ends with
+    the plaintext circuit's integers"""
+    prog = _config4_program()
+    inputs = _random_inputs(prog, 7)
+    want = np.array(prog.simulate(inputs))
+    np.save(tmp_path / "inputs.npy", inputs)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_wide_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"out{r}.npy"), want), r
+    sharded, total, seen_world, widest, threshold = np.load(tmp_path / "meta0.npy")
+    assert seen_world == world and 0 < sharded < total and widest >= threshold
+    for r in range(1, world):
+        assert np.array_equal(np.load(tmp_path / f"meta{r}.npy"), np.load(tmp_path / "meta0.npy"))
+
+
+def _run_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from bmi_amd.main import EncryptedMatrixInversion
+    emi = EncryptedMatrixInversion(4, None, 2, 40, 16, False, False, engine=_VecEngine(secret=(rank == 0)))
+    emi.error_budget = {}                      # (the stand-in engine has no noise: skip the budget of a real parameter set)
+    M = np.load(os.path.join(out_dir, "M.npy"))
+    inv = emi.run(M)
+    np.save(os.path.join(out_dir, f"inv{rank}.npy"), inv)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_call_run_on_two_ranks(tmp_path):
+    """EncryptedMatrixInversion.run() (reference main.py:93-116) with torch.distributed on two ranks: only rank 0 can encrypt and
+    decrypt (the other rank's engine refuses, as an evaluation-only context does); both return the same inverse, equal to the
+    single-process plaintext evaluation of the circuit"""
+    from bmi_amd.main import EncryptedMatrixInversion
+    M = np.random.default_rng(3).normal(0, 100, (4, 4))
+    np.save(tmp_path / "M.npy", M)
+    want = EncryptedMatrixInversion(4, None, 2, 40, 16, False, False, engine=_VecEngine()).run(M, simulate=True)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_run_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"inv{r}.npy"), want), r

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs the reference's OWN FHE test file (tests/test_qfloat_fhe.py under /root/reference, unmodified) against the
-Tracer/Compiler-compatible shim tools/encshim - `fhe.Compiler(...).compile(inputset)` -> circuit.encrypt / run / decrypt,
+Concrete-compatible front end bmi_amd/compat (plaintext back end: no GPU in the build container) - `fhe.Compiler(...).compile(inputset)` -> circuit.encrypt / run / decrypt,
 the reference's assertions on the decrypted floats included - and keeps what it compiled and ran as data:
 tests/golden/ref_own_fhe_tests.json.gz holds, per test function, the compiled circuits (this repo's IR), the inputs the
 reference's tests fed them and the outputs they produced when the reference's assertions passed.  The CPU suite
@@ -12,8 +12,8 @@ KEEP = {"add_qfloats": 3, "div_qfloats": 2, "neg_qfloats": 2}   # circuits kept 
 
 with tempfile.TemporaryDirectory() as tmp:
     rec = os.path.join(tmp, "rec.json.gz")
-    env = dict(os.environ, ENCSHIM_RECORD=rec, PYTHONDONTWRITEBYTECODE="1",
-               PYTHONPATH=os.pathsep.join([os.path.join(REPO, "tools", "encshim"), os.path.join(REF, "matrix_inversion"),
+    env = dict(os.environ, ENCSHIM_RECORD=rec, BMI_COMPAT_BACKEND="simulate", PYTHONDONTWRITEBYTECODE="1",
+               PYTHONPATH=os.pathsep.join([os.path.join(REPO, "bounty-matrix-inversion_amd", "bmi_amd", "compat"), os.path.join(REF, "matrix_inversion"),
                                            os.path.join(REPO, "bounty-matrix-inversion_amd")]))
     out = subprocess.run([sys.executable, os.path.join("tests", "test_qfloat_fhe.py")], cwd=REF, env=env,
                          capture_output=True, text=True, timeout=3600)

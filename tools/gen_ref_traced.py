@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Traces the reference's UNMODIFIED functions (base_p_arrays.py, qfloat.py under /root/reference) through the
-Tracer-compatible shim tools/encshim into circuits of this repo's IR, and writes them - as data: look-up tables, linear
+Concrete-compatible front end bmi_amd/compat into circuits of this repo's IR, and writes them - as data: look-up tables, linear
 combinations, input ranges, sample inputs and the reference's own plaintext outputs - to tests/golden/ref_traced.json.
 The CPU suite simulates the circuits against the recorded outputs; the GPU suite runs them on ciphertexts.
 Runs only in the build container (needs /root/reference)."""
 import json, os, random, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(REPO, "tools", "encshim"))
+sys.path.insert(0, os.path.join(REPO, "bounty-matrix-inversion_amd", "bmi_amd", "compat"))
 sys.path.insert(0, "/root/reference/matrix_inversion")
 sys.path.insert(0, os.path.join(REPO, "bounty-matrix-inversion_amd"))
 import numpy as np
@@ -133,6 +133,6 @@ with gzip.GzipFile(os.path.join(REPO, "tests", "golden", "ref_traced_inverse.jso
 print("wrote tests/golden/ref_traced_inverse.json.gz",
       os.path.getsize(os.path.join(REPO, "tests", "golden", "ref_traced_inverse.json.gz")), "bytes")
 
-json.dump({"generator": "tools/gen_ref_traced.py (reference functions run unmodified through tools/encshim)",
+json.dump({"generator": "tools/gen_ref_traced.py (reference functions run unmodified through bmi_amd/compat)",
            "cases": cases}, open(os.path.join(REPO, "tests", "golden", "ref_traced.json"), "w"))
 print("wrote tests/golden/ref_traced.json", os.path.getsize(os.path.join(REPO, "tests", "golden", "ref_traced.json")), "bytes")
