@@ -1242,7 +1242,7 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
             return fail(c, -1, "kernel variant 6 needs the bootstrap key at 48 bits of precision in base 2^10 (the torus default)");
         if (lat_t && c->d_bsk_fft && c->variant != 4) {   // latency form through the floating-point transform (variant 4 pins the exact one)
             rc = bmit::launch_blind_rotate_lat_fft(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_latf, c->d_tw_fh, d_out, count,
-                                                   c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
+                                                   c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, nullptr, (hipStream_t)stream);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }
         if (int rcb = build_exact_torus_copies(c, nullptr)) return rcb;   // (variants 1 / 3 / 4, or a key without FFT copies: no-op once built)
@@ -1461,7 +1461,10 @@ int bmi_fft_margin_host(bmi_ctx *c, const uint64_t *small_in, const uint32_t *lu
     if (e == hipSuccess) e = hipMemcpyAsync(c->d_small, small_in, (size_t)count * (c->P.n + 1) * 8, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->d_io_ids, lut_ids, count * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess)
-        e = c->d_bsk_w ? (hipError_t)bmit::launch_blind_rotate_wide(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_w, c->d_tw_fq, c->d_io_b,
+        e = (!c->d_bsk_w && (c->variant == 6 || c->variant == 2))   // the latency form of the N = 1024 transform (kernel variant 6 / 2 selected)
+                ? (hipError_t)bmit::launch_blind_rotate_lat_fft(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_latf, c->d_tw_fh, c->d_io_b,
+                                                                count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, d_stat, c->stream)
+            : c->d_bsk_w ? (hipError_t)bmit::launch_blind_rotate_wide(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_w, c->d_tw_fq, c->d_io_b,
                                                                     count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, d_stat, c->stream)
                        : (hipError_t)bmit::launch_blind_rotate_fft(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_fft, c->d_tw_fft, c->d_io_b,
                                                                    count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, d_stat, c->stream);

@@ -188,7 +188,7 @@ int launch_blind_rotate_fft(const u64 *small_cts, const uint32_t *lut_ids, const
 int launch_bsk_to_latf(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, int prec, hipStream_t s);
 int launch_blind_rotate_lat_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
                                 const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
-                                uint32_t base_log, hipStream_t s);
+                                uint32_t base_log, unsigned long long *stat, hipStream_t s);
 // N = 2048 (bmi_kernels_t64w.hip, fft_quarter_f64.hpp): key at 46 bits of precision (two 23-bit limbs), one workgroup of 16
 // wavefronts per ciphertext for every batch size; key copy per (polynomial, limb) 1,024 complex words A_k / 2 in the order of the
 // multiplying threads; tables fftq::QT_WORDS doubles; stat as in launch_blind_rotate_fft

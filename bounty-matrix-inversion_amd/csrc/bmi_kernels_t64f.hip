@@ -339,11 +339,13 @@ __global__ void __launch_bounds__(256) k_bsk_to_latf_t64(const u64 *__restrict__
     }
 }
 
-template <int L, int BG>
+// STATS (the test hook bmi_fft_margin_host with the latency form selected): also records the largest distance of a limb sum from the
+// integer it is rounded to
+template <int L, int BG, bool STATS = false>
 __global__ void __launch_bounds__(LF_THREADS)
     k_blind_rotate_lat_t64f(const u64 *__restrict__ small_cts, const uint32_t *__restrict__ lut_ids, const u64 *__restrict__ luts,
                             const double *__restrict__ bsk_latf, const double *__restrict__ g_tw_h, u64 *__restrict__ out,
-                            uint32_t count, uint32_t n) {
+                            uint32_t count, uint32_t n, unsigned long long *__restrict__ stat) {
     constexpr int LIMBS = Scheme<48>::LIMBS, LB = Scheme<48>::BITS, PRE = Scheme<48>::PRE, AB = 64 - PRE;
     static_assert(2.0 * L * N * (double)(1ull << (BG - 1)) * (double)(1ull << (LB - 1)) <= 0x1p45, "limb sums must stay below 2^45");
     static_assert(LIMBS == 2 && L <= LF_MAX_L && L * BG < AB, "two limbs, at most three levels");
@@ -373,6 +375,7 @@ __global__ void __launch_bounds__(LF_THREADS)
     __syncthreads();
     const int mj = tid >> 9, mo = (tid >> 8) & 1, mq = tid & 255;   // phase B: limb, output polynomial, slot
     uint32_t since_centred = 0;   // steps taken since the accumulator was last reduced mod 2^48
+    double dev = 0.0;             // STATS: largest |value - nearest integer| this lane has rounded away
 
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t a_t = at[i];
@@ -452,6 +455,7 @@ __global__ void __launch_bounds__(LF_THREADS)
             double *ao = acc + o * N + h * LF_HALF + lane;
             auto place = [&](double v) {   // the limb's exact integer (|.| < 2^45: nearest integer of the transform's output), shifted into place
                 double xr = __builtin_rint(v);
+                if constexpr (STATS) dev = __builtin_fmax(dev, __builtin_fabs(v - xr));
                 if (j == 0) return xr;
                 constexpr double W = (double)(1ull << (AB - LB));   // x 2^LB mod 2^AB: only the low AB - LB bits survive the shift
                 xr = __builtin_fma(-W, __builtin_rint(xr * (1.0 / W)), xr);
@@ -482,6 +486,7 @@ __global__ void __launch_bounds__(LF_THREADS)
             auto place = [&](double v0, double v1) {
                 const double x0 = __builtin_rint(v0);
                 double x1 = __builtin_rint(v1);
+                if constexpr (STATS) dev = __builtin_fmax(dev, __builtin_fmax(__builtin_fabs(v0 - x0), __builtin_fabs(v1 - x1)));
                 constexpr double W = (double)(1ull << (AB - LB));
                 x1 = __builtin_fma(-W, __builtin_rint(x1 * (1.0 / W)), x1);
                 return __builtin_fma(x1, (double)(1ull << LB), x0);
@@ -500,6 +505,7 @@ __global__ void __launch_bounds__(LF_THREADS)
             __syncthreads();
         }
     }
+    if constexpr (STATS) atomicMax(stat, (unsigned long long)__double_as_longlong(dev));   // non-negative doubles order like their bit patterns
     u64 *o = out + (size_t)ct * (N + 1);
     {
         const uint32_t nn = tid;
@@ -563,25 +569,29 @@ int launch_bsk_to_latf(const u64 *std_polys, double *lat_polys, const double *g_
     return 0;
 }
 
-template <int L, int BG>
+template <int L, int BG, bool STATS>
 static int launch_lat_t64f(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
-                           const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, hipStream_t s) {
+                           const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, unsigned long long *stat, hipStream_t s) {
     static std::atomic<uint64_t> configured{0};
     const size_t lds = (size_t)LF_LDS_WORDS * sizeof(double);
-    auto kern = k_blind_rotate_lat_t64f<L, BG>;
+    auto kern = k_blind_rotate_lat_t64f<L, BG, STATS>;
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds, configured)) return rc;
-    hipLaunchKernelGGL(kern, dim3(count), dim3(LF_THREADS), lds, s, small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n);
+    hipLaunchKernelGGL(kern, dim3(count), dim3(LF_THREADS), lds, s, small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, stat);
     BMITF_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_blind_rotate_lat_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
                                 const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
-                                uint32_t base_log, hipStream_t s) {
+                                uint32_t base_log, unsigned long long *stat, hipStream_t s) {
     if (count == 0) return 0;
     if (!shape_supported_fft(prec, levels, base_log)) return (int)hipErrorInvalidValue;
-    if (levels == 3) return launch_lat_t64f<3, 10>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, s);
-    return launch_lat_t64f<2, 10>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, s);
+    if (stat) {
+        if (levels == 3) return launch_lat_t64f<3, 10, true>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, stat, s);
+        return launch_lat_t64f<2, 10, true>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, stat, s);
+    }
+    if (levels == 3) return launch_lat_t64f<3, 10, false>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, nullptr, s);
+    return launch_lat_t64f<2, 10, false>(small_cts, lut_ids, luts, bsk_fft, g_tw_fft, out, count, n, nullptr, s);
 }
 
 int launch_blind_rotate_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,

@@ -7,10 +7,13 @@
 // pointwise product of two such vectors followed by the inverse is the negacyclic product.  Why a floating-point transform may
 // carry exact integer arithmetic here: the products summed per limb (6 polynomials of digits |d| <= 2^9 against balanced 24-bit
 // key limbs) are integers below 2^45, and the rounding error of this transform on them stays below 2^-11 (measured:
-// bmi_fft_margin_host; model: tools/fft_wave_model.py).  A priori: the error analysis of floating-point FFT products (Percival
-// 2003) bounds one product's error by ||d|| ||k|| ((1 + eps)^(3n) (1 + eps sqrt 5)^(3n + 1) (1 + beta)^(3n) - 1) with n = log2 of
-// the length, here <= 2^14 * 2^28 * 1.2e-14 = 0.053 per product, 0.32 < 1/2 for the six of a limb sum (digits and limbs at their
-// largest magnitudes in every coefficient), so
+// bmi_fft_margin_host; model: tools/fft_wave_model.py).  A priori (tools/fft_bound.py): the error analysis of floating-point FFT
+// products (Percival 2003) bounds one product's error by ||d|| ||k|| ((1 + eps)^(3n) (1 + eps sqrt 5)^(3n + 1) (1 + beta)^(3n) - 1),
+// n = the number of butterfly stages.  Both forms used here have n = 9 stages - this 8 x 8 x 8 transform, and the parity split of
+// fft_half_f64.hpp (eight stages of the 256-point halves + the E +- O' butterfly, whose twiddle omega_512^k is that stage's own) -
+// plus the twist multiplication of the folded form, counted as a tenth stage: ||d|| ||k|| <= 2^14 * 2^28 (digits and limbs at their
+// largest magnitudes in every coefficient) times 1.43e-14 = 0.063 per product, 0.38 < 1/2 for the six of a limb sum (0.34 without
+// the extra stage), so
 // rounding the inverse to the nearest integer returns the exact sum - the result does not depend on the order of the
 // floating-point operations, and the oracle's integer arithmetic is the specification.
 //

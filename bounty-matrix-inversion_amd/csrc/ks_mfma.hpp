@@ -32,8 +32,10 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int TILE = 32;     // ciphertexts per wavefront tile, and output columns per column block
 constexpr int KSTEP = 32;    // k consumed per MFMA
 constexpr int WAVES = 4;     // wavefronts (ciphertext tiles) per workgroup
+#ifndef BMI_KS_PF_WIDE
+#define BMI_KS_PF_WIDE 3   // ring depth for the 9-limb moduli (their operand registers leave room for three k-steps in flight)
+#endif
 #ifndef BMI_KS_PF
-#define BMI_KS_PF_WIDE 3
 #define BMI_KS_PF 4   // measured at 8,192 ciphertexts, 7 limbs (keyswitch total, three kernels): 1.13 ms with the round-2 double buffer, 0.72 / 0.70 / 0.65 ms at depth 1 / 2 / 4 of this ring
 #endif
 

@@ -174,9 +174,10 @@ int bmi_pbs_batch_host(bmi_ctx *ctx, const uint64_t *in, const uint32_t *lut_ids
 int bmi_keyswitch_batch_host(bmi_ctx *ctx, const uint64_t *in, uint32_t count, uint64_t *small_out);
 int bmi_blind_rotate_batch_host(bmi_ctx *ctx, const uint64_t *small_in, const uint32_t *lut_ids, uint32_t count,
                                 uint64_t *out);
-/* Test hook of the floating-point-transform kernels (2^64 torus, bootstrap key at 48 bits in base 2^10; kernel variants 5 / 6):
- * blind rotation of `count` small-key ciphertexts by the wave-pair kernel, which here also records how far every limb sum was
- * from the integer it was rounded to.  *max_distance must stay far below 1/2 (measured: below 2^-11) - that is what makes the
+/* Test hook of the floating-point-transform kernels (2^64 torus; N = 1024: key at 48 bits, kernel variants 5 / 6; N = 2048: key at
+ * 46 bits): blind rotation of `count` small-key ciphertexts by the wave-pair kernel - by the latency form when kernel variant 6 or 2
+ * is selected, by k_blind_rotate_w_t64f at N = 2048 -, which here also records how far every limb sum was from the integer it was
+ * rounded to.  *max_distance must stay far below 1/2 (measured: below 2^-11) - that is what makes the
  * rounded results the exact integer sums, whatever the order of the floating-point operations. */
 int bmi_fft_margin_host(bmi_ctx *ctx, const uint64_t *small_in, const uint32_t *lut_ids, uint32_t count, uint64_t *out,
                         double *max_distance);

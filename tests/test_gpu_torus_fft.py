@@ -160,8 +160,11 @@ def test_rounding_margin_of_the_limb_sums(kw):
         assert 0.0 < dist < 2.0 ** -9, dist
         e.set_kernel_variant(1)
         assert np.array_equal(out, e.blind_rotate_host(small, ids))
-        e.set_kernel_variant(6)   # the latency form at this shape (random words first)
+        e.set_kernel_variant(6)   # the latency form at this shape (random words first): same words, and its own rounding distance
         assert np.array_equal(out[:40], e.blind_rotate_host(small[:40], ids[:40]))
         assert np.array_equal(out[600:640], e.blind_rotate_host(small[600:640], ids[600:640]))
+        out6, dist6 = e.fft_margin_host(small[:256], ids[:256])
+        print(f"{kw or 'default'}: latency form (half transforms), largest distance 2^{np.log2(max(dist6, 1e-300)):.1f}")
+        assert 0.0 < dist6 < 2.0 ** -9 and np.array_equal(out6, out[:256])
     finally:
         e.close()
