@@ -199,6 +199,7 @@ struct bmi_ctx {
     double *d_tw_half = nullptr, *d_bsk_lat = nullptr;          // 49-bit field: tables and key copy of the split-transform latency kernel
     double *d_tw_fft = nullptr, *d_bsk_fft = nullptr;           // 2^64 torus, key at 48 bits: tables and key copy of the floating-point-transform wave-pair kernel (bmi_kernels_t64f.hip)
     double *d_tw_fh = nullptr, *d_bsk_latf = nullptr;           // ... and of its latency form (half transforms, fft_half_f64.hpp; key in slot-pair order)
+    double *d_zeta_pow = nullptr;                               // 2^64 torus at N = 1024: zeta^x, x in [0, 1024) as (re, im) - the factors X^c of the unrolled floating-point-transform kernel
     double *d_tw_fq = nullptr, *d_bsk_w = nullptr;              // 2^64 torus at N = 2048, key at 46 bits: tables and key copy of bmi_kernels_t64w.hip (quarter transforms, fft_quarter_f64.hpp)
     double *d_tw_wide = nullptr;                                // N = 2048: T / T^-1 of the even/odd combination (d_bsk_lat then holds the wide key copy)
     // bootstrap-key unrolling (49-bit field at N = 1024 / 2048, 2^64 torus; bmi_set_bsk_unroll): per pair of LWE coefficients the GGSW encryptions of
@@ -505,6 +506,11 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
         if (hipMalloc(&c->d_tw_fh, th.size() * 8) != hipSuccess) return bail("hipMalloc(half-fft twiddles) failed");
         if (hipMemcpy(c->d_tw_fh, th.data(), th.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(half-fft twiddles) failed");
+        std::vector<double> zp(2048);
+        for (uint32_t x = 0; x < 1024; x++) zeta_pow(x, &zp[2 * x]);
+        if (hipMalloc(&c->d_zeta_pow, zp.size() * 8) != hipSuccess) return bail("hipMalloc(zeta powers) failed");
+        if (hipMemcpy(c->d_zeta_pow, zp.data(), zp.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+            return bail("hipMemcpy(zeta powers) failed");
     }
     if ((c->f64() && !c->quad()) || c->t64()) {   // psi^x for the unrolled blind rotation (X^c at the root psi^e is psi^(e c))
         // N = 1024: psi = psi_2048, x in [0, 2048).  N = 2048: psi = psi_4096, x in [0, 2048) (the upper half is the negative)
@@ -545,7 +551,7 @@ void bmi_ctx_destroy(bmi_ctx *c) {
                     (void *)c->d_ks_limbs, (void *)c->d_ks_digits, (void *)c->d_ks_sums, (void *)c->d_tw_half,
                     (void *)c->d_bsk_lat, (void *)c->d_tw_wide, (void *)c->d_bsk3_lat, (void *)c->d_root_pow,
                     (void *)c->d_tw_fft, (void *)c->d_bsk_fft, (void *)c->d_tw_fh, (void *)c->d_bsk_latf, (void *)c->d_tw_fq,
-                    (void *)c->d_bsk_w})
+                    (void *)c->d_bsk_w, (void *)c->d_zeta_pow})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -747,7 +753,9 @@ int upload_bsk3(bmi_ctx *c) {
         return fail(c, -2, "hipMalloc(unrolled key) failed");
     }
     HIP_OK(c, hipMemcpy(d_tmp, c->bsk3_std.data(), words * 8, hipMemcpyHostToDevice));
-    const int rc = c->t64() ? bmit::launch_bsk_to_lat(d_tmp, c->d_bsk3_lat, c->d_tw_half, (uint32_t)(words / c->N), c->bsk_prec, c->stream)
+    const bool ufft = c->t64() && bmit::shape_supported_unrolled_fft(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log);
+    const int rc = ufft ? bmit::launch_bsk_to_latf(d_tmp, c->d_bsk3_lat, c->d_tw_fh, (uint32_t)(words / c->N), c->bsk_prec, c->stream)   // slot-pair order of the half FFT
+                   : c->t64() ? bmit::launch_bsk_to_lat(d_tmp, c->d_bsk3_lat, c->d_tw_half, (uint32_t)(words / c->N), c->bsk_prec, c->stream)
                    : c->wide() ? bmi49::launch_bsk_to_wide(d_tmp, c->d_bsk3_lat, (const double *)c->d_tw, c->d_tw_wide, (uint32_t)(words / c->N), c->stream)
                                : bmi49::launch_bsk_to_lat(d_tmp, c->d_bsk3_lat, c->d_tw_half, (uint32_t)(words / c->N), true, c->stream);
     if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_lat (unrolled key) launch failed"); }
@@ -833,10 +841,10 @@ int upload_eval_keys(bmi_ctx *c) {
             }
             rc = bmit::launch_bsk_to_latf(d_tmp, c->d_bsk_latf, c->d_tw_fh, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
             if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_latf (torus) launch failed"); }
-        } else {
+        } else if (bmit::shape_supported(c->bsk_prec, P.bs_levels, P.bs_base_log)) {
             HIP_OK(c, hipStreamSynchronize(c->stream));
             if (int rc2 = build_exact_torus_copies(c, d_tmp)) { (void)hipFree(d_tmp); return rc2; }
-        }
+        }   // (else: a precision that only the unrolled kernel takes - 42 bits at base 2^10: no plain key copy)
     } else if (c->wide() || c->quad()) {  // N = 2048 / 4096: one key copy, in the slot order of k_blind_rotate_wide49 / quad49
         if (!c->d_bsk_lat && hipMalloc(&c->d_bsk_lat, bsk_words * 8) != hipSuccess) {
             (void)hipFree(d_tmp);
@@ -1060,11 +1068,13 @@ int bmi_set_bsk_precision(bmi_ctx *c, uint32_t bits) {
         c->bsk_prec = (int)bits;
         return 0;
     }
-    if (!bmit::shape_supported((int)bits, c->P.bs_levels, c->P.bs_base_log))
-        return fail(c, -1, "no kernel for this precision at this decomposition: base 2^10 takes 48 (default) or 64 bits, base 2^15 takes 64 "
-                           "(default) or 42 bits (a limb sum must stay below p/2: t64_common.hpp)");
-    if (c->unroll == 2 && !bmit::shape_supported_unrolled((int)bits, c->P.bs_levels, c->P.bs_base_log))
-        return fail(c, -1, "the unrolled torus kernel takes the 48-bit key at base 2^10 only");
+    const bool unrolled_fft = bmit::shape_supported_unrolled_fft((int)bits, c->P.bs_levels, c->P.bs_base_log);   // 42 bits at base 2^10: unrolled mode only
+    if (!bmit::shape_supported((int)bits, c->P.bs_levels, c->P.bs_base_log) && !unrolled_fft)
+        return fail(c, -1, "no kernel for this precision at this decomposition: base 2^10 takes 48 (default) or 64 bits - and 42 bits for the "
+                           "unrolled floating-point-transform kernel (bmi_set_bsk_unroll) -, base 2^15 takes 64 (default) or 42 bits (a limb sum "
+                           "must stay below p/2: t64_common.hpp)");
+    if (c->unroll == 2 && !unrolled_fft && !bmit::shape_supported_unrolled((int)bits, c->P.bs_levels, c->P.bs_base_log))
+        return fail(c, -1, "the unrolled torus kernels take the key at 48 bits (exact transform) or 42 bits (floating-point transform) at base 2^10");
     c->bsk_prec = (int)bits;
     return 0;
 }
@@ -1082,8 +1092,9 @@ int bmi_set_bsk_unroll(bmi_ctx *c, uint32_t factor) {
         return fail(c, -1, "bootstrap-key unrolling has HIP kernels for the 49-bit field at N = 1024 and N = 2048 and for the 2^64 torus only");
     if (factor == 2 && c->t64() && c->wide())
         return fail(c, -1, "bootstrap-key unrolling has no HIP kernel on the 2^64 torus at N = 2048");
-    if (factor == 2 && c->t64() && !bmit::shape_supported_unrolled(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log))
-        return fail(c, -1, "on the 2^64 torus the unrolled kernel takes the 48-bit key at base 2^10 (the default torus set): the limb sums of "
+    if (factor == 2 && c->t64() && !bmit::shape_supported_unrolled(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log) &&
+        !bmit::shape_supported_unrolled_fft(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log))
+        return fail(c, -1, "on the 2^64 torus the unrolled kernels take the key at 48 or 42 bits at base 2^10 (the default torus set): the limb sums of "
                            "its three scaled products must stay below p/2");
     if (factor == 2 && c->wide() && c->P.bs_levels > 2)
         return fail(c, -1, "at N = 2048 the unrolled kernel exists for l <= 2 (at l = 3 it would not fit the registers: the plain kernel is faster)");
@@ -1231,10 +1242,15 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     if (c->t64()) {   // 2^64 torus: latency kernel (one workgroup per ciphertext) for small batches, wave pairs beyond
         if (c->unroll == 2) {   // unrolled key: one kernel (one workgroup per ciphertext) for every batch size
             if (!c->have_bsk3) return fail(c, -1, "unrolling selected but the context holds no unrolled key: generate keys after bmi_set_bsk_unroll, or bmi_import_bsk_unrolled");
-            rc = bmit::launch_blind_rotate_lat2u(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk3_lat, c->d_tw_half, c->d_root_pow, d_out,
-                                                 count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
+            rc = bmit::shape_supported_unrolled_fft(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log)
+                     ? bmit::launch_blind_rotate_lat2u_fft(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk3_lat, c->d_tw_fh, c->d_zeta_pow, d_out,
+                                                           count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, nullptr, (hipStream_t)stream)
+                     : bmit::launch_blind_rotate_lat2u(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk3_lat, c->d_tw_half, c->d_root_pow, d_out,
+                                                       count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }
+        if (!c->d_bsk_fft && !bmit::shape_supported(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log))
+            return fail(c, -1, "this bootstrap-key precision exists for the unrolled kernel only: bmi_set_bsk_unroll(ctx, 2) before keygen");
         // (floating-point-transform kernels: two rounds of 256 one-workgroup bootstraps, 7.7 ms, still beat the wave-pair kernel's
         // 8.4 ms up to 1,024 ciphertexts; three rounds do not)
         const bool lat_t = c->variant == 2 || c->variant == 4 || c->variant == 6 || (c->variant == 0 && count <= c->lat_threshold);
@@ -1446,7 +1462,8 @@ int bmi_fft_margin_host(bmi_ctx *c, const uint64_t *small_in, const uint32_t *lu
                         double *max_distance) {
     if (!c || !small_in || !lut_ids || !out || !max_distance) return -1;
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
-    if (!c->d_bsk_fft && !c->d_bsk_w)
+    const bool ufft = c->t64() && c->unroll == 2 && c->have_bsk3 && bmit::shape_supported_unrolled_fft(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log);
+    if (!c->d_bsk_fft && !c->d_bsk_w && !ufft)
         return fail(c, -1, "the floating-point-transform kernels exist on the 2^64 torus with the bootstrap key at 48 bits (N = 1024) or 46 bits "
                            "(N = 2048) in base 2^10");
     if (int bad = check_lut_ids(c, lut_ids, count)) return bad;
@@ -1461,7 +1478,9 @@ int bmi_fft_margin_host(bmi_ctx *c, const uint64_t *small_in, const uint32_t *lu
     if (e == hipSuccess) e = hipMemcpyAsync(c->d_small, small_in, (size_t)count * (c->P.n + 1) * 8, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->d_io_ids, lut_ids, count * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess)
-        e = (!c->d_bsk_w && (c->variant == 6 || c->variant == 2))   // the latency form of the N = 1024 transform (kernel variant 6 / 2 selected)
+        e = ufft ? (hipError_t)bmit::launch_blind_rotate_lat2u_fft(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk3_lat, c->d_tw_fh, c->d_zeta_pow,
+                                                                   c->d_io_b, count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, d_stat, c->stream)
+            : (!c->d_bsk_w && (c->variant == 6 || c->variant == 2))   // the latency form of the N = 1024 transform (kernel variant 6 / 2 selected)
                 ? (hipError_t)bmit::launch_blind_rotate_lat_fft(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_latf, c->d_tw_fh, c->d_io_b,
                                                                 count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, d_stat, c->stream)
             : c->d_bsk_w ? (hipError_t)bmit::launch_blind_rotate_wide(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_w, c->d_tw_fq, c->d_io_b,

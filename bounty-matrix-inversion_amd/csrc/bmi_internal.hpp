@@ -189,6 +189,13 @@ int launch_bsk_to_latf(const u64 *std_polys, double *lat_polys, const double *g_
 int launch_blind_rotate_lat_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_fft,
                                 const double *g_tw_fft, u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels,
                                 uint32_t base_log, unsigned long long *stat, hipStream_t s);
+// the unrolled step (two LWE coefficients) through the floating-point transform (bmi_kernels_t64fu.hip): key at 42 bits of precision
+// (two 21-bit limbs: the six-times larger limb sums stay inside the transform's certified range); bsk3_latf = launch_bsk_to_latf of
+// the unrolled key, g_zeta_pow = exp(i pi x / 1024) for x in [0, 1024) as (re, im); stat as in launch_blind_rotate_fft
+bool shape_supported_unrolled_fft(int prec, uint32_t levels, uint32_t base_log);
+int launch_blind_rotate_lat2u_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk3_latf,
+                                  const double *g_tw_h, const double *g_zeta_pow, u64 *out, uint32_t count, uint32_t n, int prec,
+                                  uint32_t levels, uint32_t base_log, unsigned long long *stat, hipStream_t s);
 // N = 2048 (bmi_kernels_t64w.hip, fft_quarter_f64.hpp): key at 46 bits of precision (two 23-bit limbs), one workgroup of 16
 // wavefronts per ciphertext for every batch size; key copy per (polynomial, limb) 1,024 complex words A_k / 2 in the order of the
 // multiplying threads; tables fftq::QT_WORDS doubles; stat as in launch_blind_rotate_fft

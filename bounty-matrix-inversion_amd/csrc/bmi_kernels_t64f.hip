@@ -562,7 +562,7 @@ static int launch_t64f(const u64 *small_cts, const uint32_t *lut_ids, const u64 
 }
 
 int launch_bsk_to_latf(const u64 *std_polys, double *lat_polys, const double *g_tw_h, uint32_t n_polys, int prec, hipStream_t s) {
-    if (prec != 48) return (int)hipErrorInvalidValue;
+    if (prec != 48 && prec != 42) return (int)hipErrorInvalidValue;   // (42: the unrolled key of bmi_kernels_t64fu.hip)
     const uint32_t items = n_polys * (uint32_t)t64::limbs_of(prec);
     hipLaunchKernelGGL(k_bsk_to_latf_t64, dim3((items + 1) / 2), dim3(256), 0, s, std_polys, lat_polys, g_tw_h, n_polys, prec);
     BMITF_LAUNCH_CHECK();

@@ -13,7 +13,11 @@ probes of bench.py never mix with the 8,192-ciphertext launches, and two instant
                                               workgroup size: these kernels hold one workgroup per compute unit)
     <out>/hbm_traffic.json                    what bench.py reads for roofline.traffic: the blind-rotation groups
 
-usage: summarize_prof.py <tag> <batch> [<prof dir> [<out dir>]]      (defaults: gpurun_out/final/prof, profiles)"""
+Every blind-rotation group also gets `cycles_per_cmux`: average launch time x the shader clock bench.py sampled during the SAME run
+(the JSON line in the trace pass's log, 5th argument) / (steps x workgroup rounds per compute unit) - the quantity to compare between
+boxes whose clocks differ, and with bench.py's `roofline.kernel_cycles_per_cmux`.
+
+usage: summarize_prof.py <tag> <batch> [<prof dir> [<out dir> [<log of the traced bench run>]]]      (defaults: gpurun_out/final/prof, profiles)"""
 import csv, glob, json, os, re, shutil, sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,6 +25,15 @@ tag, batch = sys.argv[1], int(sys.argv[2])
 base = sys.argv[3] if len(sys.argv) > 3 else os.path.join(REPO, "gpurun_out", "final", "prof")
 out_dir = sys.argv[4] if len(sys.argv) > 4 else os.path.join(REPO, "profiles")
 os.makedirs(out_dir, exist_ok=True)
+sclk_mhz, traced_line = None, None
+if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
+    for line in open(sys.argv[5]):
+        if line.startswith("{") and '"roofline"' in line:
+            try:
+                traced_line = json.loads(line)
+                sclk_mhz = float(traced_line["roofline"]["sclk_mhz"])
+            except Exception:
+                pass
 
 
 def newest(pattern):
@@ -105,6 +118,13 @@ for g in groups.values():
         r["ciphertexts_per_launch"] = r["workgroups"] * cpw
     if g["dur_ns"]:
         r.update(avg_ms=sum(g["dur_ns"]) / len(g["dur_ns"]) / 1e6, min_ms=min(g["dur_ns"]) / 1e6, max_ms=max(g["dur_ns"]) / 1e6)
+        if cpw and sclk_mhz:
+            steps = 742 if "w_t64f" in g["kernel"] else 630          # LWE dimension of the set the kernel serves in bench.py
+            if "lat2u" in g["kernel"]:
+                steps = (steps + 1) // 2                             # the unrolled kernels take two coefficients per step
+            rounds = -(-r["ciphertexts_per_launch"] // (cpw * 256))
+            r.update(cycles_per_cmux=r["avg_ms"] * 1e-3 * sclk_mhz * 1e6 / (steps * rounds), sclk_mhz=sclk_mhz,
+                     cycles_formula="avg_ms x sclk (sampled by bench.py in the traced run) / (steps x ceil(ciphertexts / (ciphertexts per workgroup x 256 CUs)))")
     c = g["counters"]
     if c:
         r["counters_avg_per_dispatch"] = c
@@ -124,10 +144,14 @@ rows.sort(key=lambda r: -(r.get("avg_ms", 0) * r["calls"]))
 note = ("rocprofv3 --kernel-trace --stats pass and three separate --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_*) of `python3 bench.py --batch "
         f"{batch} --no-cpu-baseline --no-inverse` (tools/gpu_final.sh); one row per (kernel instantiation, grid size, workgroup size); "
         "FETCH_SIZE / WRITE_SIZE in KiB, FETCH doubled per MI355X_MICROARCH.md")
+if traced_line is not None:
+    rl = traced_line.get("roofline", {})
+    note += (f"; the traced run's own line: value {traced_line.get('value'):.0f} PBS/s, kernel_ms {rl.get('kernel_ms'):.3f} (events), "
+             f"kernel_cycles_per_cmux {rl.get('kernel_cycles_per_cmux'):.0f}, sclk {sclk_mhz:.0f} MHz")
 json.dump({"tag": tag, "batch": batch, "note": note, "groups": rows}, open(os.path.join(out_dir, f"{tag}_kernel_groups_B{batch}.json"), "w"), indent=1)
 entries = [{"kernel": r["kernel"], "grid_size": r["grid_size"], "workgroup_size": r["workgroup_size"], "batch": r.get("ciphertexts_per_launch"),
             "avg_ms": r.get("avg_ms"), "calls": r["calls"], "bytes_per_launch": r.get("hbm_bytes_per_launch"),
-            "valu_busy_frac": r.get("valu_busy_frac"), "waves_per_simd": r.get("waves_per_simd"),
+            "valu_busy_frac": r.get("valu_busy_frac"), "waves_per_simd": r.get("waves_per_simd"), "cycles_per_cmux": r.get("cycles_per_cmux"),
             "source": f"profiles/{tag}_kernel_groups_B{batch}.json"}
            for r in rows if "blind_rotate" in r["kernel"]]
 json.dump({"entries": entries, "note": "per (kernel instantiation, launch shape); bench.py matches kernel AND batch"},
