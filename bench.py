@@ -565,7 +565,7 @@ def main():
                 plain_key_bytes = Pe.n * 4 * Pe.bs_levels * Pe.N * 8
                 gbs = plain_key_bytes * B / (kms * 1e-3) / 1e9
                 kname = ("k_blind_rotate_w_t64f<3, 10, 46, false>" if (qb == 65 and Pe.N == 2048) else
-                         {49: "k_blind_rotate_lat2u_49<3, 15>", 65: "k_blind_rotate_lat2u_t64<3, 10, 48>"}[qb] if unroll else KERNEL[qb])
+                         {49: "k_blind_rotate_lat2u_49<3, 15>", 65: "k_blind_rotate_lat2u_t64f<3, 10, 42, false>"}[qb] if unroll else KERNEL[qb])
                 one_wg_per_ct = unroll or Pe.N > 1024
                 sm, ss = ck.result()
                 rep = {"q_bits": qb, "params": {"n": int(Pe.n), "N": int(Pe.N), "k": int(Pe.k), "l": int(Pe.bs_levels), "log2_Bg": int(Pe.bs_base_log),

@@ -190,7 +190,8 @@ struct bmi_ctx {
     bool have_keys = false;
     bool have_secret = false;  // false for a context that imported evaluation keys only (no encrypt / decrypt)
     u64 seed = 0, enc_counter = 0;
-    int bsk_prec = 64;   // torus: bits of precision the bootstrap key is stored at (64 = exact, 48, 42: t64_common.hpp; bmi_set_bsk_precision)
+    int bsk_prec = 64;   // torus: bits of precision the bootstrap key is stored at (64 = exact, 48, 46, 42: t64_common.hpp; bmi_set_bsk_precision)
+    bool bsk_prec_explicit = false;   // set by bmi_set_bsk_precision: bmi_set_bsk_unroll then leaves the precision alone
     int bsk_limbs() const { return t64::limbs_of(bsk_prec); }
     bool secure_rng = false;       // true: keys / encryptions drawn from the CSPRNG below; false: test-only seeded streams
     ChaKey rng_secret, rng_public; // independent ChaCha20 keys from getrandom(): secrets + noise / public masks
@@ -1066,6 +1067,7 @@ int bmi_set_bsk_precision(bmi_ctx *c, uint32_t bits) {
             return fail(c, -1, "at N = 2048 the torus kernel takes the key at 46 bits of precision (two 23-bit limbs) only: the length at which "
                                "the floating-point transform's error bound certifies the rounding (fft_quarter_f64.hpp)");
         c->bsk_prec = (int)bits;
+        c->bsk_prec_explicit = true;
         return 0;
     }
     const bool unrolled_fft = bmit::shape_supported_unrolled_fft((int)bits, c->P.bs_levels, c->P.bs_base_log);   // 42 bits at base 2^10: unrolled mode only
@@ -1076,6 +1078,7 @@ int bmi_set_bsk_precision(bmi_ctx *c, uint32_t bits) {
     if (c->unroll == 2 && !unrolled_fft && !bmit::shape_supported_unrolled((int)bits, c->P.bs_levels, c->P.bs_base_log))
         return fail(c, -1, "the unrolled torus kernels take the key at 48 bits (exact transform) or 42 bits (floating-point transform) at base 2^10");
     c->bsk_prec = (int)bits;
+    c->bsk_prec_explicit = true;
     return 0;
 }
 
@@ -1092,6 +1095,13 @@ int bmi_set_bsk_unroll(bmi_ctx *c, uint32_t factor) {
         return fail(c, -1, "bootstrap-key unrolling has HIP kernels for the 49-bit field at N = 1024 and N = 2048 and for the 2^64 torus only");
     if (factor == 2 && c->t64() && c->wide())
         return fail(c, -1, "bootstrap-key unrolling has no HIP kernel on the 2^64 torus at N = 2048");
+    if (c->t64() && !c->bsk_prec_explicit && !c->have_keys) {
+        // the precision nobody chose follows the mode: the unrolled step runs through the floating-point transform on a key stored
+        // at 42 bits (k_blind_rotate_lat2u_t64f: 2.9 ms per bootstrap against 3.3 of the exact-transform kernel on the 48-bit key,
+        // which bmi_set_bsk_precision(ctx, 48) still selects); back to the set's default when unrolling is switched off
+        if (factor == 2 && bmit::shape_supported_unrolled_fft(42, c->P.bs_levels, c->P.bs_base_log)) c->bsk_prec = 42;
+        if (factor == 1) c->bsk_prec = default_bsk_precision(c->P);
+    }
     if (factor == 2 && c->t64() && !bmit::shape_supported_unrolled(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log) &&
         !bmit::shape_supported_unrolled_fft(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log))
         return fail(c, -1, "on the 2^64 torus the unrolled kernels take the key at 48 or 42 bits at base 2^10 (the default torus set): the limb sums of "

@@ -209,12 +209,15 @@ int bmi_set_kernel_variant(bmi_ctx *ctx, int variant);
  *       torus parameter set ("north_star_torus64": l = 3, Bg = 2^10): the rounding errors of a row (2^15 / sqrt 3 per word,
  *       summed over the ~N/2 set bits of the GLWE key: 2^18.7) stay under the key noise 2^20, and the finer base more than
  *       pays for them - bootstrap output noise 2^-22.6 against 2^-19.85 of (Bg = 2^15, exact key), measured on the formula
- *       (tests/test_gpu_parity.py).  The only precision the unrolled torus kernel takes (bmi_set_bsk_unroll).
+ *       (tests/test_gpu_parity.py).  With bmi_set_bsk_unroll: the exact-transform unrolled kernel (k_blind_rotate_lat2u_t64).
  *   46  N = 2048 only (its default and only precision; "secure128_torus"): multiples of 2^18, two 23-bit limbs - the limb width at
  *       which the a-priori error bound of the 1,024-point floating-point transform still certifies the rounding of a limb sum
  *       (0.41 < 1/2, csrc/fft_quarter_f64.hpp; 24-bit limbs: 0.83).
- *   42  round 2's option at Bg = 2^15: multiples of 2^22, two 21-bit limbs; effective key noise 2^-39.3, output noise
- *       2^-15.15 - a throughput option for flat PBS batches, too noisy for the encrypted inverse.
+ *   42  multiples of 2^22, two 21-bit limbs.  At Bg = 2^10 in UNROLLED mode only - the precision bmi_set_bsk_unroll(ctx, 2) selects
+ *       by itself when none was set: the three scaled products of an unrolled step make the limb sums six times larger, and 21-bit
+ *       limbs keep them inside the range the floating-point transform is certified for (k_blind_rotate_lat2u_t64f; output noise
+ *       2^-19.3).  At Bg = 2^15: round 2's throughput option for flat PBS batches (output noise 2^-15.15: too noisy for the
+ *       encrypted inverse).
  * The rounded key is the context's key from then on (bmi_export_keys / bmi_export_bsk_unrolled return it; results are
  * bit-exact against an oracle given that key; oracle/tfhe_oracle.c ora_round_key states the rule).  The rounding only ever
  * adds noise to valid LWE samples; generating the key on the grid directly would instead round its own noise away. */
@@ -222,13 +225,14 @@ int bmi_set_bsk_precision(bmi_ctx *ctx, uint32_t bits);
 /* the precision in force (64 on the prime fields) */
 int bmi_get_bsk_precision(const bmi_ctx *ctx, uint32_t *bits);
 
-/* 49-bit field at N = 1024, and at N = 2048 with l <= 2 (the secure128 shape), and the 2^64 torus at its default set (Bg = 2^10,
- * 48-bit key; k_blind_rotate_lat2u_t64): bootstrap-key unrolling (Zhou et al. 2018, Bourse et al. 2018; unrolling factor 2).
+/* 49-bit field at N = 1024, and at N = 2048 with l <= 2 (the secure128 shape), and the 2^64 torus at its default set (Bg = 2^10;
+ * key at 42 bits: k_blind_rotate_lat2u_t64f, the floating-point-transform route, 2.9 ms per bootstrap - what this call selects when
+ * no precision was set -, or pinned at 48 bits: k_blind_rotate_lat2u_t64, the exact transform, 3.3 ms): bootstrap-key unrolling (Zhou et al. 2018, Bourse et al. 2018; unrolling factor 2).
  * factor 1 (default): the blind rotation of CGGI, one LWE coefficient per step.  factor 2: a step absorbs two coefficients,
  *   ACC <- ACC + sum_{j<3} (X^(c_j) - 1) (K_j [.] ACC),  c = (a + a', a, a'),  K = GGSW(s s'), GGSW(s (1 - s')), GGSW((1 - s) s'),
  * with one decomposition and one set of forward transforms per step (half as many as the plain rotation; the factors X^c - 1
- * are applied in the transform domain).  Every batch size then runs k_blind_rotate_lat2u_49 (N = 1024) or
- * k_blind_rotate_wide49u (N = 2048), one workgroup per ciphertext.
+ * are applied in the transform domain).  Every batch size then runs k_blind_rotate_lat2u_49 (49-bit field, N = 1024),
+ * k_blind_rotate_wide49u (N = 2048) or the torus kernel above, one workgroup per ciphertext.
  * The unrolled key (1.5 x the plain key's size) is generated by the next keygen call, or at once when the context already
  * holds secret keys; an evaluation-only context receives it through bmi_import_bsk_unrolled.  Layout:
  * [ceil(n/2)][3][(k+1) l][(k+1)][N] words, standard domain (an odd n is completed by a zero key bit).  Price: the key-noise

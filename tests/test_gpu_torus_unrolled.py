@@ -1,5 +1,6 @@
 """GPU parity tests of the UNROLLED blind rotation on the 2^64 TORUS (Concrete's ciphertext modulus; bmi_set_bsk_unroll(ctx, 2)
-on a torus context, k_blind_rotate_lat2u_t64): two LWE coefficients per step, exact limb-split products against a bootstrap key
+on a torus context with the key pinned at 48 bits, k_blind_rotate_lat2u_t64 - the exact-transform predecessor of the unrolled FFT
+kernel of tests/test_gpu_torus_unrolled_fft.py): two LWE coefficients per step, exact limb-split products against a bootstrap key
 stored at 48 bits of precision.  Bit for bit against oracle/tfhe_oracle.c ora_blind_rotate_extract_unrolled (which rotates in
 the coefficient domain and multiplies through Goldilocks transforms of the key's 32-bit halves - a different route to the same
 integers) on the same keys; output noise on the formula; the encrypted inverses against the reference's golden digits."""
@@ -19,7 +20,8 @@ QB = 65
 def _engine(seed=SEED, **kw):
     from bmi_amd import tfhe
     e = tfhe.Engine(tfhe.default_params(q_bits=QB, **kw))
-    e.set_bsk_unroll(2)
+    e.set_bsk_precision(48)       # the exact-transform unrolled kernel (without this, unrolling picks the 42-bit key and the FFT route:
+    e.set_bsk_unroll(2)           # tests/test_gpu_torus_unrolled_fft.py)
     e.keygen(seed)
     return e
 
@@ -133,10 +135,12 @@ def test_unrolling_on_the_torus_is_refused_where_the_limb_sums_would_not_fit():
     e = tfhe.Engine(tfhe.default_params(q_bits=QB))
     try:
         e.set_bsk_unroll(2)
+        assert e.bsk_precision == 42         # the precision nobody chose follows the mode: the unrolled step takes the FFT route
         with pytest.raises(tfhe.BmiError):
             e.set_bsk_precision(64)          # would leave the unrolled mode without a kernel
-        with pytest.raises(tfhe.BmiError):
-            e.set_bsk_precision(42)          # two 21-bit limbs belong to base 2^15
+        e.set_bsk_precision(48)              # the exact-transform unrolled kernel stays selectable
+        e.set_bsk_unroll(1)
+        assert e.bsk_precision == 48         # (an explicit choice is kept)
     finally:
         e.close()
 
@@ -228,7 +232,7 @@ def test_unrolled_torus_output_noise_on_the_formula_and_timing(eng, capsys):
                                  "overflow_digit_2x2", "overflow_digit_3x3", "uniform_3x3_small_truediv", "uniform_2x2_tensorize"])
 def test_encrypted_inverse_on_the_torus_with_the_unrolled_key_matches_reference_golden(tag, capsys):
     """BASELINE configs 2-5, the overflow-digit cases and the true-division / tensorize modes on 2^64-torus ciphertexts with
-    EncryptedMatrixInversion(q_bits=65, unroll=True): decrypted digits == the reference's plaintext QFloat output
+    EncryptedMatrixInversion(q_bits=65, unroll=True) - the wrapper's unrolled torus engine: 42-bit key, k_blind_rotate_lat2u_t64f: decrypted digits == the reference's plaintext QFloat output
     (tests/golden/inverse.json, generated from the reference)."""
     from bmi_amd.main import EncryptedMatrixInversion
     with open(os.path.join(os.path.dirname(__file__), "golden", "inverse.json")) as f:
@@ -237,7 +241,7 @@ def test_encrypted_inverse_on_the_torus_with_the_unrolled_key_matches_reference_
     emi = EncryptedMatrixInversion(c["n"], None, 2, c["len"], c["ints"], c["true_division"], c["tensorize"], unroll=True, q_bits=QB)
     try:
         emi.keygen()                                # CSPRNG keys
-        assert emi.engine.q_bits == QB and emi.engine.bsk_precision == 48 and emi.engine.P.glwe_noise == 2.0 ** -44
+        assert emi.engine.q_bits == QB and emi.engine.bsk_precision == 42 and emi.engine.P.glwe_noise == 2.0 ** -44   # the FFT-route unrolled kernel
         M = np.array(c["M"]).reshape(c["n"], c["n"])
         q, s = emi.quantize(M)
         enc = emi.encrypt(q, s)
