@@ -368,17 +368,17 @@ def main():
     # the vector-ALU roof (what the blind rotation is bound by): issue cycles of the kernel's vector instructions per second
     # against 1,024 SIMDs x shader clock.  Issue cost per wave64 instruction on a SIMD-32: 2 cycles, f64 and 64-bit integer
     # instructions 4 (MI355X_MICROARCH.md: `v_fma_f32` 2 cycles; f64 runs at half the f32 rate).  Instruction counts: static, one
-    # step of the kernel's main loop (tools/isa_count.py -> profiles/r03_isa_counts.json)
+    # step of the kernel's main loop (tools/isa_count.py -> profiles/r04_isa_counts.json)
     isa = {}
     try:
-        isa = json.load(open(os.path.join(REPO, "profiles", "r03_isa_counts.json")))["kernels"]
+        isa = json.load(open(os.path.join(REPO, "profiles", "r04_isa_counts.json")))["kernels"]
     except Exception:
         pass
 
     def alu_roof(kernel, kernel_ms, count, n_lwe, waves_per_ct=2, steps_per_ct=None):
         c = isa.get(kernel)
         if not c:
-            return {"bound": "valu issue", "error": f"no static instruction count for {kernel} in profiles/r03_isa_counts.json"}
+            return {"bound": "valu issue", "error": f"no static instruction count for {kernel} in profiles/r04_isa_counts.json"}
         steps = n_lwe if steps_per_ct is None else steps_per_ct
         cyc_per_ct = float(c["valu_issue_cycles"]) * waves_per_ct * steps
         achieved = cyc_per_ct * count / (kernel_ms * 1e-3)
@@ -387,7 +387,7 @@ def main():
                 "valu_instructions_per_step_per_wavefront": c["valu"], "of_them_f64": c["valu_f64"],
                 "valu_issue_cycles_per_step_per_wavefront": c["valu_issue_cycles"], "wavefronts_per_ciphertext": waves_per_ct,
                 "steps_per_ciphertext": steps, "sclk_mhz": sclk_mhz, "sclk_source": sclk_src,
-                "source": "static ISA count (profiles/r03_isa_counts.json) x live launch rate; peak = 256 CUs x 4 SIMDs x sclk",
+                "source": "static ISA count (profiles/r04_isa_counts.json) x live launch rate; peak = 256 CUs x 4 SIMDs x sclk",
                 "modmul_per_s": MODMUL_PER_PBS * count / (kernel_ms * 1e-3), "modmul_per_pbs": MODMUL_PER_PBS}
 
     total_pbs = B * world * args.steps
