@@ -1271,8 +1271,8 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
                                                    c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, nullptr, (hipStream_t)stream);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }
-        if (int rcb = build_exact_torus_copies(c, nullptr)) return rcb;   // (variants 1 / 3 / 4, or a key without FFT copies: no-op once built)
         if (lat_t) {
+            if (int rcb = build_exact_torus_copies(c, nullptr)) return rcb;   // (variant 4, or a key without FFT copies: a no-op once built)
             rc = bmit::launch_blind_rotate_lat(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_lat, c->d_tw_half, d_out,
                                                count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
@@ -1286,6 +1286,7 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
                                                c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, nullptr, (hipStream_t)stream);
             return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
         }
+        if (int rcb = build_exact_torus_copies(c, nullptr)) return rcb;       // (variants 1 / 3, or a key without FFT copies)
         rc = bmit::launch_blind_rotate(d_small, d_lut_ids, (const u64 *)c->d_luts, (const double *)c->d_bsk,
                                        (const double *)c->d_tw, d_out, count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log,
                                        (hipStream_t)stream);
