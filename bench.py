@@ -566,7 +566,7 @@ def main():
                 plain_key_bytes = Pe.n * 4 * Pe.bs_levels * Pe.N * 8
                 gbs = plain_key_bytes * B / (kms * 1e-3) / 1e9
                 kname = ("k_blind_rotate_w_t64f<3, 10, 46, false>" if (qb == 65 and Pe.N == 2048) else
-                         {49: "k_blind_rotate_lat2u_49<3, 15>", 65: "k_blind_rotate_lat2u_t64f<3, 10, 42, false>"}[qb] if unroll else KERNEL[qb])
+                         {49: "k_blind_rotate_lat2u_49<3, 15>", 65: ("k_blind_rotate_tp2u_t64f<3, 10, 42>" if B > 256 else "k_blind_rotate_lat2u_t64f<3, 10, 42, false>")}[qb] if unroll else KERNEL[qb])
                 one_wg_per_ct = unroll or Pe.N > 1024
                 sm, ss = ck.result()
                 rep = {"q_bits": qb, "params": {"n": int(Pe.n), "N": int(Pe.N), "k": int(Pe.k), "l": int(Pe.bs_levels), "log2_Bg": int(Pe.bs_base_log),
@@ -576,7 +576,7 @@ def main():
                        "bsk_precision_bits": int(e2.bsk_precision),
                        "output_noise": output_noise(e2, out2, want_l, unrolled=unroll),
                        "kernel": kname, "kernel_ms": kms,
-                       "kernel_cycles_per_cmux": cycles_per_cmux(kms, B, (Pe.n + 1) // 2 if unroll else Pe.n, 1 if one_wg_per_ct else CTS_PER_WG[qb], sm),
+                       "kernel_cycles_per_cmux": cycles_per_cmux(kms, B, (Pe.n + 1) // 2 if unroll else Pe.n, (2 if "tp2u" in kname else 1) if one_wg_per_ct else CTS_PER_WG[qb], sm),
                        "sclk_mhz": sm,
                        "north_star": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                       "algorithmic_bytes_per_pbs": plain_key_bytes},

@@ -1252,7 +1252,14 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     if (c->t64()) {   // 2^64 torus: latency kernel (one workgroup per ciphertext) for small batches, wave pairs beyond
         if (c->unroll == 2) {   // unrolled key: one kernel (one workgroup per ciphertext) for every batch size
             if (!c->have_bsk3) return fail(c, -1, "unrolling selected but the context holds no unrolled key: generate keys after bmi_set_bsk_unroll, or bmi_import_bsk_unrolled");
-            rc = bmit::shape_supported_unrolled_fft(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log)
+            // the floating-point-transform route (42-bit key): one ciphertext per workgroup up to a full round of 256, two per workgroup
+            // (key words shared in registers: half the key bytes per bootstrap) beyond - the same words either way; variant 2 pins
+            // the former, variants 1 / 3 the latter
+            const bool ufft = bmit::shape_supported_unrolled_fft(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log);
+            const bool two = ufft && (c->variant == 1 || c->variant == 3 || (c->variant == 0 && count > 256));
+            rc = two ? bmit::launch_blind_rotate_tp2u_fft(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk3_lat, c->d_tw_fh, c->d_zeta_pow, d_out,
+                                                          count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream)
+                 : ufft
                      ? bmit::launch_blind_rotate_lat2u_fft(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk3_lat, c->d_tw_fh, c->d_zeta_pow, d_out,
                                                            count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, nullptr, (hipStream_t)stream)
                      : bmit::launch_blind_rotate_lat2u(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk3_lat, c->d_tw_half, c->d_root_pow, d_out,

@@ -232,7 +232,9 @@ int bmi_get_bsk_precision(const bmi_ctx *ctx, uint32_t *bits);
  *   ACC <- ACC + sum_{j<3} (X^(c_j) - 1) (K_j [.] ACC),  c = (a + a', a, a'),  K = GGSW(s s'), GGSW(s (1 - s')), GGSW((1 - s) s'),
  * with one decomposition and one set of forward transforms per step (half as many as the plain rotation; the factors X^c - 1
  * are applied in the transform domain).  Every batch size then runs k_blind_rotate_lat2u_49 (49-bit field, N = 1024),
- * k_blind_rotate_wide49u (N = 2048) or the torus kernel above, one workgroup per ciphertext.
+ * k_blind_rotate_wide49u (N = 2048) or the torus kernel above, one workgroup per ciphertext; on the torus's floating-point route,
+ * batches beyond 256 ciphertexts run k_blind_rotate_tp2u_t64f: two ciphertexts per workgroup sharing every key word in registers
+ * (half the key bytes per bootstrap; the same words).
  * The unrolled key (1.5 x the plain key's size) is generated by the next keygen call, or at once when the context already
  * holds secret keys; an evaluation-only context receives it through bmi_import_bsk_unrolled.  Layout:
  * [ceil(n/2)][3][(k+1) l][(k+1)][N] words, standard domain (an odd n is completed by a zero key bit).  Price: the key-noise

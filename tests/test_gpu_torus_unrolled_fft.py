@@ -69,6 +69,30 @@ def test_keys_are_the_oracles_rounded_to_42_bits_and_plain_pbs_is_refused(eng):
         e.close()
 
 
+@pytest.mark.parametrize("count", [1, 2, 5, 256, 257, 300, 701])
+def test_two_ciphertexts_per_workgroup_give_the_same_words(eng, count):
+    """the throughput form (k_blind_rotate_tp2u_t64f: two ciphertexts per workgroup sharing every key word in registers; what auto
+    runs beyond 256 ciphertexts) against the one-ciphertext form, word for word, for even and odd batches and adversarial rows"""
+    rng = np.random.default_rng(1000 + count)
+    lid = eng.lut_register(rng.integers(-8, 8, 16), 4, eng.delta_log())
+    ids = np.full(count, lid, np.uint32)
+    small = rng.integers(0, 1 << 63, (count, eng.P.small), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (count, eng.P.small), dtype=np.uint64)
+    small[0] = 0                                   # a ciphertext whose every step is skipped beside one that takes them all
+    if count > 2:
+        small[2, ::2] = 0
+        small[count - 1, 14::16] = 0
+        small[count - 1, 15::16] = 0
+    try:
+        eng.set_kernel_variant(2)
+        one = eng.blind_rotate_host(small, ids)
+        eng.set_kernel_variant(1)
+        two = eng.blind_rotate_host(small, ids)
+    finally:
+        eng.set_kernel_variant(0)
+    assert np.array_equal(one, two)
+    assert np.array_equal(eng.blind_rotate_host(small, ids), one)     # auto: whichever it picked
+
+
 @pytest.mark.parametrize("count", [1, 5, 300, 700])
 def test_unrolled_fft_pbs_bit_exact_every_batch_size(eng, count):
     to, P, ctx, sk_small, sk_big = _oracle(eng)

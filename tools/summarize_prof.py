@@ -62,7 +62,8 @@ def short(name):
 
 
 def cts_per_workgroup(kernel, wg):
-    if "lat" in kernel or "wide" in kernel or "quad" in kernel: return 1        # one workgroup per ciphertext
+    if "tp2u" in kernel: return 2                                                # two ciphertexts per workgroup sharing the key words
+    if "lat" in kernel or "wide" in kernel or "quad" in kernel or "w_t64f" in kernel: return 1        # one workgroup per ciphertext
     if wg == 512: return 4                                                       # wave-pair kernels: four ciphertexts per workgroup
     if wg == 256: return 2
     return None
@@ -120,7 +121,7 @@ for g in groups.values():
         r.update(avg_ms=sum(g["dur_ns"]) / len(g["dur_ns"]) / 1e6, min_ms=min(g["dur_ns"]) / 1e6, max_ms=max(g["dur_ns"]) / 1e6)
         if cpw and sclk_mhz:
             steps = 742 if "w_t64f" in g["kernel"] else 630          # LWE dimension of the set the kernel serves in bench.py
-            if "lat2u" in g["kernel"]:
+            if "lat2u" in g["kernel"] or "tp2u" in g["kernel"]:
                 steps = (steps + 1) // 2                             # the unrolled kernels take two coefficients per step
             rounds = -(-r["ciphertexts_per_launch"] // (cpw * 256))
             r.update(cycles_per_cmux=r["avg_ms"] * 1e-3 * sclk_mhz * 1e6 / (steps * rounds), sclk_mhz=sclk_mhz,
