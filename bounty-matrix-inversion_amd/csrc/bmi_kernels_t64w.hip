@@ -38,6 +38,9 @@ using fftq::static_for;
 using t64::f64_to_word;
 using t64::Scheme;
 
+#ifndef BMI_T64W_PRIO
+#define BMI_T64W_PRIO 0   // issue priority in the forward phase: 0 = none, 1 = a task steps down 3 (decomposition), 1 (transform), 0 (done): a wavefront that is ahead yields to the ones sharing its SIMD, 2 = the eight wavefronts that run TWO forward tasks (L = 3) keep priority 2 through the phase
+#endif
 #ifndef BMI_T64W_KEY_ROWS_AHEAD
 #define BMI_T64W_KEY_ROWS_AHEAD 2   // key rows (of 2 l) a thread holds in registers: requested before phase A, then row r + this many when row r is done
 #endif
@@ -189,6 +192,9 @@ __global__ void __launch_bounds__(WF_THREADS)
             // t0 + 64 (J & 3) + 256 (J >> 2) - the low 9 bits are the slot inside the residue block, bit 9 is the sign
             const uint32_t e0 = (4 * lane + h + 2 * WN - a_t) & (2 * WN - 1);
             const uint32_t t0 = e0 >> 2, pbase = (e0 & 3) * WF_RES;
+#if BMI_T64W_PRIO == 1
+            __builtin_amdgcn_s_setprio(3);
+#endif
             // (four coefficients at a time, fenced: the 32 key registers in flight leave this task ~90)
             static_for<0, 2>([&](auto G) {
                 double vr[4], vs[4];
@@ -216,10 +222,19 @@ __global__ void __launch_bounds__(WF_THREADS)
             });
             const double re[4] = {x[0], x[1], x[2], x[3]}, im[4] = {x[4], x[5], x[6], x[7]};
             C v[4];
+#if BMI_T64W_PRIO == 1
+            __builtin_amdgcn_s_setprio(1);
+#endif
             fftq::forward_quarter(h, re, im, v, lane, lds);
             double2 *tile = tiles + (size_t)T * WQ;
             static_for<0, 4>([&](auto R4) { tile[R4 * 64 + lane] = double2{v[R4].r, v[R4].i}; });
+#if BMI_T64W_PRIO == 1
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
+#if BMI_T64W_PRIO == 2
+        if (8 * L > 16 && wave < 8 * L - 16) __builtin_amdgcn_s_setprio(2);
+#endif
         forward_task(wave);
         PH_MARK(1);   // first forward task
         if constexpr (8 * L > 16) {
@@ -227,6 +242,9 @@ __global__ void __launch_bounds__(WF_THREADS)
             if (wave < 8 * L - 16) forward_task(16 + wave);
         }
         PH_MARK(2);   // second forward task (wavefronts 0 .. 8 L - 17)
+#if BMI_T64W_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();
         PH_MARK(3);   // barrier A -> B
         C s_lo[LIMBS], s_hi[LIMBS];
