@@ -1070,7 +1070,8 @@ int bmi_set_bsk_precision(bmi_ctx *c, uint32_t bits) {
         c->bsk_prec_explicit = true;
         return 0;
     }
-    const bool unrolled_fft = bmit::shape_supported_unrolled_fft((int)bits, c->P.bs_levels, c->P.bs_base_log);   // 42 bits at base 2^10: unrolled mode only
+    // 42 bits at base 2^10: in unrolled mode only (bmi_set_bsk_unroll first - which selects it by itself when no precision was set)
+    const bool unrolled_fft = c->unroll == 2 && bmit::shape_supported_unrolled_fft((int)bits, c->P.bs_levels, c->P.bs_base_log);
     if (!bmit::shape_supported((int)bits, c->P.bs_levels, c->P.bs_base_log) && !unrolled_fft)
         return fail(c, -1, "no kernel for this precision at this decomposition: base 2^10 takes 48 (default) or 64 bits - and 42 bits for the "
                            "unrolled floating-point-transform kernel (bmi_set_bsk_unroll) -, base 2^15 takes 64 (default) or 42 bits (a limb sum "

@@ -88,7 +88,8 @@ int main(void) {
     CHECK(bmi_preset_params("north_star_torus64", &S) == 0 && S.q_bits == BMI_Q_TORUS64, "torus preset");
     CHECK(bmi_ctx_create(&S, 0, &ctx) == 0, "torus context");
     {
-        /* the torus set: Bg = 2^10, bootstrap key stored at 48 bits of precision (two limbs); 42 bits belongs to Bg = 2^15 */
+        /* the torus set: Bg = 2^10, bootstrap key stored at 48 bits of precision (two limbs); 42 bits belongs to Bg = 2^15 - and, at
+         * this base, to the unrolled mode only (bmi_set_bsk_unroll first) */
         uint32_t prec = 0;
         CHECK(S.bs_base_log == 10 && bmi_get_bsk_precision(ctx, &prec) == 0 && prec == 48, "torus set: base 2^10, 48-bit key");
         CHECK(bmi_set_bsk_precision(ctx, 42) < 0, "42-bit key refused at base 2^10");

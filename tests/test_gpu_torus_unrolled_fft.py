@@ -22,8 +22,9 @@ PREC = 42
 def _engine(seed=SEED, **kw):
     from bmi_amd import tfhe
     e = tfhe.Engine(tfhe.default_params(q_bits=QB, **kw))
-    e.set_bsk_precision(PREC)
-    e.set_bsk_unroll(2)
+    e.set_bsk_unroll(2)           # selects the 42-bit key and the FFT route by itself ...
+    assert e.bsk_precision == PREC
+    e.set_bsk_precision(PREC)     # ... and the explicit choice is accepted in unrolled mode
     e.keygen(seed)
     return e
 
@@ -57,10 +58,15 @@ def test_keys_are_the_oracles_rounded_to_42_bits_and_plain_pbs_is_refused(eng):
     bsk3 = eng.export_bsk_unrolled()
     assert np.array_equal(to.round_key(to.keygen_bsk_unrolled(P, SEED, K.sk_small, K.sk_big), PREC), bsk3)
     assert not (bsk3 & np.uint64((1 << 22) - 1)).any()
-    # the 42-bit key at base 2^10 exists for the unrolled kernel only: a context left in plain mode refuses to bootstrap
+    # the 42-bit key at base 2^10 exists for the unrolled kernel only: a context in plain mode refuses the precision, and one that
+    # leaves the unrolled mode with the precision pinned refuses to bootstrap
     e = tfhe.Engine(tfhe.default_params(q_bits=QB))
     try:
+        with pytest.raises(tfhe.BmiError):
+            e.set_bsk_precision(PREC)
+        e.set_bsk_unroll(2)
         e.set_bsk_precision(PREC)
+        e.set_bsk_unroll(1)
         e.keygen(SEED)
         lid = e.lut_register(np.arange(-8, 8), 4, e.delta_log())
         with pytest.raises(tfhe.BmiError):
