@@ -37,6 +37,8 @@ def default_bsk_precision(P):
         return 64
     if P.log_N == 11:
         return 46
+    if P.log_N == 12:
+        return 44
     return 48 if P.bs_base_log <= 10 else 64
 
 
@@ -139,15 +141,15 @@ def candidate_sets(msg_bits, q_bits=None, secure=False):
     from . import tfhe
     torus = q_bits in (None, tfhe.TORUS64)       # None: the library's default modulus
     if secure:
-        if msg_bits > 4:
-            raise ValueError("the 128-bit-secure sets carry 4-bit look-ups (a 5-bit look-up would sit at 4.5 sigma under the secure LWE noise)")
-        return [("secure128_torus", "secure128_torus")] if torus else [("secure128", "secure128")]
+        # the secure LWE noise leaves a 4-bit look-up 9 sigma at N = 2048; a 5-bit one sits at 4.4 sigma there and at 4.9 sigma at
+        # N = 4096 (torus only) - whether that meets p_error is the budget's call, circuit by circuit
+        if msg_bits > 5 or (msg_bits > 4 and not torus):
+            raise ValueError("the 128-bit-secure sets carry 4-bit look-ups (5-bit ones on the 2^64 torus, at 4.4 - 4.9 sigma)")
+        return [("secure128_torus", "secure128_torus"), ("secure128_torus_wide", "secure128_torus_wide")] if torus else [("secure128", "secure128")]
     out = []
     for log_n in (10, 11, 12):
         if (1 << (msg_bits + 6)) > (1 << log_n):
             continue                                  # N >= 2^(msg_bits + 6): the box structure of the tracer's message space
-        if torus and log_n > 11:
-            continue                                  # the 2^64 torus has kernels for N = 1024 and N = 2048
         qb = tfhe.TORUS64 if torus else 49
         out.append((f"q_bits={qb}, N={1 << log_n}", dict(q_bits=qb, log_N=log_n) if log_n != 10 else dict(q_bits=qb)))
     if not out:

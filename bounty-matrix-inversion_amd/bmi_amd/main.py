@@ -167,14 +167,13 @@ class EncryptedMatrixInversion:
                 params, self.error_budget = error_budget.choose_params(self.program, self.p_error, q_bits=qb, unroll=self.unroll)
             elif self.msg_bits <= 4:
                 params = tfhe.default_params(q_bits=qb)
-            elif self.msg_bits == 5 and qb == tfhe.TORUS64:   # 5-bit look-ups on the 2^64 torus: N = 2048 (k_blind_rotate_w_t64f)
-                params = tfhe.default_params(q_bits=tfhe.TORUS64, log_N=11)
-            elif self.msg_bits == 5 and qb is None:           # the library's default modulus (the torus) carries 5 bits at N = 2048
-                params = tfhe.default_params(log_N=11)
-            elif qb in (None, 49):                            # 6-bit look-ups: N = 4096, 49-bit field only
-                params = tfhe.default_params(q_bits=49, log_N=self.msg_bits + 6)
+            elif self.msg_bits <= 6 and qb in (None, tfhe.TORUS64, 49):
+                # 5-bit look-ups: N = 2048, 6-bit ones: N = 4096 - one more message bit per doubling of N at the same margin; on the
+                # library's default modulus (the 2^64 torus: k_blind_rotate_w_t64f / k_blind_rotate_q_t64f) unless q_bits says 49
+                params = tfhe.default_params(log_N=self.msg_bits + 6, **({} if qb is None else dict(q_bits=qb)))
             else:
-                raise ValueError("look-ups wider than 5 bits need N = 4096, which exists on the 49-bit field only")
+                raise ValueError("look-ups wider than 4 bits need N >= 2048, which exists on the 2^64 torus and the 49-bit field; "
+                                 "wider than 6 bits: no parameter set")
             if self.unroll:
                 if self.msg_bits > 4 or params.log_N != 10:
                     raise ValueError("bootstrap-key unrolling exists at N = 1024 (4-bit look-ups) only")

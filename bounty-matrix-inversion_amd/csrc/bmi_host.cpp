@@ -23,6 +23,7 @@
 #include "ntt_wave_f64.hpp"
 #include "fft_half_f64.hpp"
 #include "fft_wave_f64.hpp"
+#include "fft_eighth_f64.hpp"
 #include "fft_quarter_f64.hpp"
 #include "t64_common.hpp"
 
@@ -201,7 +202,8 @@ struct bmi_ctx {
     double *d_tw_fft = nullptr, *d_bsk_fft = nullptr;           // 2^64 torus, key at 48 bits: tables and key copy of the floating-point-transform wave-pair kernel (bmi_kernels_t64f.hip)
     double *d_tw_fh = nullptr, *d_bsk_latf = nullptr;           // ... and of its latency form (half transforms, fft_half_f64.hpp; key in slot-pair order)
     double *d_zeta_pow = nullptr;                               // 2^64 torus at N = 1024: zeta^x, x in [0, 1024) as (re, im) - the factors X^c of the unrolled floating-point-transform kernel
-    double *d_tw_fq = nullptr, *d_bsk_w = nullptr;              // 2^64 torus at N = 2048, key at 46 bits: tables and key copy of bmi_kernels_t64w.hip (quarter transforms, fft_quarter_f64.hpp)
+    double *d_tw_fq = nullptr, *d_bsk_w = nullptr;              // 2^64 torus at N = 2048, key at 46 bits: tables and key copy of bmi_kernels_t64w.hip (quarter transforms, fft_quarter_f64.hpp);
+                                                                // at N = 4096, key at 44 bits: those of bmi_kernels_t64q.hip (eighth transforms, fft_eighth_f64.hpp)
     double *d_tw_wide = nullptr;                                // N = 2048: T / T^-1 of the even/odd combination (d_bsk_lat then holds the wide key copy)
     // bootstrap-key unrolling (49-bit field at N = 1024 / 2048, 2^64 torus; bmi_set_bsk_unroll): per pair of LWE coefficients the GGSW encryptions of
     // s s', s (1 - s'), (1 - s) s'; host copy in the standard domain, device copy in the slot order of the latency kernel
@@ -366,13 +368,13 @@ std::vector<u64> build_twiddles_quad(const Fq &f) {
 
 // precision a torus context stores its bootstrap key at unless bmi_set_bsk_precision says otherwise: 48 bits (two 24-bit limbs)
 // where the decomposition base leaves room for it (Bg <= 2^10: the default torus set), else the exact key (three 22-bit limbs)
-// (N = 2048: 46 bits, two 23-bit limbs - the length at which the floating-point transform's error bound still certifies the rounding)
-int default_bsk_precision(const bmi_params &P) { return P.log_N == 11 ? 46 : (P.bs_base_log <= 10 ? 48 : 64); }
+// (N = 2048: 46 bits, two 23-bit limbs; N = 4096: 44 bits, two 22-bit limbs - the lengths at which the floating-point transform's error
+// bound still certifies the rounding)
+int default_bsk_precision(const bmi_params &P) { return P.log_N == 12 ? 44 : P.log_N == 11 ? 46 : (P.bs_base_log <= 10 ? 48 : 64); }
 
 bool params_supported(const bmi_params &P, std::string &why) {
-    if (P.q_bits == BMI_Q_TORUS64 && P.log_N != 10 && P.log_N != 11) { why = "the 2^64 torus has HIP kernels for N = 1024 and N = 2048"; return false; }
-    if (P.log_N != 10 && !((P.log_N == 11 || P.log_N == 12) && P.q_bits == 49) && !(P.log_N == 11 && P.q_bits == BMI_Q_TORUS64)) {
-        why = "log_N must be 10 (N = 1024), 11 (N = 2048: 49-bit field or 2^64 torus) or 12 (N = 4096: 49-bit field)";
+    if (P.log_N < 10 || P.log_N > 12 || (P.log_N != 10 && P.q_bits != 49 && P.q_bits != BMI_Q_TORUS64)) {
+        why = "log_N must be 10 (N = 1024), 11 (N = 2048: 49-bit field or 2^64 torus) or 12 (N = 4096: 49-bit field or 2^64 torus)";
         return false;
     }
     if (P.k != 1) { why = "only k = 1 has a HIP kernel in this build"; return false; }
@@ -381,7 +383,8 @@ bool params_supported(const bmi_params &P, std::string &why) {
     // (2, 2^15) and (1, 2^23): the templated 49-bit kernels (N = 1024 wave-pair / latency kernels, N = 2048), and (2, 2^15) on the torus
     const bool ok_lb = (lb_default && P.q_bits != BMI_Q_TORUS64) || (P.q_bits == 49 && P.log_N <= 11 && lb_f64) ||
                        (P.q_bits == BMI_Q_TORUS64 && P.log_N == 10 && bmit::shape_supported(default_bsk_precision(P), P.bs_levels, P.bs_base_log)) ||
-                       (P.q_bits == BMI_Q_TORUS64 && P.log_N == 11 && bmit::shape_supported_wide(default_bsk_precision(P), P.bs_levels, P.bs_base_log));
+                       (P.q_bits == BMI_Q_TORUS64 && P.log_N == 11 && bmit::shape_supported_wide(default_bsk_precision(P), P.bs_levels, P.bs_base_log)) ||
+                       (P.q_bits == BMI_Q_TORUS64 && P.log_N == 12 && bmit::shape_supported_quad(default_bsk_precision(P), P.bs_levels, P.bs_base_log));
     if (!ok_lb) {
         why = "(l, Bg) must be (3, 2^15); the 49-bit field at N <= 2048 also takes (2, 2^15) and (1, 2^23), the 2^64 torus (3 or 2, 2^10) "
               "and, at N = 1024, (3 or 2, 2^15)";
@@ -434,6 +437,15 @@ int bmi_preset_params(const char *name, bmi_params *out) {
         // (two 23-bit limbs: exact limb sums through the floating-point transform, fft_quarter_f64.hpp) - output noise 2^-22.9,
         // below the 49-bit preset's 2^-19.5; keyswitch 8 x 2 bits as there.
         *out = bmi_params{742, 11, 1, 3, 10, 8, 2, BMI_Q_TORUS64, 7.069849454709433e-6, std::ldexp(1.0, -44)};
+        return 0;
+    }
+    if (s == "secure128_torus_wide") {
+        // the same LWE pair under a GLWE of size 4096 (harder than the 2048 the noise 2^-44 is rated for) on q = 2^64, for the 5-bit
+        // look-ups of the reference's unmodified circuits and of bases other than 2: key at 44 bits of precision (two 22-bit limbs,
+        // fft_eighth_f64.hpp), bootstrap 3 x 10 bits.  The keyswitch noise (4,096 x levels rows at the LWE noise security dictates)
+        // is what bounds the margin: 16 levels of 1 bit (mean-square digit 1/2) put a 5-bit look-up at 5.4 sigma, against 4.6 with
+        // 8 x 2 bits and 4.4 at N = 2048 - whether that carries a circuit is error_budget's call (p_error), look-up count by count.
+        *out = bmi_params{742, 12, 1, 3, 10, 16, 1, BMI_Q_TORUS64, 7.069849454709433e-6, std::ldexp(1.0, -44)};
         return 0;
     }
     return -1;
@@ -525,9 +537,11 @@ int bmi_ctx_create(const bmi_params *params, int device, bmi_ctx **out) {
         if (hipMemcpy(c->d_root_pow, rpd.data(), rpd.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(root powers) failed");
     }
-    if (c->t64() && c->wide()) {   // tables of the quarter transforms (fft_quarter_f64.hpp): powers of zeta = exp(i pi / 2048)
+    if (c->t64() && (c->wide() || c->quad())) {   // tables of the quarter / eighth transforms: powers of zeta = exp(i pi / N)
+        static_assert(ffte::ET_WORDS == fftq::QT_WORDS, "the two table sets share a size");
         std::vector<double> tq(fftq::QT_WORDS);
-        fftq::build_tables(tq.data());
+        if (c->quad()) ffte::build_tables(tq.data());
+        else fftq::build_tables(tq.data());
         if (hipMalloc(&c->d_tw_fq, tq.size() * 8) != hipSuccess) return bail("hipMalloc(quarter-fft twiddles) failed");
         if (hipMemcpy(c->d_tw_fq, tq.data(), tq.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
             return bail("hipMemcpy(quarter-fft twiddles) failed");
@@ -814,13 +828,13 @@ int upload_eval_keys(bmi_ctx *c) {
     HIP_OK(c, hipMalloc(&d_tmp, bsk_words * sizeof(u64)));
     HIP_OK(c, hipMemcpy(d_tmp, c->bsk_std.data(), bsk_words * sizeof(u64), hipMemcpyHostToDevice));
     int rc = 0;
-    if (c->t64() && c->wide()) {  // 2^64 torus at N = 2048: ONE key copy, two limb polynomials per key polynomial in the order of bmi_kernels_t64w.hip
+    if (c->t64() && (c->wide() || c->quad())) {  // 2^64 torus at N = 2048 / 4096: ONE key copy, two limb polynomials per key polynomial in the order of bmi_kernels_t64w.hip / t64q.hip
         if (c->d_bsk_w) { (void)hipFree(c->d_bsk_w); c->d_bsk_w = nullptr; }
         if (hipMalloc(&c->d_bsk_w, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) {
             (void)hipFree(d_tmp);
-            return fail(c, -2, "hipMalloc(torus N = 2048 key) failed");
+            return fail(c, -2, "hipMalloc(torus N = 2048 / 4096 key) failed");
         }
-        rc = bmit::launch_bsk_to_wide(d_tmp, c->d_bsk_w, c->d_tw_fq, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
+        rc = (c->quad() ? bmit::launch_bsk_to_quad : bmit::launch_bsk_to_wide)(d_tmp, c->d_bsk_w, c->d_tw_fq, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
         if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_wide (torus) launch failed"); }
     } else if (c->t64()) {  // 2^64 torus at N = 1024: bsk_limbs transform-domain limb polynomials per key polynomial
         for (void **p : {&c->d_bsk, (void **)&c->d_bsk_lat, (void **)&c->d_bsk_fft, (void **)&c->d_bsk_latf})
@@ -887,7 +901,7 @@ int upload_eval_keys(bmi_ctx *c) {
     }
     // limb-wise copy of the keyswitch key for the matrix-core keyswitch (int8 operands, int32 sums: the digits must
     // fit int8 and a column sum of rows * (B/2) * 128 must stay below 2^31)
-    c->ks_mfma_ok = ksk_rows % 32 == 0 && P.ks_levels <= 8 && P.ks_base_log <= 7 &&
+    c->ks_mfma_ok = ksk_rows % 32 == 0 && P.ks_levels <= 16 && P.ks_base_log <= 7 &&
                     (ksk_rows << (P.ks_base_log - 1)) < ((size_t)1 << 24);
     if (c->ks_mfma_ok) {
         const uint32_t cbs = (n + 1 + 31) / 32;
@@ -1060,12 +1074,13 @@ int bmi_lut_get(const bmi_ctx *c, uint32_t lut_id, uint64_t *test_vector) {
 int bmi_set_bsk_precision(bmi_ctx *c, uint32_t bits) {
     if (!c) return -1;
     if (!c->t64()) return fail(c, -1, "the bootstrap-key precision option exists on the 2^64 torus only");
-    if (!t64::precision_ok((int)bits)) return fail(c, -1, "bootstrap-key precision must be 64 (exact), 48, 46 or 42 bits");
+    if (!t64::precision_ok((int)bits)) return fail(c, -1, "bootstrap-key precision must be 64 (exact), 48, 46, 44 or 42 bits");
     if (c->have_keys) return fail(c, -1, "set the bootstrap-key precision before generating or importing keys");
-    if (c->wide()) {
-        if (!bmit::shape_supported_wide((int)bits, c->P.bs_levels, c->P.bs_base_log))
-            return fail(c, -1, "at N = 2048 the torus kernel takes the key at 46 bits of precision (two 23-bit limbs) only: the length at which "
-                               "the floating-point transform's error bound certifies the rounding (fft_quarter_f64.hpp)");
+    if (c->wide() || c->quad()) {
+        if (!(c->quad() ? bmit::shape_supported_quad : bmit::shape_supported_wide)((int)bits, c->P.bs_levels, c->P.bs_base_log))
+            return fail(c, -1, "at N = 2048 the torus kernel takes the key at 46 bits of precision (two 23-bit limbs) only, at N = 4096 at 44 bits (two "
+                               "22-bit limbs): the lengths at which the floating-point transform's error bound certifies the rounding "
+                               "(fft_quarter_f64.hpp, fft_eighth_f64.hpp)");
         c->bsk_prec = (int)bits;
         c->bsk_prec_explicit = true;
         return 0;
@@ -1094,8 +1109,8 @@ int bmi_set_bsk_unroll(bmi_ctx *c, uint32_t factor) {
     if (factor != 1 && factor != 2) return fail(c, -1, "the unrolling factor is 1 or 2");
     if (factor == 2 && !((c->f64() && !c->quad()) || c->t64()))
         return fail(c, -1, "bootstrap-key unrolling has HIP kernels for the 49-bit field at N = 1024 and N = 2048 and for the 2^64 torus only");
-    if (factor == 2 && c->t64() && c->wide())
-        return fail(c, -1, "bootstrap-key unrolling has no HIP kernel on the 2^64 torus at N = 2048");
+    if (factor == 2 && c->t64() && (c->wide() || c->quad()))
+        return fail(c, -1, "bootstrap-key unrolling has no HIP kernel on the 2^64 torus at N = 2048 / 4096");
     if (c->t64() && !c->bsk_prec_explicit && !c->have_keys) {
         // the precision nobody chose follows the mode: the unrolled step runs through the floating-point transform on a key stored
         // at 42 bits (k_blind_rotate_lat2u_t64f: 2.9 ms per bootstrap against 3.3 of the exact-transform kernel on the 48-bit key,
@@ -1121,7 +1136,7 @@ int bmi_set_bsk_unroll(bmi_ctx *c, uint32_t factor) {
 
 int bmi_import_bsk_unrolled(bmi_ctx *c, const uint64_t *bsk3) {
     if (!c || !bsk3) return -1;
-    if (!((c->f64() && !c->quad()) || (c->t64() && !c->wide())))
+    if (!((c->f64() && !c->quad()) || (c->t64() && !c->wide() && !c->quad())))
         return fail(c, -1, "bootstrap-key unrolling has HIP kernels for the 49-bit field at N = 1024 and N = 2048 and for the 2^64 torus at N = 1024 only");
     if (!c->have_keys) return fail(c, -1, "no keys: import or generate the key set first");
     const size_t words = c->bsk3_words();
@@ -1245,8 +1260,8 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     // with wave-pair work, the throughput kernel beyond that (49-bit field: the exchange-once form).
     const bool latency = c->variant == 2 || (c->variant == 0 && count <= c->lat_threshold);
     int rc;
-    if (c->t64() && c->wide()) {   // 2^64 torus at N = 2048: one kernel (one workgroup per ciphertext) for every batch size
-        rc = bmit::launch_blind_rotate_wide(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_w, c->d_tw_fq, d_out, count, c->P.n,
+    if (c->t64() && (c->wide() || c->quad())) {   // 2^64 torus at N = 2048 / 4096: one kernel (one workgroup per ciphertext) for every batch size
+        rc = (c->quad() ? bmit::launch_blind_rotate_quad : bmit::launch_blind_rotate_wide)(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_w, c->d_tw_fq, d_out, count, c->P.n,
                                             c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, nullptr, (hipStream_t)stream);
         return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
     }
@@ -1483,8 +1498,8 @@ int bmi_fft_margin_host(bmi_ctx *c, const uint64_t *small_in, const uint32_t *lu
     if (!c->have_keys) return fail(c, -1, "no keys: call bmi_keygen first");
     const bool ufft = c->t64() && c->unroll == 2 && c->have_bsk3 && bmit::shape_supported_unrolled_fft(c->bsk_prec, c->P.bs_levels, c->P.bs_base_log);
     if (!c->d_bsk_fft && !c->d_bsk_w && !ufft)
-        return fail(c, -1, "the floating-point-transform kernels exist on the 2^64 torus with the bootstrap key at 48 bits (N = 1024) or 46 bits "
-                           "(N = 2048) in base 2^10");
+        return fail(c, -1, "the floating-point-transform kernels exist on the 2^64 torus with the bootstrap key at 48 bits (N = 1024), 46 bits "
+                           "(N = 2048) or 44 bits (N = 4096) in base 2^10");
     if (int bad = check_lut_ids(c, lut_ids, count)) return bad;
     HIP_OK(c, hipSetDevice(c->device));
     int rc = ensure_io(c, count);
@@ -1502,7 +1517,7 @@ int bmi_fft_margin_host(bmi_ctx *c, const uint64_t *small_in, const uint32_t *lu
             : (!c->d_bsk_w && (c->variant == 6 || c->variant == 2))   // the latency form of the N = 1024 transform (kernel variant 6 / 2 selected)
                 ? (hipError_t)bmit::launch_blind_rotate_lat_fft(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_latf, c->d_tw_fh, c->d_io_b,
                                                                 count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, d_stat, c->stream)
-            : c->d_bsk_w ? (hipError_t)bmit::launch_blind_rotate_wide(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_w, c->d_tw_fq, c->d_io_b,
+            : c->d_bsk_w ? (hipError_t)(c->quad() ? bmit::launch_blind_rotate_quad : bmit::launch_blind_rotate_wide)(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_w, c->d_tw_fq, c->d_io_b,
                                                                     count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, d_stat, c->stream)
                        : (hipError_t)bmit::launch_blind_rotate_fft(c->d_small, c->d_io_ids, (const u64 *)c->d_luts, c->d_bsk_fft, c->d_tw_fft, c->d_io_b,
                                                                    count, c->P.n, c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, d_stat, c->stream);

@@ -200,6 +200,14 @@ int launch_blind_rotate_lat2u_fft(const u64 *small_cts, const uint32_t *lut_ids,
 int launch_blind_rotate_tp2u_fft(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk3_latf,
                                  const double *g_tw_h, const double *g_zeta_pow, u64 *out, uint32_t count, uint32_t n, int prec,
                                  uint32_t levels, uint32_t base_log, hipStream_t s);
+// N = 4096 (bmi_kernels_t64q.hip, fft_eighth_f64.hpp): key at 44 bits of precision (two 22-bit limbs), one workgroup per ciphertext,
+// one decomposition level of tiles in LDS at a time; key copy per (polynomial, limb) [t 8][256 slots] complex words A_k / 4; tables
+// ffte::ET_WORDS doubles
+bool shape_supported_quad(int prec, uint32_t levels, uint32_t base_log);
+int launch_bsk_to_quad(const u64 *std_polys, double *q_polys, const double *g_tw_e, uint32_t n_polys, int prec, hipStream_t s);
+int launch_blind_rotate_quad(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_q, const double *g_tw_e,
+                             u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels, uint32_t base_log, unsigned long long *stat,
+                             hipStream_t s);
 // N = 2048 (bmi_kernels_t64w.hip, fft_quarter_f64.hpp): key at 46 bits of precision (two 23-bit limbs), one workgroup of 16
 // wavefronts per ciphertext for every batch size; key copy per (polynomial, limb) 1,024 complex words A_k / 2 in the order of the
 // multiplying threads; tables fftq::QT_WORDS doubles; stat as in launch_blind_rotate_fft

@@ -39,7 +39,7 @@ constexpr int WAVES = 4;     // wavefronts (ciphertext tiles) per workgroup
 #define BMI_KS_PF 4   // measured at 8,192 ciphertexts, 7 limbs (keyswitch total, three kernels): 1.13 ms with the round-2 double buffer, 0.72 / 0.70 / 0.65 ms at depth 1 / 2 / 4 of this ring
 #endif
 
-// ---- digits: one thread per mask coefficient; requires levels <= 8 (one 8-byte store when levels == 8)
+// ---- digits: one thread per mask coefficient; requires levels <= 16 (8-byte stores when levels is 8 or 16)
 template <class F>
 __global__ void __launch_bounds__(256)
     k_ks_digits(const u64 *__restrict__ in, signed char *__restrict__ D, uint32_t count, uint32_t big_n, uint32_t levels,
@@ -47,15 +47,17 @@ __global__ void __launch_bounds__(256)
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)count * big_n) return;
     const uint32_t ct = (uint32_t)(idx / big_n), j = (uint32_t)(idx % big_n);
-    unsigned char d[8];
+    unsigned char d[16];
     F::digits(in[(size_t)ct * (big_n + 1) + j], levels, base_log, d);
     const int half = 1 << (base_log - 1);
     signed char *o = D + ((size_t)ct * big_n + j) * levels;
-    if (levels == 8) {
-        u64 w = 0;
+    if ((levels & 7) == 0) {
+        for (uint32_t g = 0; g < levels; g += 8) {
+            u64 w = 0;
 #pragma unroll
-        for (int lev = 0; lev < 8; lev++) w |= (u64)(unsigned char)(signed char)((int)d[lev] - half) << (8 * lev);
-        *reinterpret_cast<u64 *>(o) = w;
+            for (int lev = 0; lev < 8; lev++) w |= (u64)(unsigned char)(signed char)((int)d[g + lev] - half) << (8 * lev);
+            *reinterpret_cast<u64 *>(o + g) = w;
+        }
     } else {
         for (uint32_t lev = 0; lev < levels; lev++) o[lev] = (signed char)((int)d[lev] - half);
     }

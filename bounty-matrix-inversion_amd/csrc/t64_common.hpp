@@ -15,6 +15,8 @@
 //                                          error (2^15.x per word, summed over the GLWE key's set bits: 2^18.7 per row) stays
 //                                          under the key noise 2^20 - output noise 2^-22.6 against 2^-19.85 of (Bg 2^15, exact)
 //   42 bits  2 limbs of 21 bits, PRE = 22  round 2's throughput option at Bg = 2^15 (effective key noise 2^-39.3)
+//   44 bits  2 limbs of 22 bits, PRE = 20  N = 4096 (Bg = 2^10, l = 3) through the floating-point transform only (bmi_kernels_t64q.hip,
+//                                          fft_eighth_f64.hpp): the a-priori error bound of the 2,048-point transform is 0.45 at this width
 //   46 bits  2 limbs of 23 bits, PRE = 18  N = 2048 (the secure128_torus set, Bg = 2^10, l = 3) through the floating-point
 //                                          transform only (bmi_kernels_t64w.hip): a limb sum 2 l N 2^9 2^22 = 2^44.6 keeps the
 //                                          a-priori error bound of the 1,024-point transform below 1/2 (fft_quarter_f64.hpp)
@@ -38,8 +40,9 @@ template <> struct Scheme<64> { static constexpr int LIMBS = 3, BITS = 22, PRE =
 template <> struct Scheme<48> { static constexpr int LIMBS = 2, BITS = 24, PRE = 16; };
 template <> struct Scheme<42> { static constexpr int LIMBS = 2, BITS = 21, PRE = 22; };
 template <> struct Scheme<46> { static constexpr int LIMBS = 2, BITS = 23, PRE = 18; };
+template <> struct Scheme<44> { static constexpr int LIMBS = 2, BITS = 22, PRE = 20; };
 
-T64_HD bool precision_ok(int prec) { return prec == 64 || prec == 48 || prec == 46 || prec == 42; }
+T64_HD bool precision_ok(int prec) { return prec == 64 || prec == 48 || prec == 46 || prec == 44 || prec == 42; }
 T64_HD int limbs_of(int prec) { return prec == 64 ? 3 : 2; }
 T64_HD int limb_bits(int prec) { return prec == 64 ? 22 : prec / 2; }
 T64_HD int limb_pre(int prec) { return 64 - prec; }

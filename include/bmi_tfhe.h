@@ -44,11 +44,11 @@ typedef struct bmi_ctx bmi_ctx;
 
 typedef struct {
     uint32_t n;           /* small LWE dimension (630; up to 1024) */
-    uint32_t log_N;       /* log2 polynomial size (10) */
+    uint32_t log_N;       /* log2 polynomial size (10; 11 and 12 on the 2^64 torus and the 49-bit field) */
     uint32_t k;           /* GLWE dimension (1) */
     uint32_t bs_levels;   /* l: bootstrap decomposition levels (3; (2, 15) and (1, 23) on the 49-bit field at N <= 2048, */
     uint32_t bs_base_log; /* bootstrap decomposition base log (15; 10 on the 2^64 torus)   (3 | 2, 10 | 15) on the torus) */
-    uint32_t ks_levels;   /* keyswitch levels (8) */
+    uint32_t ks_levels;   /* keyswitch levels (8; up to 16 through the matrix-core kernel) */
     uint32_t ks_base_log; /* keyswitch base log (4) */
     uint32_t q_bits;      /* ciphertext modulus: 64 -> q = 2^64 - 2^32 + 1 (Goldilocks, integer kernels);
                              49 -> q = 2^49 - 720895 (exact integers carried in f64: the fastest kernels);
@@ -82,6 +82,10 @@ int bmi_default_params_for(uint32_t q_bits, bmi_params *out);
  *                           q = 2^64: N 2048, k 1, l 3 x 10 bits, keyswitch 8 x 2 bits, bootstrap key stored at 46 bits of
  *                           precision (two 23-bit limbs; exact limb sums through the floating-point transform,
  *                           k_blind_rotate_w_t64f).  Output noise 2^-22.9 (the 49-bit preset: 2^-19.5).
+ *   "secure128_torus_wide"  the same LWE pair under N 4096 on q = 2^64, for 5-bit look-ups (the reference's unmodified circuits,
+ *                           bases other than 2): l 3 x 10 bits, bootstrap key at 44 bits of precision (two 22-bit limbs,
+ *                           k_blind_rotate_q_t64f), keyswitch 16 x 1 bit - the keyswitch noise bounds the margin: a 5-bit look-up
+ *                           sits at 5.4 sigma (4.6 with 8 x 2 bits; 4.4 at N 2048).  error_budget.choose_params decides per circuit.
  * The north-star sets keep n = 630 as BASELINE.json prescribes; their noise is sized for correctness, NOT for 128-bit
  * security. */
 int bmi_preset_params(const char *name, bmi_params *out);
@@ -175,7 +179,7 @@ int bmi_keyswitch_batch_host(bmi_ctx *ctx, const uint64_t *in, uint32_t count, u
 int bmi_blind_rotate_batch_host(bmi_ctx *ctx, const uint64_t *small_in, const uint32_t *lut_ids, uint32_t count,
                                 uint64_t *out);
 /* Test hook of the floating-point-transform kernels (2^64 torus; N = 1024: key at 48 bits, kernel variants 5 / 6; N = 2048: key at
- * 46 bits): blind rotation of `count` small-key ciphertexts by the wave-pair kernel - by the latency form when kernel variant 6 or 2
+ * 46 bits; N = 4096: key at 44 bits, k_blind_rotate_q_t64f): blind rotation of `count` small-key ciphertexts by the wave-pair kernel - by the latency form when kernel variant 6 or 2
  * is selected, by k_blind_rotate_w_t64f at N = 2048 -, which here also records how far every limb sum was from the integer it was
  * rounded to.  *max_distance must stay far below 1/2 (measured: below 2^-11) - that is what makes the
  * rounded results the exact integer sums, whatever the order of the floating-point operations. */
@@ -213,6 +217,8 @@ int bmi_set_kernel_variant(bmi_ctx *ctx, int variant);
  *   46  N = 2048 only (its default and only precision; "secure128_torus"): multiples of 2^18, two 23-bit limbs - the limb width at
  *       which the a-priori error bound of the 1,024-point floating-point transform still certifies the rounding of a limb sum
  *       (0.41 < 1/2, csrc/fft_quarter_f64.hpp; 24-bit limbs: 0.83).
+ *   44  N = 4096 only (its default and only precision; 6-bit look-ups, "secure128_torus_wide"): multiples of 2^20, two 22-bit limbs
+ *       (2,048-point transform: bound 0.45, csrc/fft_eighth_f64.hpp; 23-bit limbs: 0.90).
  *   42  multiples of 2^22, two 21-bit limbs.  At Bg = 2^10 in UNROLLED mode only - the precision bmi_set_bsk_unroll(ctx, 2) selects
  *       by itself when none was set: the three scaled products of an unrolled step make the limb sums six times larger, and 21-bit
  *       limbs keep them inside the range the floating-point transform is certified for (k_blind_rotate_lat2u_t64f; output noise

@@ -56,12 +56,14 @@ def default_params(**kw):
 
 def default_bsk_precision(P):
     """bits of precision the library stores a torus bootstrap key at by default (bmi_set_bsk_precision): 48 where the
-    decomposition base leaves room for two 24-bit limbs (Bg <= 2^10), else the exact key; 46 (two 23-bit limbs) at N = 2048;
+    decomposition base leaves room for two 24-bit limbs (Bg <= 2^10), else the exact key; 46 (two 23-bit limbs) at N = 2048, 44 (two 22-bit limbs) at N = 4096;
     other moduli: exact"""
     if P.q_bits != TORUS64:
         return 64
     if P.log_N == 11:
         return 46
+    if P.log_N == 12:
+        return 44
     return 48 if P.bs_base_log <= 10 else 64
 
 

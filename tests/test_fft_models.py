@@ -90,6 +90,25 @@ def test_quarter_transform_model():
     assert np.all(np.rint(out) == exact) and np.abs(out - exact).max() < 2.0 ** -9
 
 
+def test_eighth_transform_model():
+    """N = 4096 (csrc/fft_eighth_f64.hpp): eight 256-point eighths + a radix-8 butterfly against the definition, the three stored
+    tables W_1, W_2, W_4 against W_h, and one CMUX-sized sum of products (digits against 22-bit limbs, the key side scaled by 1/4
+    as the key copy is) rounding to the exact integers"""
+    import fft_eighth_model as m
+    rng = np.random.default_rng(5)
+    for h in range(8):
+        a, b = m.w_table(h), m.w_from_three(h)
+        assert max(np.abs(a[r] - b[r]).max() for r in range(4)) < 1e-14
+    c = rng.integers(-512, 512, 4096).astype(float)
+    assert np.abs(m.full_from_eighths(c) - m.definition(c)).max() < 1e-4
+    d = rng.integers(-512, 512, (6, 4096)).astype(float)
+    k = rng.integers(-(1 << 21), 1 << 21, (6, 4096)).astype(float)
+    Y = sum(m.full_from_eighths(d[p]) * (0.25 * m.full_from_eighths(k[p])) for p in range(6))
+    out = m.inverse_from_products(Y)
+    exact = m.exact_negacyclic_sum(d, k)
+    assert np.all(np.rint(out) == exact) and np.abs(out - exact).max() < 2.0 ** -8
+
+
 def test_a_priori_rounding_bounds():
     """tools/fft_bound.py: Percival's bound on a limb sum stays below 1/2 for both torus sets (the twist counted as a stage of its
     own) and fails for 24-bit limbs at N = 2048 - which is why that set stores its key at 46 bits"""
@@ -97,4 +116,6 @@ def test_a_priori_rounding_bounds():
     n1024, _ = b.limb_sum_bound(10, 3, 10, 24)
     n2048, _ = b.limb_sum_bound(11, 3, 10, 23)
     bad, _ = b.limb_sum_bound(11, 3, 10, 24)
-    assert 0.3 < n1024 < 0.5 and 0.3 < n2048 < 0.5 and bad > 0.5
+    n4096, _ = b.limb_sum_bound(12, 3, 10, 22)
+    bad4, _ = b.limb_sum_bound(12, 3, 10, 23)
+    assert 0.3 < n1024 < 0.5 and 0.3 < n2048 < 0.5 and bad > 0.5 and 0.3 < n4096 < 0.5 and bad4 > 0.5

@@ -537,13 +537,14 @@ def test_encrypted_base3_inverse_matches_reference_golden():
         emi.engine.close()
 
 
-def test_six_bit_circuit_on_the_N4096_parameter_set():
-    """Circuit(msg_bits=6) through the executor on the N = 4096 set: a 64-entry look-up, an 8 x 8 packed bivariate one
-    and a 7-bit odd one on ciphertexts, against the plaintext simulation."""
+@pytest.mark.parametrize("qb", [65, 49])
+def test_six_bit_circuit_on_the_N4096_parameter_set(qb):
+    """Circuit(msg_bits=6) through the executor on the N = 4096 set (2^64 torus: k_blind_rotate_q_t64f; 49-bit field): a 64-entry
+    look-up, an 8 x 8 packed bivariate one and a 7-bit odd one on ciphertexts, against the plaintext simulation."""
     from bmi_amd import tfhe
     from bmi_amd.circuit import Circuit
     from bmi_amd.executor import Executor
-    e = tfhe.Engine(tfhe.default_params(q_bits=49, log_N=12))
+    e = tfhe.Engine(tfhe.default_params(q_bits=qb, log_N=12))
     try:
         e.keygen(0x5EED)
         c = Circuit(msg_bits=6)

@@ -38,6 +38,8 @@ SETS = {
     "north_star_torus64 (N 1024, l 3, Bg 2^10, 24-bit limbs)": (10, 3, 10, 24),
     "secure128_torus   (N 2048, l 3, Bg 2^10, 23-bit limbs)": (11, 3, 10, 23),
     "N 2048 with 24-bit limbs (NOT used: bound fails)": (11, 3, 10, 24),
+    "N 4096 torus sets (l 3, Bg 2^10, 22-bit limbs)": (12, 3, 10, 22),
+    "N 4096 with 23-bit limbs (NOT used: bound fails)": (12, 3, 10, 23),
 }
 
 if __name__ == "__main__":

@@ -13,7 +13,8 @@ if os.environ.get('BMI_TFHE_LIB'):
 def main():
     preset = sys.argv[1] if len(sys.argv) > 1 else "secure128_torus"
     batches = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,256,2048").split(",")]
-    eng = tfhe.Engine(tfhe.preset_params(preset))
+    over = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("BMI_PARAMS", "").split(",") if kv)}   # e.g. BMI_PARAMS=ks_levels=16,ks_base_log=1
+    eng = tfhe.Engine(tfhe.preset_params(preset, **over))
     if os.environ.get('BMI_UNROLL') == '2':
         eng.set_bsk_unroll(2)
     eng.keygen(0x5EED)
