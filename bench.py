@@ -23,7 +23,7 @@ GPUs than were asked for.  Rank 0 prints ONE JSON line:
   `roofline.north_star` / `roofline.north_star_frac`;
 * `cpu_baseline`: the oracle's fast path (exact f64 arithmetic, OpenMP over the batch; bit-identical to the generic oracle and to
   the GPU, re-checked inside the run) on this box's host cores, on a bounded sample of the same ciphertexts (N=1, rank 0 only);
-* legs (N=1, rank 0; objects `secure128_torus`, `p49_field`, `torus64_unrolled_key`, `unrolled_key_49`; `--goldilocks-leg` adds the
+* legs (N=1, rank 0; objects `secure128_torus`, `secure128_torus_wide`, `p49_field`, `torus64_unrolled_key`, `unrolled_key_49`; `--goldilocks-leg` adds the
   Goldilocks kernels): PBS/s, kernel time, output noise against the CGGI formula, latency of 1 and 256, inverse wall-clocks.
 """
 import argparse
@@ -183,7 +183,7 @@ def compact(res):
     cb = res.get("cpu_baseline")
     if isinstance(cb, dict):
         r["cpu_baseline"] = {k: v for k, v in cb.items() if k not in ("host", "concrete")}
-    for k in ("secure128_torus", "torus64", "p49_field", "torus64_unrolled_key", "unrolled_key_49", "roofline_q64_goldilocks"):
+    for k in ("secure128_torus", "secure128_torus_wide", "torus64", "p49_field", "torus64_unrolled_key", "unrolled_key_49", "roofline_q64_goldilocks"):
         if k in r:
             r[k] = leg(r[k])
     r["details"] = "gpurun_out/bench_details.json (every leg in full)"
@@ -566,6 +566,7 @@ def main():
                 plain_key_bytes = Pe.n * 4 * Pe.bs_levels * Pe.N * 8
                 gbs = plain_key_bytes * B / (kms * 1e-3) / 1e9
                 kname = ("k_blind_rotate_w_t64f<3, 10, 46, false>" if (qb == 65 and Pe.N == 2048) else
+                         "k_blind_rotate_q_t64f<3, 10, 44, false>" if (qb == 65 and Pe.N == 4096) else
                          {49: "k_blind_rotate_lat2u_49<3, 15>", 65: ("k_blind_rotate_tp2u_t64f<3, 10, 42>" if B > 256 else "k_blind_rotate_lat2u_t64f<3, 10, 42, false>")}[qb] if unroll else KERNEL[qb])
                 one_wg_per_ct = unroll or Pe.N > 1024
                 sm, ss = ck.result()
@@ -625,6 +626,7 @@ def main():
                 ("torus64_unrolled_key", 65, True, True, None, None), ("unrolled_key_49", 49, True, True, None, None)]
         if not args.no_secure_leg:
             legs.insert(0, ("secure128_torus", 65, False, True, "secure128_torus", min(B, 2048)))
+            legs.insert(1, ("secure128_torus_wide", 65, False, False, "secure128_torus_wide", min(B, 1024)))
         if args.goldilocks_leg:
             legs.append(("roofline_q64_goldilocks", 64, False, False, None, None))
         for name, qb, un, inv, preset, bt in legs:
@@ -655,6 +657,13 @@ def main():
                 st["reference_readme_64core_cpu_run_s"] = {"2x2_len23_ints9": 85.0, "3x3_len23_ints9": "1349-1768",
                                                            "note": "README.md:129-141: concrete-python 2.1.0 at its 128-bit defaults, `low` "
                                                                    "precision (len 23, ints 9); the sizes here are BASELINE's (20, 8) / (30, 12) / (40, 16)"}
+        if "kernel_ms" in res.get("secure128_torus_wide", {}):
+            sw = res["secure128_torus_wide"]
+            sw["key"] = ("preset secure128_torus_wide: the same LWE pair under N 4096 on q = 2^64 (5-bit look-ups: the reference's unmodified "
+                         "circuits); (l, Bg) = (3, 2^10), key at 44 bits (two 22-bit limbs), folded 2,048-point f64 FFT split over eight "
+                         "wavefronts, keyswitch 16 x 1 bit on the matrix cores; measured here on 4-bit tables")
+            res["secure128_torus_wide_pbs_per_s"] = sw["pbs_per_s"]
+            res["secure128_torus_wide_latency_ms_256"] = sw.get("latency_ms_256")
         if "kernel_ms" in res.get("torus64", {}):
             res["value_torus64"] = res["torus64"]["pbs_per_s"]
             res["frac_torus64"] = res["torus64"]["frac"]

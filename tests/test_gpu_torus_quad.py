@@ -2,10 +2,15 @@
 bits of precision = two 22-bit limbs; csrc/bmi_kernels_t64q.hip, fft_eighth_f64.hpp).  The specification is the oracle's INTEGER
 arithmetic on the same (rounded, exported) key - the generic path of oracle/tfhe_oracle.c - : every output word must be identical
 for every batch shape, and the limb sums must sit far from the half-integers when they are rounded."""
+import gzip
+import json
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 SEED = 0x5EED
 QB = 65
@@ -177,3 +182,32 @@ def test_l2_shape_and_six_bit_tables_bit_exact():
     finally:
         e.close()
 
+
+
+def test_reference_five_bit_circuits_at_128_bit_security(eng):
+    """What this set is for: the reference's UNMODIFIED qfloat_matrix_inverse (tests/golden/ref_traced_inverse.json.gz: 2x2 as
+    written and lazily fused; 5-bit look-ups) and the 5-bit circuits of its own FHE test file (ref_own_fhe_tests.json.gz), on
+    Concrete's modulus under the 128-bit-secure LWE pair; the error budget of each is what EncryptedMatrixInversion(p_error=...)
+    would hold it to (reference: matrix_inversion/main.py:53-66, tests/test_qfloat_fhe.py:136-335)"""
+    from bmi_amd.circuit import Circuit
+    from bmi_amd.executor import Executor
+    from bmi_amd.program import Program
+    dl = eng.delta_log(5)
+    with gzip.open(os.path.join(G, "ref_traced_inverse.json.gz"), "rt") as f:
+        traced = json.load(f)["cases"]
+    for case in (traced[0], traced[2]):
+        c = Circuit.from_dict(case["circuit"])
+        assert c.msg_bits == 5
+        rep = Program.from_circuit(c).failure_probability(eng)
+        print(f"\n{case['name']}: {rep['lookups']} look-ups, worst margin {rep['worst_margin_sigma']:.2f} sigma, p_fail {rep['p_fail']:.1e}")
+        assert rep["p_fail"] < 1e-5 and 5.2 < rep["worst_margin_sigma"] < 5.5
+        ex = Executor(c, eng)
+        v = case["vectors"][0]
+        assert list(eng.decrypt(ex.run(eng.encrypt(v["inputs"], dl)), dl)) == v["expected"], case["name"]
+    with gzip.open(os.path.join(G, "ref_own_fhe_tests.json.gz"), "rt") as f:
+        own = [c for c in json.load(f)["cases"] if c["msg_bits"] == 5 and c["function"] != "div_qfloats"]
+    assert len(own) >= 2
+    for case in own:
+        ex = Executor(Circuit.from_dict(case["circuit"]), eng)
+        for r in case["runs"]:
+            assert list(eng.decrypt(ex.run(eng.encrypt(r["inputs"], dl)), dl)) == r["outputs"], case["function"]
