@@ -546,7 +546,7 @@ class Circuit:
     # ---- back ends.  Default: encrypt / run / decrypt work on LWE ciphertexts through the engine (bmi_amd.tfhe.Engine + executor:
     # every look-up a programmable bootstrap on the MI355X).  The parameter set is the first one of the chosen modulus whose error
     # budget for this circuit meets the configuration's global_p_error (4-bit look-ups: N = 1024, or N = 2048 where the look-up
-    # count needs the margin; 5 bits: N = 2048; 6 bits: N = 4096 on the 49-bit field).  BMI_COMPAT_BACKEND=simulate: plaintext.
+    # count needs the margin; 5 bits: N = 2048; 6 bits: N = 4096; with security_level=128 the secure128_torus sets, N = 4096 for 5 bits).  BMI_COMPAT_BACKEND=simulate: plaintext.
     def program(self):
         if getattr(self, "_prog", None) is None:
             from bmi_amd.program import Program
@@ -569,12 +569,7 @@ class Circuit:
         secure = self.configuration.security_level is not None
         if secure and int(self.configuration.security_level) != 128:
             raise ValueError("security_level: only 128 has a parameter set (secure128_torus / secure128)")
-        try:
-            return error_budget.choose_params(prog, self._p_error_target(), q_bits=qb, secure=secure)
-        except ValueError:
-            if qb != 49 and not secure:      # 6-bit look-ups exist on the 49-bit field only
-                return error_budget.choose_params(prog, self._p_error_target(), q_bits=49)
-            raise
+        return error_budget.choose_params(prog, self._p_error_target(), q_bits=qb, secure=secure)
 
     def _gpu(self):
         if getattr(self, "_ex", None) is None:

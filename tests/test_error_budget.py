@@ -59,6 +59,34 @@ def test_parameter_choice_follows_p_error():
         error_budget.choose_params(big, 1e-40, q_bits=tfhe.TORUS64, secure=True)
 
 
+def test_wider_look_ups_pick_the_wider_rings_on_the_torus():
+    """6-bit look-ups: N = 4096 on the library's default modulus (k_blind_rotate_q_t64f); 5-bit look-ups under security_level 128:
+    secure128_torus (N 2048, 4.4 sigma per look-up) while that meets the target, secure128_torus_wide (N 4096, keyswitch 16 x 1 bit:
+    5.3 sigma) beyond"""
+    from bmi_amd.circuit import Circuit
+    from bmi_amd.program import Program
+
+    def chain(bits, n):
+        c = Circuit(msg_bits=bits)
+        h = 1 << (bits - 1)
+        xs = [c.input(-h, h - 1) for _ in range(n)]
+        c.set_outputs([c.lut(x, lambda v: -v - 1) for x in xs])
+        return Program.from_circuit(c)
+
+    P, rep = error_budget.choose_params(chain(6, 8), 1e-5)
+    assert (P.N, P.q_bits, P.n) == (4096, tfhe.TORUS64, 630) and rep["p_fail"] < 1e-7 and 6.0 < rep["worst_margin_sigma"] < 6.5
+    P, _ = error_budget.choose_params(chain(6, 8), 1e-5, q_bits=49)
+    assert (P.N, P.q_bits) == (4096, 49)
+    five = chain(5, 60)
+    P, rep = error_budget.choose_params(five, 1e-2, q_bits=tfhe.TORUS64, secure=True)
+    assert rep["chosen"] == "secure128_torus" and 4.2 < rep["worst_margin_sigma"] < 4.6
+    P, rep = error_budget.choose_params(five, 1e-4, q_bits=tfhe.TORUS64, secure=True)
+    assert rep["chosen"] == "secure128_torus_wide" and (P.N, P.n, P.ks_levels, P.ks_base_log) == (4096, 742, 16, 1)
+    assert 5.2 < rep["worst_margin_sigma"] < 5.5 and rep["tried"][0][1] > 1e-4
+    with pytest.raises(ValueError):
+        error_budget.choose_params(chain(6, 8), 1e-5, secure=True)          # no 128-bit-secure set carries 6-bit look-ups
+
+
 def test_wrapper_reports_and_enforces_its_budget():
     """EncryptedMatrixInversion(p_error=...) picks the set when it creates the engine; with an engine passed in, the budget is
     checked against it (no GPU here: a stand-in with the engine's parameter fields)"""

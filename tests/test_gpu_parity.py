@@ -726,7 +726,7 @@ def test_wider_parameter_sets_bit_exact(log_N):
     finally:
         e.close()
     with pytest.raises(tfhe.BmiError):
-        tfhe.Engine(tfhe.default_params(q_bits=64, log_N=log_N))    # the wider rings exist on the 49-bit field only
+        tfhe.Engine(tfhe.default_params(q_bits=64, log_N=log_N))    # the wider rings exist on the 49-bit field and the 2^64 torus
 
 
 def test_pbs_known_answer_digests_on_gpu():
