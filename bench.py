@@ -15,6 +15,7 @@ process, one rank per GPU, before this process touches a GPU) and exits with the
 GPUs than were asked for.  Rank 0 prints ONE JSON line:
 
 * top level: the contract's fields, then the scalars to quote - inverse_{2x2,3x3,4x4}_s (headline engine, evaluate wall-clock),
+  inverse_3x3_batched_{s_per_matrix, pbs_per_s} (16 matrices in one walk of the levels: the serving form, evaluate_many),
   secure128_torus_{pbs_per_s, latency_ms_1, latency_ms_256, inverse_*_s} (the 128-bit-secure set on q = 2^64), value_p49 /
   value_torus64_unrolled / inverse_3x3_s_{torus64_unrolled, p49_unrolled} (the other engines);
 * `roofline`: the PHYSICAL bound of the dominant kernel (f64 vector issue: static instruction counts x live launch rate against
@@ -219,6 +220,7 @@ def main():
                     help="skip the extra legs (N=1, rank 0): the 128-bit-secure torus set, the 49-bit field, the unrolled keys")
     ap.add_argument("--goldilocks-leg", action="store_true",
                     help="also time the Goldilocks-field kernels (an independent implementation, 4x slower; never the product path)")
+    ap.add_argument("--inverse-batch", type=int, default=16, help="matrices per batched 3x3 evaluation (EncryptedMatrixInversion.evaluate_many)")
     ap.add_argument("--no-secure-leg", action="store_true", help="skip the secure128_torus leg (n 742, N 2048 on q = 2^64)")
     ap.add_argument("--inverse-sizes", default=None, help="matrix sizes of the encrypted-inverse legs: default 2,3,4 at N=1 (BASELINE "
                     "configs 2, 3, 4 on rank 0; 8 takes ~2 min more) and 8 for --inverse-sharded (config 5: the one whose levels are wide "
@@ -700,6 +702,13 @@ def main():
                 res[f"inverse_{k}_s"] = v["evaluate_s"]
         except Exception as e:  # reported, never hidden
             res["config"]["encrypted_inverse_wall_clock"] = {"error": repr(e)}
+        try:   # the serving form: 16 matrices through one walk of the 3x3 circuit's levels (throughput kernel instead of 319 latency rounds each)
+            bt = inverse_bench.run_batched(eng, 3, args.inverse_batch)
+            res["config"]["encrypted_inverse_batched"] = bt
+            res["inverse_3x3_batched_s_per_matrix"] = bt["per_matrix_s"]
+            res["inverse_3x3_batched_pbs_per_s"] = bt["pbs_per_s"]
+        except Exception as e:
+            res["config"]["encrypted_inverse_batched"] = {"error": repr(e)}
         if not args.no_readme_benchmark:
             try:   # the reference's own published benchmark configurations (README.md:129-142), beside its figures
                 res["config"]["reference_readme_benchmark"] = inverse_bench.run_readme_low(eng)

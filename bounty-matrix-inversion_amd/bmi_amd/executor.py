@@ -16,6 +16,11 @@ width): each rank forms and bootstraps ITS rows only, one all-gather (RCCL) on t
 everywhere, then every rank scatters the whole level into its store; this is the path's only exchange step.  Narrower
 levels are computed redundantly by every rank - cheaper than any transfer, since a level below ~256 ciphertexts
 costs one latency-kernel round whatever its width.
+
+Several INPUTS at once (`batch`): the same program evaluated on `batch` independent input vectors in one walk of the level list -
+every level is `batch` times wider (replica b of a node reads replica b's rows: the store is `batch` stacked copies of the
+one-input store), so the levels of one latency-kernel round become throughput-kernel launches: the serving form (a 3x3 inverse
+is 319 rounds of <= 256 look-ups alone, 69 k look-ups at the throughput kernel's rate in a batch).
 """
 from __future__ import annotations
 
@@ -79,13 +84,13 @@ def assign_rows(prog: Program, recycle=True):
 
 
 class Executor:
-    def __init__(self, circuit, engine, group=None, shard_threshold=None, recycle=True):
+    def __init__(self, circuit, engine, group=None, shard_threshold=None, recycle=True, batch=1):
         """circuit: a program.Program (or a circuit.Circuit, frozen here); group: a torch.distributed process group (None:
         the default group when initialised with more than one rank, otherwise single-GPU execution); shard_threshold:
         narrowest level that is split across the ranks - None (default) = every level wider than one latency-kernel
         round (257 ciphertexts), and the program's levels are then re-packed for `world` x 256 ciphertexts per round
         (Program.rescheduled): G GPUs working on one level are one machine with G x 256 workgroup slots; recycle: reuse
-        store rows after a leaf's last consumer."""
+        store rows after a leaf's last consumer; batch: number of independent input vectors one run() evaluates (module docstring)."""
         import torch
         self.torch = torch
         prog = Program.from_circuit(circuit) if isinstance(circuit, Circuit) else circuit
@@ -117,9 +122,13 @@ class Executor:
                 self.c = self.prog = prog
         self.shard_threshold = max(int(shard_threshold), 1)
         self.big = engine.P.big
+        self.batch = B = int(batch)
+        if B < 1:
+            raise ValueError("batch must be at least 1")
         n_in = prog.n_inputs
         order, counts = prog.level_order()
-        self.row_of, self.n_rows = assign_rows(prog, recycle)
+        self.row_of, self.n_rows1 = assign_rows(prog, recycle)
+        self.n_rows = self.n_rows1 * B
         self.delta_log = engine.delta_log(prog.msg_bits)
         q, dl = engine.modulus, self.delta_log
         # a lut_neg table (-+1) is registered at half the output scale: its ciphertexts carry (bit - 1/2) Delta, and every
@@ -130,17 +139,27 @@ class Executor:
         to_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.dev)  # noqa: E731
 
         # every level's rows in level order: one set of flat arrays for the whole program, sliced per level
+        consts = prog.half_unit_consts(prog.node_ptr, prog.term_leaf, prog.term_coef, prog.node_const)   # units of Delta / 2
+        shift = np.zeros(order.size, np.int64)      # store-row offset of a node's replica
+        if B > 1:
+            # replica b of every node right after replica b - 1 of its level: per level the node list tiled B times
+            lvl_start = np.concatenate([[0], np.cumsum(counts)])
+            tiled = [np.tile(order[lvl_start[t]: lvl_start[t + 1]], B) for t in range(len(counts))]
+            shift = np.concatenate([np.repeat(np.arange(B, dtype=np.int64) * self.n_rows1, int(counts[t])) for t in range(len(counts))]) \
+                if len(counts) else shift
+            order = np.concatenate(tiled) if tiled else order
+            counts = counts * B
         lens = np.diff(prog.node_ptr)[order]
         starts = prog.node_ptr[:-1][order]
         tot = int(lens.sum())
         off = np.arange(tot) - np.repeat(np.cumsum(lens) - lens, lens) + np.repeat(starts, lens)
-        self.d_idx = to_dev(self.row_of[prog.term_leaf[off]] if tot else [0], np.int32)
+        self.d_idx = to_dev(self.row_of[prog.term_leaf[off]] + np.repeat(shift, lens) if tot else [0], np.int32)
         self.d_coef = to_dev(prog.term_coef[off] if tot else [0], np.int64)
-        consts = prog.half_unit_consts(prog.node_ptr, prog.term_leaf, prog.term_coef, prog.node_const)[order]   # units of Delta / 2
+        consts = consts[order]
         uniq, inv = np.unique(consts, return_inverse=True)
         self.d_const = to_dev(_torus(uniq, dl - 1, q)[inv] if consts.size else [0], np.int64)
         self.d_ids = to_dev(lut_ids[prog.node_lut[order]] if order.size else [0], np.int32)
-        self.d_rows = to_dev(self.row_of[n_in + order] if order.size else [0], np.int32)
+        self.d_rows = to_dev(self.row_of[n_in + order] + shift if order.size else [0], np.int32)
         # row_ptr of all nodes in level order, absolute term offsets: a level (or a rank's part of it) is a slice
         self.d_rp = to_dev(np.concatenate([[0], np.cumsum(lens)]), np.int32)
         self.levels = []          # (width, position of the level's first node, padded width)
@@ -149,10 +168,14 @@ class Executor:
             padded = -(-w // self.world) * self.world if (self.world > 1 and w >= self.shard_threshold) else w
             self.levels.append((w, pos, padded))
             pos += w
-        self.out_csr = (to_dev(prog.out_ptr, np.int32), to_dev(self.row_of[prog.out_leaf] if prog.out_leaf.size else [0], np.int32),
-                        to_dev(prog.out_coef if prog.out_coef.size else [0], np.int64),
-                        to_dev(_torus(prog.half_unit_consts(prog.out_ptr, prog.out_leaf, prog.out_coef, prog.out_const), dl - 1, q), np.int64))
-        self.n_out = prog.n_outputs
+        o_len = np.diff(prog.out_ptr)
+        o_rows = self.row_of[prog.out_leaf] if prog.out_leaf.size else np.zeros(0, np.int64)
+        o_const = _torus(prog.half_unit_consts(prog.out_ptr, prog.out_leaf, prog.out_coef, prog.out_const), dl - 1, q)
+        self.out_csr = (to_dev(np.concatenate([[0], np.cumsum(np.tile(o_len, B))]), np.int32),
+                        to_dev(np.concatenate([o_rows + b * self.n_rows1 for b in range(B)]) if o_rows.size else [0], np.int32),
+                        to_dev(np.tile(prog.out_coef, B) if prog.out_coef.size else [0], np.int64),
+                        to_dev(np.tile(o_const, B), np.int64))
+        self.n_out = prog.n_outputs * B
         self.max_width = max((p for *_, p in self.levels), default=1)
         self.sharded_levels = sum(1 for w, *_ in self.levels if self.world > 1 and w >= self.shard_threshold)
         self.store = torch.zeros((max(self.n_rows, 1), self.big), dtype=torch.int64, device=self.dev)
@@ -165,14 +188,15 @@ class Executor:
         return int(self.store.numel() + self.tmp.numel() + self.lvl.numel()) * 8
 
     def run(self, ct_inputs):
-        """ct_inputs: (n_inputs, k*N+1) uint64 ciphertexts (host) -> (n_outputs, k*N+1) uint64 (host)"""
+        """ct_inputs: (n_inputs, k*N+1) uint64 ciphertexts (host) -> (n_outputs, k*N+1) uint64 (host); with batch > 1:
+        (batch, n_inputs, k*N+1) -> (batch, n_outputs, k*N+1)"""
         torch = self.torch
         n_in = self.prog.n_inputs
-        ct = np.ascontiguousarray(ct_inputs, dtype=np.uint64).reshape(n_in, self.big)
+        ct = np.ascontiguousarray(ct_inputs, dtype=np.uint64).reshape(self.batch, n_in, self.big)
         import contextlib
         with (torch.cuda.device(self.dev) if self.on_gpu else contextlib.nullcontext()):
             stream = torch.cuda.current_stream().cuda_stream if self.on_gpu else 0
-            self.store[:n_in].copy_(torch.from_numpy(ct.view(np.int64)), non_blocking=False)
+            self.store.view(self.batch, -1, self.big)[:, :n_in].copy_(torch.from_numpy(ct.view(np.int64)), non_blocking=False)
             eng, tmp, lvl = self.eng, self.tmp, self.lvl
             for width, pos, padded in self.levels:
                 lo, hi = 0, width
@@ -195,7 +219,8 @@ class Executor:
             eng.lincomb(self.store, rp, ix, cf, cs, self.n_out, self.out, stream)
             if self.on_gpu:
                 torch.cuda.synchronize(self.dev)
-            return self.out[: self.n_out].cpu().numpy().view(np.uint64)
+            res = self.out[: self.n_out].cpu().numpy().view(np.uint64)
+            return res if self.batch == 1 else res.reshape(self.batch, -1, self.big)
 
     def _all_gather_rows(self, region, per):
         """in-place all-gather of a level buffer: rank r contributed rows [r*per, (r+1)*per) (rows of the last rank past

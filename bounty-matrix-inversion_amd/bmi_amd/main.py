@@ -210,11 +210,14 @@ class EncryptedMatrixInversion:
         else:
             eng.keygen(seed)
 
-    def _executor(self):
+    def _executor(self, batch=1):
+        """the executor of this circuit for `batch` input matrices per run (one per batch size, built on first use)"""
         if self._exec is None:
+            self._exec = {}
+        if batch not in self._exec:
             from .executor import Executor
-            self._exec = Executor(self.circuit, self._engine(), shard_threshold=self.shard_threshold)
-        return self._exec
+            self._exec[batch] = Executor(self.circuit, self._engine(), shard_threshold=self.shard_threshold, batch=batch)
+        return self._exec[batch]
 
     # ---- the reference's six methods -----------------------------------------------------------------
     def quantize(self, matrix: np.ndarray):
@@ -240,6 +243,30 @@ class EncryptedMatrixInversion:
 
     def evaluate(self, encrypted_quantized_matrix: np.ndarray) -> np.ndarray:
         return self._executor().run(encrypted_quantized_matrix)
+
+    def evaluate_many(self, encrypted_quantized_matrices) -> np.ndarray:
+        """B encrypted matrices (a sequence of encrypt() results, or one (B, inputs, words) array) through the circuit in ONE walk of
+        its levels: every level is B times wider, so the look-ups run on the throughput kernel instead of B x depth rounds of the
+        latency kernel (executor.py, `batch`) - the serving form.  Returns (B, outputs, words); decrypt() each."""
+        enc = np.ascontiguousarray(np.stack([np.asarray(e) for e in encrypted_quantized_matrices]), dtype=np.uint64)
+        if enc.ndim != 3:
+            raise ValueError("expected B encrypted matrices of shape (inputs, words)")
+        return self._executor(enc.shape[0]).run(enc)
+
+    def run_many(self, matrices, validate=True):
+        """run() for a batch of matrices on one GPU: quantize, encrypt, ONE batched encrypted evaluation (evaluate_many), decrypt,
+        dequantize - the same inverses as run() matrix by matrix"""
+        if self._dist() is not None:
+            raise NotImplementedError("run_many is the one-GPU serving form; under torch.distributed call run() per matrix")
+        qs = []
+        for m in matrices:
+            assert np.issubdtype(m.dtype, np.floating) and m.shape == self.shape
+            q = self.quantize(m)
+            if validate:
+                self.simulate(*q)
+            qs.append(q)
+        res = self.evaluate_many([self.encrypt(q, s_) for q, s_ in qs])
+        return [self.dequantize(self.decrypt(r)) for r in res]
 
     def decrypt(self, encrypted_quantized_inverted_matrix: np.ndarray) -> np.ndarray:
         n2 = self.shape[0] * self.shape[1]

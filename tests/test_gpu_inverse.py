@@ -635,3 +635,27 @@ def test_concrete_compatible_front_end_runs_on_the_gpu(monkeypatch):
         for e in _f._ENGINES.values():
             e.close()
         _f._ENGINES.clear()
+
+
+def test_batched_inverses_on_the_gpu(eng):
+    """EncryptedMatrixInversion.evaluate_many / run_many: five encrypted 2x2 matrices through ONE walk of the levels (every level five
+    times wider: the wide ones reach the throughput kernel) decrypt to the same digits as one by one, == the plaintext circuit;
+    a batch of one is the plain executor"""
+    from bmi_amd.main import EncryptedMatrixInversion
+    emi = EncryptedMatrixInversion(2, None, 2, 20, 8, False, False, engine=eng)
+    rng = np.random.default_rng(77)
+    Ms = [rng.standard_normal((2, 2)) * 50 for _ in range(5)]
+    qs = [emi.quantize(M) for M in Ms]
+    encs = [emi.encrypt(q, s) for q, s in qs]
+    res = emi.evaluate_many(encs)
+    assert res.shape == (5, 4 * 21, eng.P.big)
+    ex = emi._executor(5)
+    assert max(w for w, *_ in ex.levels) == 5 * max(w for w, *_ in emi._executor().levels) > 512
+    for r, enc, (q, s) in zip(res, encs, qs):
+        want = emi.simulate(q, s)
+        assert np.array_equal(emi.decrypt(r), want)
+    assert np.array_equal(emi.decrypt(emi.evaluate(encs[3])), emi.simulate(*qs[3]))
+    assert np.array_equal(emi.decrypt(emi.evaluate_many([encs[1]])[0]), emi.simulate(*qs[1]))
+    invs = emi.run_many(Ms[:2])
+    for M, inv in zip(Ms, invs):
+        assert np.array_equal(inv, emi.dequantize(emi.simulate(*emi.quantize(M))))

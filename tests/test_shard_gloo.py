@@ -313,3 +313,38 @@ def test_one_call_run_on_two_ranks(tmp_path):
     mp.spawn(_run_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f"inv{r}.npy"), want), r
+
+
+def test_batched_executor_and_run_many_match_the_single_runs():
+    """Executor(batch=B): B input vectors through one walk of the levels (every level B times wider, replica b on its own copy
+    of the store) == B single runs; EncryptedMatrixInversion.run_many == run() matrix by matrix.  (Stand-in engine on plaintext
+    rows; the GPU twin is tests/test_gpu_inverse.py::test_batched_inverses_on_the_gpu.)"""
+    from bmi_amd.executor import Executor
+    from bmi_amd.main import EncryptedMatrixInversion, compile_inverse
+    prog, _ = compile_inverse(2, 20, 8)
+    from bmi_amd.qfloat_matrix_inversion import float_matrix_to_qfloat_arrays
+    rng = np.random.default_rng(11)
+    B = 3
+    inputs = []
+    for _ in range(B):
+        q, s = float_matrix_to_qfloat_arrays(rng.normal(0, 10, (2, 2)), 20, 8, 2)
+        inputs.append(np.concatenate([np.asarray(q, np.int64).reshape(-1), np.asarray(s, np.int64)]))
+    cts = np.zeros((B, prog.n_inputs, 3), np.uint64)
+    for b in range(B):
+        cts[b, :, -1] = (2 * inputs[b]).view(np.uint64)
+    ex = Executor(prog, _VecEngine(), batch=B)
+    one = Executor(prog, _VecEngine())
+    assert [w for w, *_ in ex.levels] == [B * w for w, *_ in one.levels] and ex.n_rows == B * one.n_rows
+    out = ex.run(cts)
+    assert out.shape == (B, prog.n_outputs, 3)
+    for b in range(B):
+        want = np.array(prog.simulate(inputs[b]))
+        assert np.array_equal(out[b, :, -1].view(np.int64) // 2, want), b
+        assert np.array_equal(one.run(cts[b])[:, -1].view(np.int64) // 2, want), b
+    assert not np.array_equal(out[0], out[1])
+    emi = EncryptedMatrixInversion(2, None, 2, 20, 8, False, False, engine=_VecEngine())
+    emi.error_budget = {}
+    Ms = [rng.normal(0, 10, (2, 2)) for _ in range(4)]
+    many = emi.run_many(Ms)
+    for M, inv in zip(Ms, many):
+        assert np.array_equal(inv, emi.run(M)) and np.allclose(inv @ M, np.eye(2), atol=0.1)
