@@ -251,7 +251,7 @@ class EncryptedMatrixInversion:
         enc = np.ascontiguousarray(np.stack([np.asarray(e) for e in encrypted_quantized_matrices]), dtype=np.uint64)
         if enc.ndim != 3:
             raise ValueError("expected B encrypted matrices of shape (inputs, words)")
-        return self._executor(enc.shape[0]).run(enc)
+        return self._executor(enc.shape[0]).run(enc).reshape(enc.shape[0], -1, enc.shape[2])
 
     def run_many(self, matrices, validate=True):
         """run() for a batch of matrices on one GPU: quantize, encrypt, ONE batched encrypted evaluation (evaluate_many), decrypt,
