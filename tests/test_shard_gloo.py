@@ -348,3 +348,38 @@ def test_batched_executor_and_run_many_match_the_single_runs():
     many = emi.run_many(Ms)
     for M, inv in zip(Ms, many):
         assert np.array_equal(inv, emi.run(M)) and np.allclose(inv @ M, np.eye(2), atol=0.1)
+
+
+def _batched_exec_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bmi_amd.executor import Executor
+    circ = _trace_small()
+    ex = Executor(circ, _PlainEngine(), shard_threshold=16, batch=3)
+    inputs = np.load(os.path.join(out_dir, "inputs3.npy"))
+    cts = np.zeros((3, circ.n_inputs, 3), np.uint64)
+    cts[:, :, -1] = (2 * inputs.astype(np.int64)).view(np.uint64)
+    out = ex.run(cts)
+    np.save(os.path.join(out_dir, f"out3_{rank}.npy"), out[:, :, -1].view(np.int64) // 2)
+    np.save(os.path.join(out_dir, f"sharded3_{rank}.npy"), np.array([ex.sharded_levels, len(ex.levels)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batched_executor_on_two_ranks(tmp_path):
+    """batch and sharding together: three input vectors per walk, the (three times wider) levels split across two gloo ranks"""
+    circ = _trace_small()
+    rng = np.random.default_rng(9)
+    inputs = np.array([[rng.integers(lo, hi + 1) for lo, hi in zip(circ.leaf_lo[:circ.n_inputs], circ.leaf_hi[:circ.n_inputs])] for _ in range(3)])
+    np.save(tmp_path / "inputs3.npy", inputs)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_batched_exec_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = np.load(tmp_path / f"out3_{r}.npy")
+        for b in range(3):
+            assert np.array_equal(got[b], np.array(circ.simulate(list(inputs[b])))), (r, b)
+    sharded, total = np.load(tmp_path / "sharded3_0.npy")
+    assert 0 < sharded <= total
