@@ -1,4 +1,4 @@
-// 2^64 TORUS at N = 4096 (6-bit look-ups; 5-bit look-ups at 128-bit-secure noise: preset secure128_torus_5bit): blind rotation with
+// 2^64 TORUS at N = 4096 (6-bit look-ups; 5-bit look-ups at 128-bit-secure noise: preset secure128_torus_wide): blind rotation with
 // the exact limb products carried by the floating-point transform of fft_eighth_f64.hpp (gfx950).
 //
 // Same scheme as bmi_kernels_t64w.hip one size up: bootstrap key stored at 44 bits of precision (words rounded to multiples of 2^20;
