@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Many random matrices through the encrypted inverse on the GPU, each compared with the plaintext evaluation of the same
 compiled program (identical integers expected) and with numpy's inverse: an empirical look at the look-up failure rate
-(every 4-bit look-up sits at >= 5.6 sigma).  usage: gpu_random_inverses.py [n] [count] [q_bits] [unroll]
+(every 4-bit look-up sits at >= 5.6 sigma).  usage: gpu_random_inverses.py [n] [count] [q_bits] [unroll] [base]
 (unroll = 2: the unrolled bootstrap key - at key noise 2^-41 on the 49-bit field; on the torus the 42-bit key through the FFT -, what
 EncryptedMatrixInversion(unroll=True) runs; q_bits may also be a preset name, e.g. secure128_torus).  Prints the error budget of the
 circuit under the engine's parameters beside the observed mismatches."""
@@ -20,17 +20,20 @@ def main():
     qb = int(qb) if preset is None else None
     ln, ints = {2: (20, 8), 3: (30, 12), 4: (40, 16)}[n]
     unroll = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    base = int(sys.argv[5]) if len(sys.argv) > 5 else 2          # 3: the base-3 configuration of tests/golden/inverse.json (5-bit look-ups)
+    if base != 2:
+        ln, ints = 14, 6
     eng = tfhe.Engine(tfhe.preset_params(preset) if preset else
                       tfhe.default_params(q_bits=qb, **({"glwe_noise": 2.0 ** -41} if (unroll == 2 and qb == 49) else {})))
     eng.set_bsk_unroll(unroll)
     eng.keygen()          # CSPRNG keys
-    emi = EncryptedMatrixInversion(n, None, 2, ln, ints, False, False, engine=eng, unroll=(unroll == 2))
+    emi = EncryptedMatrixInversion(n, None, base, ln, ints, False, False, engine=eng, unroll=(unroll == 2))
     rng = np.random.default_rng(4242 + n)
     wrong = skipped = 0; pbs = emi.program.n_nodes; worst = 0.0; t0 = time.time()
     for i in range(count):
-        M = rng.normal(0, 100, (n, n))
+        M = rng.normal(0, 100, (n, n)) if base == 2 else rng.uniform(-100, 100, (n, n))
         q, s = emi.quantize(M)
-        if q[:, 0].max() > 3:            # entry beyond the traced leading-digit range (|x| >= 2^(ints+2)): not an input of this circuit
+        if q[:, 0].max() > 2 * base - 1:            # entry beyond the traced leading-digit range (|x| >= 2^(ints+2)): not an input of this circuit
             skipped += 1; continue
         want = emi.simulate(q, s)
         got = emi.decrypt(emi.evaluate(emi.encrypt(q, s)))
@@ -44,7 +47,7 @@ def main():
     print(json.dumps({"n": n, "q_bits": eng.q_bits, "preset": preset, "N": eng.P.N, "lwe_n": eng.P.n, "bsk_precision": eng.bsk_precision,
                       "p_fail_per_inverse_budget": budget["p_fail"], "expected_mismatches": budget["p_fail"] * done, "matrices": done, "mismatching_the_plaintext_circuit": wrong, "lookups_total": done * pbs,
                       "lookups_per_inverse": pbs, "worst_abs_err_vs_numpy_among_matching": worst, "seconds": round(time.time() - t0, 1),
-                      "keys": "CSPRNG", "unroll": unroll}))
+                      "keys": "CSPRNG", "unroll": unroll, "base": base, "len": ln, "ints": ints, "depth": emi.program.depth}))
     eng.close()
     return 1 if wrong else 0
 
