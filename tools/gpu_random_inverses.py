@@ -39,6 +39,8 @@ def main():
         got = emi.decrypt(emi.evaluate(emi.encrypt(q, s)))
         if not np.array_equal(got, want):
             wrong += 1
+        if (i + 1) % 5 == 0:     # a silent run is taken to be hung by gpurun
+            print(f"# {i + 1} / {count} matrices, {wrong} mismatching, {time.time() - t0:.0f} s", flush=True)
         else:
             err = np.max(np.abs(emi.dequantize(got) - np.linalg.inv(M)))
             if np.isfinite(err): worst = max(worst, float(err))
