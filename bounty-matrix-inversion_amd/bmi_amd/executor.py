@@ -121,6 +121,13 @@ class Executor:
                 prog = prog.rescheduled(Program_ROUND * self.world, Program_WIDE_ROUND * self.world)
                 self.c = self.prog = prog
         self.shard_threshold = max(int(shard_threshold), 1)
+        if int(batch) > 1:
+            # `batch` replicas of every level run side by side: a level is cheapest when replicas x width fills whole rounds of the
+            # throughput kernel (1,024 ciphertexts per round and GPU), so the program's levels are re-packed for that width per
+            # replica (same depth; 3x3 at 8 matrices per walk: 7 % fewer rounds, 2x2: 17 %)
+            per = max(Program_WIDE_ROUND * self.world // int(batch), 1)
+            prog = prog.rescheduled(per, per)
+            self.c = self.prog = prog
         self.big = engine.P.big
         self.batch = B = int(batch)
         if B < 1:
