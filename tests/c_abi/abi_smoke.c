@@ -84,6 +84,9 @@ int main(void) {
     /* named presets; the 2^64 torus (Concrete's modulus) end to end; the compiler passes (context-free, CPU) */
     bmi_params S;
     CHECK(bmi_preset_params("secure128", &S) == 0 && S.n == 742 && S.log_N == 11, "secure128 preset");
+    CHECK(bmi_preset_params("secure128_torus", &S) == 0 && S.n == 742 && S.log_N == 11 && S.q_bits == BMI_Q_TORUS64, "secure128_torus preset");
+    CHECK(bmi_preset_params("secure128_torus_wide", &S) == 0 && S.n == 742 && S.log_N == 12 && S.ks_levels == 16 && S.ks_base_log == 1,
+          "secure128_torus_wide preset");
     CHECK(bmi_preset_params("no such set", &S) < 0, "unknown preset rejected");
     CHECK(bmi_preset_params("north_star_torus64", &S) == 0 && S.q_bits == BMI_Q_TORUS64, "torus preset");
     CHECK(bmi_ctx_create(&S, 0, &ctx) == 0, "torus context");
