@@ -35,6 +35,9 @@ using ffte::static_for;
 using t64::f64_to_word;
 using t64::Scheme;
 
+#ifndef BMI_T64Q_BOTH_ROWS
+#define BMI_T64Q_BOTH_ROWS 0   // 1: both rows' key words of a level requested before the level's barrier (A/B)
+#endif
 constexpr int QN = 4096, QLOG = 12;
 constexpr int QS = ffte::EIGHTH;                 // slots per eighth
 constexpr int QF_THREADS = 1024;
@@ -183,6 +186,10 @@ __global__ void __launch_bounds__(QF_THREADS)
             // this thread's key words of the level's first row (component 0): they land under the barrier
             double2 kw[8];
             static_for<0, 8>([&](auto T) { kw[T] = row_ptr(0 * L + lev)[T * QS]; });
+#if BMI_T64Q_BOTH_ROWS
+            double2 kw1[8];
+            static_for<0, 8>([&](auto T) { kw1[T] = row_ptr(1 * L + lev)[T * QS]; });
+#endif
             pin();
             __syncthreads();
             static_for<0, 2>([&](auto CC) {   // rows (component CC, this level)
@@ -193,15 +200,22 @@ __global__ void __launch_bounds__(QF_THREADS)
                 });
                 fftw::dft8<false>(q);   // frequency kappa + 256 t in q[t]
                 static_for<0, 8>([&](auto T) {
-                    y[T].r = __builtin_fma(q[T].r, kw[T].x, __builtin_fma(-q[T].i, kw[T].y, y[T].r));
-                    y[T].i = __builtin_fma(q[T].r, kw[T].y, __builtin_fma(q[T].i, kw[T].x, y[T].i));
+#if BMI_T64Q_BOTH_ROWS
+                    const double2 k = CC == 0 ? kw[T] : kw1[T];
+#else
+                    const double2 k = kw[T];
+#endif
+                    y[T].r = __builtin_fma(q[T].r, k.x, __builtin_fma(-q[T].i, k.y, y[T].r));
+                    y[T].i = __builtin_fma(q[T].r, k.y, __builtin_fma(q[T].i, k.x, y[T].i));
                 });
                 // the sums are materialised HERE: the branches of the next task (times_w) would otherwise let the compiler sink these
                 // multiply-adds below them, keeping every level's tile and key words alive (scratch)
                 keep(y);
+#if !BMI_T64Q_BOTH_ROWS
                 if constexpr (CC == 0) {
                     static_for<0, 8>([&](auto T) { kw[T] = row_ptr(1 * L + lev)[T * QS]; });
                 }
+#endif
                 pin();
             });
             __syncthreads();   // every thread has read this level's tiles: the next level (or the sums) may overwrite them
