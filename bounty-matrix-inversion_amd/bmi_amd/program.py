@@ -47,8 +47,9 @@ def _tracer_fingerprint():
     """hash of the modules that define what a trace looks like: a cached program is only valid for the code that made it"""
     here = os.path.dirname(os.path.abspath(__file__))
     h = hashlib.sha256()
-    # main.py too: it declares the inputs (order, intervals), picks the message width and the division radix of a configuration
-    for name in ("circuit.py", "base_p_arrays.py", "qfloat.py", "qfloat_matrix_inversion.py", "program.py", "main.py"):
+    # inverse_circuit.py too: it declares the inputs (order, intervals), picks the message width and the division radix of a
+    # configuration (the API wrapper, main.py, is NOT part of it)
+    for name in ("circuit.py", "base_p_arrays.py", "qfloat.py", "qfloat_matrix_inversion.py", "program.py", "inverse_circuit.py"):
         with open(os.path.join(here, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """(Re)writes bounty-matrix-inversion_amd/bmi_amd/programs/: the compiled programs of the BASELINE configurations whose trace takes
 minutes (8 x 8 config 5; the 10 x 10 of the reference's own driver), in the compact form of Program.save_compact.  Their file names
-carry the tracer fingerprint, so they must be regenerated after ANY change to the tracer's sources (tests/test_host_qfloat.py
-checks that they are current); stale ones are removed here."""
+carry the tracer fingerprint, so they must be regenerated after ANY change to the tracer's sources - circuit.py, base_p_arrays.py,
+qfloat.py, qfloat_matrix_inversion.py, program.py, inverse_circuit.py (NOT the API wrapper main.py) - (tests/test_host_qfloat.py checks
+that they are current); stale ones are removed here."""
 import glob, os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "bounty-matrix-inversion_amd"))
