@@ -51,8 +51,14 @@ using t64::Scheme;
 #ifndef BMI_T64F_CTS
 #define BMI_T64F_CTS 4      // ciphertexts (wavefront pairs) per workgroup: 4 fill the CU's LDS; 3 and 2 measured slower per ciphertext
 #endif
+#ifndef BMI_T64F_LDSKEY
+#define BMI_T64F_LDSKEY 0   // TIMING-ONLY A/B (wrong results on purpose; EXPERIMENTS A15): key rows staged once per workgroup in an LDS ring
+                            // by LDS-DMA (each wavefront of a column group requests a third of a row) and read back from LDS, with NO
+                            // hand-off between the wavefronts - the lower bound of what any correct staging scheme costs.  Needs BMI_T64F_CTS=3.
+#endif
 constexpr int TF_CTS = BMI_T64F_CTS;
-constexpr int TF_LDS_WORDS = TW_WORDS + 2 * TF_CTS * (SCRATCH_WORDS + N) + TF_CTS * BMI_AT_WORDS + 4 * TF_CTS;
+constexpr int TF_RING_WORDS = BMI_T64F_LDSKEY ? 2 * 2 * N + 128 : 0;   // [column group 2][slot 2][512 complex] + 1 KiB of slack
+constexpr int TF_LDS_WORDS = TW_WORDS + 2 * TF_CTS * (SCRATCH_WORDS + N) + TF_CTS * BMI_AT_WORDS + 4 * TF_CTS + TF_RING_WORDS;
 static_assert(TF_LDS_WORDS <= BMI_LDS_WORDS_MAX, "TF_LDS_WORDS exceeds the 160 KB of LDS");
 static_assert(SCRATCH_WORDS >= N, "a tile carries 512 complex partial sums to the partner");
 
@@ -93,6 +99,9 @@ __global__ void __launch_bounds__(128 * TF_CTS)
     double *accs = tiles + 2 * CTS * SCRATCH_WORDS;          // accumulators: exact integers word / 2^PRE, centred mod 2^AB
     double *at_base = accs + 2 * CTS * N;
     uint32_t *flags = reinterpret_cast<uint32_t *>(at_base + CTS * BMI_AT_WORDS);  // [2 CTS] published, [2 CTS] consumed
+#if BMI_T64F_LDSKEY
+    double2 *ring = reinterpret_cast<double2 *>(at_base + CTS * BMI_AT_WORDS + 4 * CTS);
+#endif
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ctl = wave >> 1, c = wave & 1;
     if (threadIdx.x < 4 * CTS) flags[threadIdx.x] = 0;
@@ -165,6 +174,24 @@ __global__ void __launch_bounds__(128 * TF_CTS)
             return reinterpret_cast<const double2 *>(bsk_c + ((size_t)(lev * 2 + col) * LIMBS + j) * N);
         };
         double2 kb[2][8];
+#if BMI_T64F_LDSKEY
+        // a row: this wavefront's share of the LDS-DMA requests (slices ctl, ctl + 3, ctl + 6 of the eight 1-KiB slices), then the whole
+        // row read back from the ring slot (no hand-off: timing only)
+        auto fetch = [&](double2 (&dst)[8], int t) {
+            double2 *slot = ring + ((size_t)c * 2 + (t & 1)) * (N / 2);
+            // this wavefront's three consecutive 1-KiB slices, starting at slice 0 / 3 / 5 (slice 5 is requested twice: every request stays
+            // inside the row); the instruction offset moves the global and the LDS address alike
+            const int first = ctl * 3 - (ctl >> 1);
+            const double2 *g = row_ptr(t) + first * 64 + lane;
+            double2 *l = slot + first * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 1024, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 2048, 0);
+            static_for<0, 8>([&](auto P) { dst[P] = slot[P * 64 + lane]; });
+        };
+#else
+        auto fetch = [&](double2 (&dst)[8], int t) { static_for<0, 8>([&](auto P) { dst[P] = row_ptr(t)[P * 64 + lane]; }); };
+#endif
         static_for<0, L>([&](auto LEV) {
             constexpr int lev = L - 1 - LEV;  // least significant digit first
             pin();
@@ -181,7 +208,7 @@ __global__ void __launch_bounds__(128 * TF_CTS)
                 }
             });
             if constexpr (lev == 0) {
-                static_for<0, 8>([&](auto P) { kb[0][P] = row_ptr(0)[P * 64 + lane]; });
+                fetch(kb[0], 0);
                 pin();
             }
             forward(X[lev], lane, lds, tile);
@@ -195,8 +222,7 @@ __global__ void __launch_bounds__(128 * TF_CTS)
             constexpr int t = T, j = t / (2 * L), q = t % (2 * L), lev = q % L, cur = t & 1;
             if constexpr (q == 0) hand++;
             // (the first row of the next limb is requested after the inverse transform, which needs the registers)
-            if constexpr (t + 1 < LIMBS * 2 * L && q != 2 * L - 1)
-                static_for<0, 8>([&](auto P) { kb[cur ^ 1][P] = row_ptr(t + 1)[P * 64 + lane]; });
+            if constexpr (t + 1 < LIMBS * 2 * L && q != 2 * L - 1) fetch(kb[cur ^ 1], t + 1);
             sched_fence();
             static_for<0, 8>([&](auto P) {
                 const double xr = X[lev][P], xi = X[lev][P + 8];
@@ -232,7 +258,7 @@ __global__ void __launch_bounds__(128 * TF_CTS)
                 inverse(acc, lane, lds, tile);
                 PH_MARK(6);   // inverse transform
                 if constexpr (t + 1 < LIMBS * 2 * L) {
-                    static_for<0, 8>([&](auto P) { kb[cur ^ 1][P] = row_ptr(t + 1)[P * 64 + lane]; });
+                    fetch(kb[cur ^ 1], t + 1);
                     pin();
                 }
                 // the limb's exact integer result (|.| < 2^45: nearest integer of the transform's output), shifted into place
