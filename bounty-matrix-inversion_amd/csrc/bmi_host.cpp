@@ -204,6 +204,7 @@ struct bmi_ctx {
     double *d_zeta_pow = nullptr;                               // 2^64 torus at N = 1024: zeta^x, x in [0, 1024) as (re, im) - the factors X^c of the unrolled floating-point-transform kernel
     double *d_tw_fq = nullptr, *d_bsk_w = nullptr;              // 2^64 torus at N = 2048, key at 46 bits: tables and key copy of bmi_kernels_t64w.hip (quarter transforms, fft_quarter_f64.hpp);
                                                                 // at N = 4096, key at 44 bits: those of bmi_kernels_t64q.hip (eighth transforms, fft_eighth_f64.hpp)
+    double *d_bsk_w2 = nullptr;                                 // N = 2048: the key copy of the two-ciphertexts-per-workgroup kernel (bmi_kernels_t64w2.hip: [t 4][256 slots] per polynomial and limb)
     double *d_tw_wide = nullptr;                                // N = 2048: T / T^-1 of the even/odd combination (d_bsk_lat then holds the wide key copy)
     // bootstrap-key unrolling (49-bit field at N = 1024 / 2048, 2^64 torus; bmi_set_bsk_unroll): per pair of LWE coefficients the GGSW encryptions of
     // s s', s (1 - s'), (1 - s) s'; host copy in the standard domain, device copy in the slot order of the latency kernel
@@ -566,7 +567,7 @@ void bmi_ctx_destroy(bmi_ctx *c) {
                     (void *)c->d_ks_limbs, (void *)c->d_ks_digits, (void *)c->d_ks_sums, (void *)c->d_tw_half,
                     (void *)c->d_bsk_lat, (void *)c->d_tw_wide, (void *)c->d_bsk3_lat, (void *)c->d_root_pow,
                     (void *)c->d_tw_fft, (void *)c->d_bsk_fft, (void *)c->d_tw_fh, (void *)c->d_bsk_latf, (void *)c->d_tw_fq,
-                    (void *)c->d_bsk_w, (void *)c->d_zeta_pow})
+                    (void *)c->d_bsk_w, (void *)c->d_bsk_w2, (void *)c->d_zeta_pow})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -835,6 +836,14 @@ int upload_eval_keys(bmi_ctx *c) {
             return fail(c, -2, "hipMalloc(torus N = 2048 / 4096 key) failed");
         }
         rc = (c->quad() ? bmit::launch_bsk_to_quad : bmit::launch_bsk_to_wide)(d_tmp, c->d_bsk_w, c->d_tw_fq, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
+        if (!rc && c->wide()) {   // ... and at N = 2048 the copy of the throughput form (two ciphertexts per workgroup: batches beyond 256)
+            if (c->d_bsk_w2) { (void)hipFree(c->d_bsk_w2); c->d_bsk_w2 = nullptr; }
+            if (hipMalloc(&c->d_bsk_w2, bsk_words * 8 * c->bsk_limbs()) != hipSuccess) {
+                (void)hipFree(d_tmp);
+                return fail(c, -2, "hipMalloc(torus N = 2048 throughput-form key) failed");
+            }
+            rc = bmit::launch_bsk_to_wide2(d_tmp, c->d_bsk_w2, c->d_tw_fq, (uint32_t)(bsk_words / N), c->bsk_prec, c->stream);
+        }
         if (rc) { (void)hipFree(d_tmp); return fail(c, -2, "bsk_to_wide (torus) launch failed"); }
     } else if (c->t64()) {  // 2^64 torus at N = 1024: bsk_limbs transform-domain limb polynomials per key polynomial
         for (void **p : {&c->d_bsk, (void **)&c->d_bsk_lat, (void **)&c->d_bsk_fft, (void **)&c->d_bsk_latf})
@@ -964,7 +973,7 @@ int bmi_key_bytes(const bmi_ctx *c, uint64_t *bsk_bytes, uint64_t *ksk_bytes) {
         const u64 one = (u64)c->P.n * c->rows * (c->P.k + 1) * c->N * 8 * (c->t64() ? c->bsk_limbs() : 1);
         u64 copies = 0;
         for (const void *p : {(const void *)c->d_bsk, (const void *)c->d_bsk_lat, (const void *)c->d_bsk_fft, (const void *)c->d_bsk_latf,
-                              (const void *)c->d_bsk_w})
+                              (const void *)c->d_bsk_w, (const void *)c->d_bsk_w2})
             copies += p != nullptr;
         *bsk_bytes = one * copies + (c->have_bsk3 ? (u64)c->bsk3_words() * 8 * (c->t64() ? c->bsk_limbs() : 1) : 0);
     }
@@ -1260,7 +1269,14 @@ int bmi_blind_rotate_batch(bmi_ctx *c, const uint64_t *d_small, const uint32_t *
     // with wave-pair work, the throughput kernel beyond that (49-bit field: the exchange-once form).
     const bool latency = c->variant == 2 || (c->variant == 0 && count <= c->lat_threshold);
     int rc;
-    if (c->t64() && (c->wide() || c->quad())) {   // 2^64 torus at N = 2048 / 4096: one kernel (one workgroup per ciphertext) for every batch size
+    if (c->t64() && c->wide() && c->d_bsk_w2 && (c->variant == 1 || c->variant == 3 || (c->variant == 0 && count > 256))) {
+        // N = 2048, batches beyond one round of 256: two ciphertexts per workgroup sharing the key words (variants 1 / 3 pin it, 2 pins the
+        // one-ciphertext form below); the same words
+        rc = bmit::launch_blind_rotate_wide2(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_w2, c->d_tw_fq, d_out, count, c->P.n, c->bsk_prec,
+                                             c->P.bs_levels, c->P.bs_base_log, (hipStream_t)stream);
+        return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;
+    }
+    if (c->t64() && (c->wide() || c->quad())) {   // 2^64 torus at N = 2048 / 4096: one workgroup per ciphertext (N = 2048: up to 256 ciphertexts, see above)
         rc = (c->quad() ? bmit::launch_blind_rotate_quad : bmit::launch_blind_rotate_wide)(d_small, d_lut_ids, (const u64 *)c->d_luts, c->d_bsk_w, c->d_tw_fq, d_out, count, c->P.n,
                                             c->bsk_prec, c->P.bs_levels, c->P.bs_base_log, nullptr, (hipStream_t)stream);
         return rc ? fail(c, -2, std::string("blind_rotate launch: ") + hipGetErrorString((hipError_t)rc)) : 0;

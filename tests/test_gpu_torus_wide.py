@@ -174,3 +174,26 @@ def test_l2_shape_bit_exact():
         octx.close()
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("count", [257, 300, 601])
+def test_two_ciphertexts_per_workgroup_form_same_words(eng, ora, count):
+    """k_blind_rotate_w2_t64f (csrc/bmi_kernels_t64w2.hip: what auto dispatch runs beyond 256 ciphertexts; variants 1 / 3 pin it, 2 pins
+    the one-ciphertext form): the same words as the one-ciphertext kernel on every batch shape - odd batches (the last workgroup runs
+    one ciphertext twice), adversarial rows, skipped steps - and as the oracle"""
+    to, octx, _, _, sk_big = ora
+    tables, ids, tvs, msgs, sel, small = _batch(eng, count, 900 + count)
+    small[5] = small[4]
+    small[5, ::2] = 0                      # a pair whose ciphertexts skip different steps
+    eng.set_kernel_variant(2)
+    one = eng.blind_rotate_host(small, ids[sel])
+    eng.set_kernel_variant(0)
+    two = eng.blind_rotate_host(small, ids[sel])
+    assert np.array_equal(one, two)
+    for c in (1, 2, 3, 7):                 # pinned on small and odd batches as well
+        eng.set_kernel_variant(3)
+        got = eng.blind_rotate_host(small[:c], ids[sel][:c])
+        eng.set_kernel_variant(0)
+        assert np.array_equal(got, one[:c]), c
+    pick = np.array([0, 1, 2, 3, 4, 5, count - 1])
+    assert np.array_equal(two[pick], octx.blind_rotate(small[pick], tvs, sel[pick]))

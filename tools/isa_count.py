@@ -81,9 +81,9 @@ def demangle(names):
 
 def build(out_path):
     srcs = {"bmi_kernels_f64.hip": True, "bmi_kernels_t64.hip": True, "bmi_kernels_t64f.hip": True, "bmi_kernels_t64fu.hip": True,
-            "bmi_kernels_t64w.hip": True, "bmi_kernels_t64q.hip": True, "bmi_kernels_f64u.hip": False, "bmi_kernels_t64u.hip": False}   # True: max-ilp scheduler (csrc/Makefile)
+            "bmi_kernels_t64w.hip": True, "bmi_kernels_t64w2.hip": True, "bmi_kernels_t64q.hip": True, "bmi_kernels_f64u.hip": False, "bmi_kernels_t64u.hip": False}   # True: max-ilp scheduler (csrc/Makefile)
     want = ("k_blind_rotate_tpx49", "k_blind_rotate_t64", "k_blind_rotate_lat2_49", "k_blind_rotate_lat2u_49", "k_blind_rotate_lat_t64",
-            "k_blind_rotate_lat2u_t64", "k_blind_rotate_w_t64f", "k_blind_rotate_q_t64f")   # (substring match: the t64f / t64fu kernels are picked up by the t64 entries)
+            "k_blind_rotate_lat2u_t64", "k_blind_rotate_w_t64f", "k_blind_rotate_w2_t64f", "k_blind_rotate_q_t64f")   # (substring match: the t64f / t64fu kernels are picked up by the t64 entries)
     res = {}
     with tempfile.TemporaryDirectory() as td:
         for src, ilp in srcs.items():
