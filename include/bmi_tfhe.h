@@ -201,7 +201,9 @@ int bmi_sync(bmi_ctx *ctx, void *stream);
  * 5 = 2^64 torus only, bootstrap key at 48 bits in base 2^10 (the torus default): the wave-pair kernel whose exact limb
  *     products are carried by a folded 512-point complex FFT in f64 and rounded to the nearest integer (same words as 1 / 3,
  *     which pin the exact transform mod 2^49 - 720895; what auto picks for large batches on that key),
- * 6 = the same for the latency form (one workgroup per ciphertext; what auto and 2 pick on that key; 4 pins the exact transform). */
+ * 6 = the same for the latency form (one workgroup per ciphertext; what auto and 2 pick on that key; 4 pins the exact transform).
+ * 2^64 torus at N = 2048: auto = one workgroup per ciphertext up to 256 ciphertexts (2 pins it), two ciphertexts per workgroup sharing
+ *     the key words beyond (1 / 3 pin it); the same words.  N = 4096: one kernel. */
 int bmi_set_kernel_variant(bmi_ctx *ctx, int variant);
 
 /* 2^64 torus only, before keygen / import: precision the bootstrap key is stored at.  No transform exists mod 2^64, so the
