@@ -32,6 +32,9 @@ using fftq::static_for;
 using t64::f64_to_word;
 using t64::Scheme;
 
+#ifndef BMI_T64W2_LEVEL_AHEAD
+#define BMI_T64W2_LEVEL_AHEAD 0   // 1: a level's key words requested during the level before (A/B)
+#endif
 constexpr int WN = 2048, WLOG = 11;
 constexpr int WS = fftq::QUARTER;                // slots per quarter
 constexpr int W2_THREADS = 1024;
@@ -160,6 +163,10 @@ __global__ void __launch_bounds__(W2_THREADS)
         auto row_ptr = [&](int R) { return kth + (size_t)R * 2 * LIMBS * (WN / 2); };
         C y[2][4];
         static_for<0, 2>([&](auto B) { static_for<0, 4>([&](auto T) { y[B][T] = C{0.0, 0.0}; }); });
+        double2 kw[2][4];
+#if BMI_T64W2_LEVEL_AHEAD
+        static_for<0, 2>([&](auto CC) { static_for<0, 4>([&](auto T) { kw[CC][T] = row_ptr(CC * L)[T * WS]; }); });
+#endif
         static_for<0, L>([&](auto LEV) {
             constexpr int lev = LEV;
             {   // phase A
@@ -199,9 +206,10 @@ __global__ void __launch_bounds__(W2_THREADS)
                 double2 *tile = tiles + (size_t)wave * WS;     // wave = (ciphertext 2, component 2, quarter 4)
                 static_for<0, 4>([&](auto R4) { tile[R4 * 64 + lane] = double2{v[R4].r, v[R4].i}; });
             }
+#if !BMI_T64W2_LEVEL_AHEAD
             // this thread's key words of the level's two rows (component 0 / 1): they land under the barrier
-            double2 kw[2][4];
             static_for<0, 2>([&](auto CC) { static_for<0, 4>([&](auto T) { kw[CC][T] = row_ptr(CC * L + lev)[T * WS]; }); });
+#endif
             pin();
             __syncthreads();
             static_for<0, 2>([&](auto CC) {   // rows (component CC, this level)
@@ -220,6 +228,10 @@ __global__ void __launch_bounds__(W2_THREADS)
                 keep(y);
                 pin();
             });
+#if BMI_T64W2_LEVEL_AHEAD
+            if constexpr (lev + 1 < L)
+                static_for<0, 2>([&](auto CC) { static_for<0, 4>([&](auto T) { kw[CC][T] = row_ptr(CC * L + lev + 1)[T * WS]; }); });
+#endif
             __syncthreads();   // every thread has read this level's tiles: the next level (or the sums) may overwrite them
         });
         static_for<0, 2>([&](auto B) { dft4<true>(y[B]); });   // sum_t i^(-h t) Y_t in y[b][h]; conj W_h is applied by the inverse task
