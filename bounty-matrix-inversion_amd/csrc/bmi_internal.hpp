@@ -214,7 +214,7 @@ int launch_bsk_to_wide2(const u64 *std_polys, double *w2_polys, const double *g_
 int launch_blind_rotate_wide2(const u64 *small_cts, const uint32_t *lut_ids, const u64 *luts, const double *bsk_w2, const double *g_tw_q,
                               u64 *out, uint32_t count, uint32_t n, int prec, uint32_t levels, uint32_t base_log, hipStream_t s);
 // N = 2048 (bmi_kernels_t64w.hip, fft_quarter_f64.hpp): key at 46 bits of precision (two 23-bit limbs), one workgroup of 16
-// wavefronts per ciphertext for every batch size; key copy per (polynomial, limb) 1,024 complex words A_k / 2 in the order of the
+// wavefronts per ciphertext (auto dispatch: up to 256 ciphertexts; launch_blind_rotate_wide2 beyond); key copy per (polynomial, limb) 1,024 complex words A_k / 2 in the order of the
 // multiplying threads; tables fftq::QT_WORDS doubles; stat as in launch_blind_rotate_fft
 bool shape_supported_wide(int prec, uint32_t levels, uint32_t base_log);
 int launch_bsk_to_wide(const u64 *std_polys, double *w_polys, const double *g_tw_q, uint32_t n_polys, int prec, hipStream_t s);

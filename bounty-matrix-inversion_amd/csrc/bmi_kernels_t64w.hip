@@ -8,7 +8,7 @@
 // returns it exactly (a-priori bound 0.41 < 1/2 in the header; measured distance ~2^-12, bmi_fft_margin_host) - so the kernel's
 // words equal the oracle's integer arithmetic bit for bit (tests/test_gpu_torus_wide.py).
 //
-// One workgroup of 16 wavefronts per ciphertext, every batch size; a transform is split over FOUR wavefronts by the folded index
+// One workgroup of 16 wavefronts per ciphertext (what auto dispatch runs up to 256 ciphertexts; beyond: bmi_kernels_t64w2.hip); a transform is split over FOUR wavefronts by the folded index
 // mod 4 (quarters of 256 points, 4 complex points per lane, no LDS inside a quarter).  Per CMUX:
 //   A  8 l forward tasks (input polynomial c, level, quarter h) over the 16 wavefronts: rotate / decompose 512 coefficients of the
 //      accumulator (the oracle's integer rule), forward quarter -> tile (slot order, times W_h)
